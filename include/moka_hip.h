@@ -1,0 +1,132 @@
+/*
+ * moka_hip.h -- C ABI of the MI355X-native MokA adapter path (libmoka_hip.so).
+ *
+ * The library replaces the *adapter* arithmetic of the two reference layers
+ *   AVT  AudioVisualText/peft_hyper/tuners/lora.py:367-532        (Linear.forward, 3 modalities)
+ *   VT   VisualText/modified_peft/tuners/lora/layer.py:548-681    (Linear.forward, 2 modalities)
+ * and of their autograd backward (the reference has no hand-written backward).  The frozen
+ * base GEMM (lora.py:369, layer.py:580) stays on stock PyTorch-ROCm: these entry points take
+ * the base output / base input-gradient as an in/out operand and add the adapter term to it.
+ *
+ * Conventions
+ *   - plain C symbols, raw device pointers + sizes + hipStream_t; no torch types.
+ *   - every function returns 0 on success, a negative MOKA_E* code otherwise, never throws,
+ *     never exits; moka_last_error() returns a thread-local message for the last failure.
+ *   - all work is enqueued on `stream` (the caller's current stream); no internal
+ *     synchronisation, no default-stream use, no persistent device allocations: workspaces
+ *     are owned by the caller.  Entry points are re-entrant (activation checkpointing
+ *     re-runs the forward inside backward).
+ *   - token-major layouts: T = B*S flattened tokens, row-major, contiguous.
+ *       x  [T, d_in]  bf16      y / gy [T, d_out] bf16      dx [T, d_in] bf16
+ *       A_m [r, d_in] bf16 (lora_A{m}.weight / lora_A[name].weight)
+ *       Bw [d_out, r] bf16 (lora_B0.weight / lora_B['text'].weight)
+ *     rank-space tensors live in fp32 with a padded row of RP = moka_rank_pad(r) floats:
+ *       h, hp, g, dh [T, RP] fp32;  split-K partials [KS, T, RP] fp32.
+ *   - dtype: MOKA_BF16 (=0) is the only storage type implemented (fp32 accumulate).
+ *
+ * Unified routed formulation (oracle/moka_oracle.py):
+ *     h[t]  = s_in * x[t] A[mod(t)]^T                 (0 when mod(t) == MOKA_MOD_NONE)
+ *     K_b   = rows kpos[b][0..klen[b]) of h  (kpos == -1: zero row that still enters the softmax)
+ *     hp[t] = h[t] + w * softmax(h[t] K_b^T * inv_sqrt_dk) K_b    for query rows
+ *             (query row: mod(t) in 1..M-1 and klen[b] > 0), hp[t] = h[t] otherwise
+ *     y[t] += s_out[mod(t)] * hp[t] Bw^T
+ *   AVT: s_in = lora_alpha/r0, s_out = {1,1,1}, w = blc_weight, inv_sqrt_dk = 1/sqrt(r0)
+ *   VT : s_in = 1, s_out = {scaling['text'], scaling['image']}, w = attn_weight, 1/sqrt(r)
+ */
+#ifndef MOKA_HIP_H
+#define MOKA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef MOKA_STREAM_T
+#define MOKA_STREAM_T
+typedef void* moka_stream_t;            /* hipStream_t */
+#endif
+
+#define MOKA_VERSION      100            /* 0.1.0 */
+#define MOKA_MAX_MOD      3
+#define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
+#define MOKA_BF16         0
+
+#define MOKA_OK           0
+#define MOKA_EINVAL      -1             /* bad argument (shape, alignment, unsupported size) */
+#define MOKA_EDTYPE      -2             /* unsupported storage dtype */
+#define MOKA_ELAUNCH     -3             /* HIP launch failure */
+#define MOKA_ENODEV      -4             /* no gfx950 device */
+
+/* Token routing of one batch, all device pointers (built once per batch, reused by the
+ * 224 adapter calls of a forward; replaces the per-call nonzero()/where() host syncs of
+ * layer.py:603-667 and lora.py:489/:512). */
+typedef struct moka_routing {
+    const uint8_t* tok_mod;   /* [>= round_up(T,64)] modality id 0..M-1, MOKA_MOD_NONE otherwise;
+                                 entries past T must be MOKA_MOD_NONE */
+    const int32_t* kpos;      /* [B, Lk_max] key positions inside the sample, -1 = zero key row */
+    const int32_t* klen;      /* [B] number of key slots (0: sample has no interaction) */
+    int32_t B, S, Lk_max, M;
+} moka_routing;
+
+int         moka_version(void);
+const char* moka_last_error(void);
+/* 0 when a gfx950 device is current, MOKA_ENODEV otherwise. */
+int         moka_device_check(void);
+
+/* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
+int moka_rank_pad(int r);
+/* Number of split-K partial slices moka_down_fwd (C = d_in, M = n modalities) or
+ * moka_up_bwd (C = d_out, M = 1) writes for width C.  The caller sizes the partial
+ * buffer as ks * T * RP floats. */
+int moka_ksplit(int C, int r, int M);
+
+/* ---- forward ----------------------------------------------------------------------- */
+
+/* Per-modality masked down-projection  h_part[s][t] = partial over d_in slice s of
+ * s_in * x[t] A[mod(t)]^T.  Replaces lora.py:468-477 (3 dense masked GEMMs) and
+ * layer.py:603-621 (gather + GEMM + index_put).  Tokens with MOKA_MOD_NONE are skipped
+ * (their partial rows are left unwritten; consumers treat them as zero). */
+int moka_down_fwd(const void* x, const void* const* A /*host array of M device ptrs*/,
+                  const uint8_t* tok_mod, float* h_part,
+                  int T, int d_in, int r, int M, float s_in, int dtype, moka_stream_t stream);
+
+/* Rank-r cross-modal interaction: sums the ks partials into h, then
+ * hp = h + w * softmax(h K^T * inv_sqrt_dk) K for query rows.  Replaces the per-sample
+ * Python loops lora.py:485-521 / layer.py:627-653.  h and hp are both written ([T,RP]). */
+int moka_cross_fwd(const float* h_part, int ks, const moka_routing* rt,
+                   float* h, float* hp, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+
+/* Shared up-projection + residual add  y[t] += s_out[mod(t)] * hp[t] Bw^T  (in place on the
+ * base output).  Replaces lora.py:524-530 and layer.py:656-669 (gather, GEMM, scatter-add). */
+int moka_up_fwd(const float* hp, const void* Bw, const uint8_t* tok_mod,
+                const float* s_out /*host, M floats*/, void* y_inout,
+                int T, int r, int d_out, int M, int dtype, moka_stream_t stream);
+
+/* ---- backward ---------------------------------------------------------------------- */
+
+/* One pass over gy:  g_part[s][t] = partial over d_out slice s of s_out[mod(t)] * gy[t] Bw
+ * and dB_acc[o][k] += sum_t s_out[mod(t)] * gy[t][o] * hp[t][k]  (fp32 accumulate, the
+ * caller zeroes / owns dB_acc [d_out, r]). */
+int moka_up_bwd(const void* gy, const float* hp, const void* Bw, const uint8_t* tok_mod,
+                const float* s_out /*host*/, float* g_part, float* dB_acc,
+                int T, int r, int d_out, int M, int dtype, moka_stream_t stream);
+
+/* Backward of the cross-modal interaction: sums the ks partials of g (= dL/dhp) and
+ * produces dh = dL/dh [T,RP] (softmax backward for query rows, key/value gradients
+ * scattered back onto the question rows). */
+int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routing* rt,
+                   float* dh, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+
+/* dA_acc[m][k][c] += s_in * sum_{t: mod(t)=m} dh[t][k] x[t][c]   (fp32 accumulate) and
+ * dx[t] += s_in * dh[t] A[mod(t)]   (in place on the base input-gradient gy W). */
+int moka_down_bwd(const float* dh, const void* x, const void* const* A /*host array*/,
+                  const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
+                  void* dx_inout /* may be NULL: skip dx */,
+                  int T, int d_in, int r, int M, float s_in, int dtype, moka_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOKA_HIP_H */

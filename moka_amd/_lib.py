@@ -1,0 +1,90 @@
+"""ctypes binding of libmoka_hip.so (the C ABI declared in include/moka_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``python -m moka_amd.build``.
+There is NO fallback: if the shared object is missing, or the current device is not a
+gfx950, every compute entry point raises -- a silent eager path would void the parity and
+performance claims of this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoka_hip.so")
+
+MOKA_BF16 = 0
+MOKA_MOD_NONE = 255
+MOKA_MAX_MOD = 3
+
+
+class MokaRoutingStruct(Structure):
+    _fields_ = [("tok_mod", c_void_p), ("kpos", c_void_p), ("klen", c_void_p),
+                ("B", c_int32), ("S", c_int32), ("Lk_max", c_int32), ("M", c_int32)]
+
+
+class MokaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list EVERY symbol include/moka_hip.h declares
+SYMBOLS = {
+    "moka_version": (c_int, []),
+    "moka_last_error": (c_char_p, []),
+    "moka_device_check": (c_int, []),
+    "moka_rank_pad": (c_int, [c_int]),
+    "moka_ksplit": (c_int, [c_int, c_int, c_int]),
+    "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
+                              c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "moka_cross_fwd": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), c_void_p, c_void_p,
+                               c_int, c_float, c_float, c_void_p]),
+    "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "moka_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_void_p,
+                               c_int, c_float, c_float, c_void_p]),
+    "moka_down_bwd": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
+                              c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+}
+
+
+def load():
+    """Load the shared library (once).  Raises MokaError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MokaError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). moka_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().moka_last_error().decode("utf-8", "replace")
+        raise MokaError(f"{what or 'moka'} failed with code {rc}: {msg}")
+
+
+def rank_pad(r: int) -> int:
+    rp = load().moka_rank_pad(int(r))
+    if rp < 0:
+        raise ValueError(f"`r` should be an integer in 1..64 for the HIP path but the value passed is {r}")
+    return rp
+
+
+def ksplit(C: int, r: int, M: int) -> int:
+    ks = load().moka_ksplit(int(C), int(r), int(M))
+    if ks < 0:
+        raise ValueError(f"unsupported shape for the HIP path: width={C} r={r} M={M}")
+    return ks

@@ -1,0 +1,190 @@
+"""Host glue between torch tensors and the C ABI (include/moka_hip.h).
+
+``ops`` are thin 1:1 wrappers of the exported entry points (pointer extraction, workspace
+allocation, current-stream lookup); ``MokaLinearFn`` is the autograd node of one adapted
+projection: frozen base GEMM on stock PyTorch-ROCm + the MokA adapter on the HIP kernels,
+with the explicit backward the reference leaves to autograd.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, byref, c_float, c_void_p
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .routing import MokaRouting
+
+
+def _stream_ptr(device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_device(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.MokaError(
+            f"moka_amd: `{name}` lives on {t.device}; the MokA adapter path only exists as HIP kernels for "
+            "MI355X (gfx950) -- there is no CPU fallback (use oracle/ for CPU checking).")
+
+
+def _require_bf16(t: torch.Tensor, name: str):
+    if t.dtype != torch.bfloat16:
+        raise _lib.MokaError(f"moka_amd: `{name}` is {t.dtype}; the HIP path stores activations and weights in bf16")
+
+
+def _ptrs(tensors: Sequence[torch.Tensor]):
+    arr = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def _floats(vals: Sequence[float]):
+    return (c_float * len(vals))(*[float(v) for v in vals])
+
+
+# --------------------------------------------------------------------------------------
+# 1:1 wrappers of the C entry points
+# --------------------------------------------------------------------------------------
+def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float) -> torch.Tensor:
+    """x2 [T,d_in] bf16 -> h_part [ks,T,RP] fp32."""
+    lib = _lib.load()
+    T, d_in = x2.shape
+    M = len(A)
+    RP = _lib.rank_pad(r)
+    ks = _lib.ksplit(d_in, r, M)
+    h_part = torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device)
+    _lib.check(lib.moka_down_fwd(x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(), h_part.data_ptr(),
+                                 T, d_in, r, M, float(s_in), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_fwd")
+    return h_part
+
+
+def cross_fwd(h_part: torch.Tensor, rt: MokaRouting, r: int, w: float, inv_sqrt_dk: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    ks, T, RP = h_part.shape
+    h = torch.empty((T, RP), dtype=torch.float32, device=h_part.device)
+    hp = torch.empty((T, RP), dtype=torch.float32, device=h_part.device)
+    _lib.check(lib.moka_cross_fwd(h_part.data_ptr(), ks, byref(rt.struct), h.data_ptr(), hp.data_ptr(),
+                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(h_part.device)), "moka_cross_fwd")
+    return h, hp
+
+
+def up_fwd_(y2: torch.Tensor, hp: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float]):
+    """In place: y2 [T,d_out] bf16 += s_out[mod] * hp Bw^T."""
+    lib = _lib.load()
+    T, d_out = y2.shape
+    _lib.check(lib.moka_up_fwd(hp.data_ptr(), Bw.data_ptr(), rt.tok_mod.data_ptr(), _floats(s_out), y2.data_ptr(),
+                               T, r, d_out, len(s_out), _lib.MOKA_BF16, _stream_ptr(y2.device)), "moka_up_fwd")
+    return y2
+
+
+def up_bwd(gy2: torch.Tensor, hp: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float],
+           dB_acc: Optional[torch.Tensor]) -> torch.Tensor:
+    """gy2 [T,d_out] bf16 -> g_part [ks,T,RP]; dB_acc [d_out,r] fp32 += (may be None: skip)."""
+    lib = _lib.load()
+    T, d_out = gy2.shape
+    RP = _lib.rank_pad(r)
+    ks = _lib.ksplit(d_out, r, 1)
+    g_part = torch.empty((ks, T, RP), dtype=torch.float32, device=gy2.device)
+    _lib.check(lib.moka_up_bwd(gy2.data_ptr(), hp.data_ptr(), Bw.data_ptr(), rt.tok_mod.data_ptr(), _floats(s_out),
+                               g_part.data_ptr(), None if dB_acc is None else dB_acc.data_ptr(),
+                               T, r, d_out, len(s_out), _lib.MOKA_BF16, _stream_ptr(gy2.device)), "moka_up_bwd")
+    return g_part
+
+
+def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, w: float, inv_sqrt_dk: float) -> torch.Tensor:
+    lib = _lib.load()
+    ks, T, RP = g_part.shape
+    dh = torch.empty((T, RP), dtype=torch.float32, device=g_part.device)
+    _lib.check(lib.moka_cross_bwd(g_part.data_ptr(), ks, h.data_ptr(), byref(rt.struct), dh.data_ptr(),
+                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(g_part.device)), "moka_cross_bwd")
+    return dh
+
+
+def down_bwd_(dh: torch.Tensor, x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float,
+              dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor]):
+    """dA_acc[m] [r,d_in] fp32 += ; dx2 [T,d_in] bf16 += (either may be None)."""
+    lib = _lib.load()
+    T, d_in = x2.shape
+    M = len(A)
+    _lib.check(lib.moka_down_bwd(dh.data_ptr(), x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(),
+                                 None if dA_acc is None else _ptrs(dA_acc),
+                                 None if dx2 is None else dx2.data_ptr(),
+                                 T, d_in, r, M, float(s_in), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_bwd")
+
+
+# --------------------------------------------------------------------------------------
+# autograd node of one adapted projection
+# --------------------------------------------------------------------------------------
+class AdapterSpec:
+    """Static description of one adapted projection (what varies between AVT and VT)."""
+
+    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk")
+
+    def __init__(self, r: int, s_in: float, s_out: Sequence[float], w: float, inv_sqrt_dk: float):
+        self.r, self.s_in, self.s_out, self.w, self.inv_sqrt_dk = int(r), float(s_in), [float(s) for s in s_out], float(w), float(inv_sqrt_dk)
+
+
+class MokaLinearFn(torch.autograd.Function):
+    """y = x W^T (+ bias) + adapter(x).  Inputs: x, W, bias|None, Bw, A_0..A_{M-1}.
+
+    Forward: base GEMM (hipBLASLt through torch), then three launches -- down-projection,
+    cross-modal interaction, up-projection with the residual add done in place on the base
+    output.  Backward: base input-gradient GEMM (frozen W: no dW), then one pass over gy
+    (dB + dL/dhp), the rank-space backward, and one pass over x / dx (dA_m, dx += dh A_m).
+    Saves x, h, hp; nothing else (the softmax is recomputed in rank space).
+    """
+
+    @staticmethod
+    def forward(ctx, x, W, bias, Bw, rt: MokaRouting, spec: AdapterSpec, *A):
+        _require_device(x, "x")
+        for n, t_ in (("x", x), ("base weight", W), ("lora_B", Bw)):
+            _require_bf16(t_, n)
+        for a in A:
+            _require_bf16(a, "lora_A")
+        d_in = x.shape[-1]
+        x2 = x.reshape(-1, d_in)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        if x2.shape[0] != rt.T:
+            raise ValueError(f"x has {x2.shape[0]} tokens but the masks describe {rt.T}")
+        y = torch.nn.functional.linear(x2, W, bias)                   # frozen base, stock PyTorch-ROCm
+        A = [a if a.is_contiguous() else a.contiguous() for a in A]
+        Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
+        h_part = down_fwd(x2, A, rt, spec.r, spec.s_in)
+        h, hp = cross_fwd(h_part, rt, spec.r, spec.w, spec.inv_sqrt_dk)
+        up_fwd_(y, hp, Bw_c, rt, spec.r, spec.s_out)
+        ctx.save_for_backward(x2, W, Bw_c, h, hp, *A)
+        ctx.rt, ctx.spec, ctx.x_shape, ctx.has_bias = rt, spec, x.shape, bias is not None
+        return y.reshape(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, W, Bw, h, hp, *A = ctx.saved_tensors
+        rt, spec = ctx.rt, ctx.spec
+        r = spec.r
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        need_B = ctx.needs_input_grad[3]
+        need_A = any(ctx.needs_input_grad[6:])
+        dB_acc = torch.zeros((Bw.shape[0], r), dtype=torch.float32, device=gy2.device) if need_B else None
+        g_part = up_bwd(gy2, hp, Bw, rt, r, spec.s_out, dB_acc)
+        dh = cross_bwd(g_part, h, rt, r, spec.w, spec.inv_sqrt_dk)
+        dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
+        dA_acc = [torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=gy2.device) for _ in A] if need_A else None
+        if need_A or need_x:
+            down_bwd_(dh, x2, A, rt, r, spec.s_in, dA_acc, dx2)
+        gbias = gy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gW = None
+        if ctx.needs_input_grad[1]:
+            raise _lib.MokaError("moka_amd: the base weight is frozen in MokA; requires_grad on it is not supported")
+        gA = [None] * len(A)
+        if need_A:
+            gA = [dA_acc[m].to(A[m].dtype) if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
+        return (None if dx2 is None else dx2.reshape(ctx.x_shape), gW, gbias,
+                None if dB_acc is None else dB_acc.to(Bw.dtype), None, None, *gA)
+
+
+def moka_linear(x, W, bias, Bw, A: Sequence[torch.Tensor], rt: MokaRouting, spec: AdapterSpec):
+    return MokaLinearFn.apply(x, W, bias, Bw, rt, spec, *A)

@@ -1,0 +1,155 @@
+"""Token routing: the reference's masks compiled ONCE per batch into the index data the HIP
+kernels consume (``moka_routing`` in include/moka_hip.h).
+
+The reference re-derives indices from the masks inside every one of the 224 adapter calls
+of a forward, with ~10 host syncs per call (VT ``layer.py:603-667``: ``.any()``,
+``.nonzero()``, ``torch.where``; AVT ``lora.py:489,512``: ``torch.where`` per sample).  Here
+the masks are turned into ``tok_mod`` / ``kpos`` / ``klen`` on the device with a single
+host read-back per batch (needed for the key-block size and to raise the reference's
+errors), and the result is cached on the identity of the mask tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+MOD_NONE = _lib.MOKA_MOD_NONE
+
+
+class MokaRouting:
+    """Device-resident routing of one batch.  ``struct`` is the C view passed to the library."""
+
+    def __init__(self, tok_mod: torch.Tensor, kpos: torch.Tensor, klen: torch.Tensor,
+                 B: int, S: int, Lk_max: int, M: int):
+        self.tok_mod, self.kpos, self.klen = tok_mod, kpos, klen
+        self.B, self.S, self.Lk_max, self.M = B, S, Lk_max, M
+        self.T = B * S
+        self.struct = _lib.MokaRoutingStruct(tok_mod.data_ptr(), kpos.data_ptr(), klen.data_ptr(), B, S, Lk_max, M)
+
+    @property
+    def device(self):
+        return self.tok_mod.device
+
+    # ------------------------------------------------------------------ constructors
+    @staticmethod
+    def _pad_tok_mod(tok_mod_bs: torch.Tensor) -> torch.Tensor:
+        T = tok_mod_bs.numel()
+        Tpad = (T + 63) // 64 * 64 + 64
+        out = torch.full((Tpad,), MOD_NONE, dtype=torch.uint8, device=tok_mod_bs.device)
+        out[:T] = tok_mod_bs.reshape(-1)
+        return out
+
+    @classmethod
+    def from_avt_masks(cls, modality_mask: Sequence[torch.Tensor]) -> "MokaRouting":
+        """[text, video, audio, question] masks, {0,1}, shape [B,L,1] or [B,L]
+        (AVT ``unified_arch.py:159-240`` builds them, ``lora.py:462-521`` consumes them).
+        Keys = contiguous span first..last question token (``lora.py:489-491``), a key row is
+        non-zero only where the token is question AND text (``lora.py:482``).
+        Raises IndexError when a sample has no question token, as ``lora.py:489-490`` does."""
+        t, v, a, q = [(m.reshape(m.shape[0], m.shape[1]) == 1) for m in modality_mask[:4]]
+        B, S = t.shape
+        dev = t.device
+        tok = torch.full((B, S), MOD_NONE, dtype=torch.uint8, device=dev)
+        tok[t] = 0
+        tok[v] = 1
+        tok[a] = 2
+        idx = torch.arange(S, device=dev).expand(B, S)
+        first = torch.where(q, idx, S).min(dim=1).values
+        last = torch.where(q, idx, -1).max(dim=1).values
+        klen = (last - first + 1)
+        overlap = ((t.int() + v.int() + a.int()) > 1).any()
+        stats = torch.stack([overlap.int(), (klen <= 0).any().int(), klen.max().int()]).tolist()   # the one sync
+        if stats[1]:
+            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+        if stats[0]:
+            raise ValueError("modality masks overlap: a token belongs to more than one modality")
+        Lk = int(stats[2])
+        kp = first[:, None] + torch.arange(Lk, device=dev)[None, :]
+        inside = kp <= last[:, None]
+        kpc = kp.clamp(max=S - 1)
+        valid = inside & q.gather(1, kpc) & t.gather(1, kpc)
+        kpos = torch.where(valid, kp, -1).to(torch.int32).contiguous()
+        return cls(cls._pad_tok_mod(tok), kpos, klen.to(torch.int32).contiguous(), B, S, Lk, 3)
+
+    @classmethod
+    def from_vt_masks(cls, text_mask: torch.Tensor, image_mask: torch.Tensor,
+                      question_mask: torch.Tensor) -> "MokaRouting":
+        """bool [B,S] masks (VT ``train.py:206-231``; consumed at ``layer.py:594-669``).
+        Keys = exact question index set; a sample without image or question tokens has no
+        interaction (``layer.py:630-637``)."""
+        B, S = text_mask.shape[0], text_mask.shape[1]
+        t = (text_mask.reshape(B, S) == 1)
+        i = (image_mask.reshape(B, S) == 1)
+        q = (question_mask.reshape(B, S) == 1)
+        dev = t.device
+        tok = torch.full((B, S), MOD_NONE, dtype=torch.uint8, device=dev)
+        tok[t] = 0
+        tok[i] = 1
+        klen = torch.where(i.any(dim=1), q.sum(dim=1), 0)
+        overlap = (t & i).any()
+        stats = torch.stack([overlap.int(), klen.max().int()]).tolist()                           # the one sync
+        if stats[0]:
+            raise ValueError("text and image masks overlap")
+        Lk = int(stats[1])
+        order = torch.sort((~q).to(torch.uint8), dim=1, stable=True).indices[:, :Lk]
+        live = torch.arange(Lk, device=dev)[None, :] < klen[:, None]
+        kpos = torch.where(live, order, -1).to(torch.int32).contiguous()
+        if Lk == 0:
+            kpos = torch.full((B, 1), -1, dtype=torch.int32, device=dev)
+        return cls(cls._pad_tok_mod(tok), kpos, klen.to(torch.int32).contiguous(), B, S, Lk, 2)
+
+    @classmethod
+    def plain(cls, B: int, S: int, device, M: int = 1) -> "MokaRouting":
+        """Masks None (decode step): every token goes through the text adapter, no interaction
+        (AVT ``lora.py:373-381``, VT ``layer.py:672-678``)."""
+        tok = torch.zeros((B, S), dtype=torch.uint8, device=device)
+        kpos = torch.full((B, 1), -1, dtype=torch.int32, device=device)
+        klen = torch.zeros((B,), dtype=torch.int32, device=device)
+        return cls(cls._pad_tok_mod(tok), kpos, klen, B, S, 0, M)
+
+
+class RoutingCache:
+    """Routing keyed on the identity (storage pointer, shape, version) of the mask tensors: the
+    decoder passes the very same mask objects to all 7 x n_layers projections of a forward."""
+
+    def __init__(self, capacity: int = 8):
+        self.capacity = capacity
+        self._items: List[tuple] = []
+
+    @staticmethod
+    def _key(kind: str, masks: Sequence[torch.Tensor]):
+        return (kind,) + tuple((m.data_ptr(), tuple(m.shape), m._version, m.dtype) for m in masks)
+
+    def get(self, kind: str, masks: Sequence[torch.Tensor]) -> MokaRouting:
+        key = self._key(kind, masks)
+        for k, rt, _keep in self._items:
+            if k == key:
+                return rt
+        if kind == "avt":
+            rt = MokaRouting.from_avt_masks(masks)
+        elif kind == "vt":
+            rt = MokaRouting.from_vt_masks(*masks)
+        else:
+            raise ValueError(kind)
+        self._items.append((key, rt, list(masks)))     # keep the masks alive so data_ptr stays unique
+        if len(self._items) > self.capacity:
+            self._items.pop(0)
+        return rt
+
+    def plain(self, B: int, S: int, device, M: int) -> MokaRouting:
+        key = ("plain", B, S, str(device), M)
+        for k, rt, _keep in self._items:
+            if k == key:
+                return rt
+        rt = MokaRouting.plain(B, S, device, M)
+        self._items.append((key, rt, None))
+        if len(self._items) > self.capacity:
+            self._items.pop(0)
+        return rt
+
+
+GLOBAL_ROUTING_CACHE = RoutingCache()

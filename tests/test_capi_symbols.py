@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/moka_hip.h
+declares; host-side argument validation returns error codes without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from moka_amd import build, _lib
+    build.build(verbose=False)          # hipcc cross-compiles without a GPU; no-op when up to date
+    return _lib.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "moka_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(moka_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from moka_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 11
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in moka_hip.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype"
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_version_and_rank_pad(lib):
+    assert lib.moka_version() == 100
+    assert [lib.moka_rank_pad(r) for r in (1, 4, 8, 16, 17, 32, 33, 64)] == [16, 16, 16, 16, 32, 32, 64, 64]
+    assert lib.moka_rank_pad(0) < 0 and lib.moka_rank_pad(65) < 0
+
+
+def test_ksplit_covers_width(lib):
+    for C, r, M in [(4096, 16, 3), (11008, 16, 3), (4096, 16, 1), (11008, 16, 1), (64, 4, 3), (5120, 64, 3), (8192, 16, 2), (28672, 16, 3)]:
+        ks = lib.moka_ksplit(C, r, M)
+        assert 1 <= ks <= 64
+    assert lib.moka_ksplit(16, 16, 3) < 0
+    assert lib.moka_ksplit(4096, 16, 4) < 0
+
+
+def test_argument_validation_sets_error_message(lib):
+    dummy = ctypes.c_void_p(64)
+    arr = (ctypes.c_void_p * 1)(64)
+    # unsupported dtype
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 1, None)
+    assert rc == -2 and b"bf16" in lib.moka_last_error()
+    # width not a multiple of 32
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0, None)
+    assert rc == -1 and b"multiple of 32" in lib.moka_last_error()
+    # rank out of range
+    rc = lib.moka_up_fwd(dummy, dummy, dummy, (ctypes.c_float * 1)(1.0), dummy, 16, 65, 64, 1, 0, None)
+    assert rc == -1 and b"rank" in lib.moka_last_error()
+    # null pointer
+    rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0, None)
+    assert rc == -1 and b"null" in lib.moka_last_error()
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from moka_amd import _lib
+    from moka_amd.functional import AdapterSpec, moka_linear
+    if torch.cuda.is_available():
+        pytest.skip("runs on the CPU-only container")
+    x = torch.zeros(1, 4, 64, dtype=torch.bfloat16)
+    with pytest.raises(_lib.MokaError):
+        moka_linear(x, torch.zeros(64, 64, dtype=torch.bfloat16), None, torch.zeros(64, 4, dtype=torch.bfloat16),
+                    [torch.zeros(4, 64, dtype=torch.bfloat16)], None, AdapterSpec(4, 1.0, [1.0], 0.0, 0.5))
