@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Benchmark of the MokA adapter hot path on MI355X (contract: see the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seq S]
+
+One "step" = one pass of the hot path over one batch: adapter forward + backward of all
+7 x 32 adapted projections of Llama-2-7B (r = 16, 3 modalities, AVT semantics) on B synthetic
+sequences of 2048 tokens per GPU (SURVEY.md 8(d) layout: 16 text | 256 image | 16 text |
+128 audio | 64 question | text), then the data-parallel step on the adapter gradients
+(bucketed RCCL all-reduce of the flat fp32 gradient buffer on a side stream, launched as soon as
+a group of layers has finished its backward and overlapped with the backward of the remaining
+layers) and a fused AdamW update of the adapter parameters.  The frozen base GEMMs
+are NOT part of the hot path (they run on stock PyTorch-ROCm); their outputs / input
+gradients are the in/out operands of the kernels and are resident in HBM before the clock
+starts.
+
+Prints ONE JSON line on rank 0 (metric of BASELINE.json, `roofline` for the dominant kernel,
+`cpu_baseline` = the oracle port on the host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+from ctypes import byref, c_float, c_void_p
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+LLAMA7B = dict(d=4096, ff=11008, layers=32)
+# the 7 adapted projections of one decoder layer in the reference's call order
+# (AudioVisualText/models/modeling_llama.py:326-328,384,222-224): name, d_in, d_out, input id
+PROJS = [("q_proj", "d", "d", "hid"), ("k_proj", "d", "d", "hid"), ("v_proj", "d", "d", "hid"),
+         ("o_proj", "d", "d", "attn"), ("gate_proj", "d", "ff", "hid2"), ("up_proj", "d", "ff", "hid2"),
+         ("down_proj", "ff", "d", "act")]
+E = 2  # bytes per bf16
+
+
+def algorithmic_bytes_per_token(d, ff, r, layers):
+    """fwd E(d_in + 2 d_out + 2r), bwd E(d_out + 3 d_in + 3r) per projection."""
+    fwd = bwd = 0
+    for _, di, do, _ in PROJS:
+        di = d if di == "d" else ff
+        do = d if do == "d" else ff
+        fwd += E * (di + 2 * do + 2 * r)
+        bwd += E * (do + 3 * di + 3 * r)
+    return fwd * layers, bwd * layers
+
+
+class Proj:
+    """One adapted projection: device buffers + pre-built ctypes arguments for the six launches."""
+
+    def __init__(self, lib, name, d_in, d_out, r, M, T, bufs, params, grads, ws, rt, s_in, s_out, w, c):
+        from moka_amd import _lib
+        self.name, self.d_in, self.d_out = name, d_in, d_out
+        RP = _lib.rank_pad(r)
+        self.ks_in = _lib.ksplit(d_in, r, M)
+        self.ks_out = _lib.ksplit(d_out, r, 1)
+        x, y, dx = bufs
+        A, Bw = params
+        dA, dB = grads
+        self.keep = (x, y, dx, A, Bw, dA, dB)
+        h_part, h, hp, g_part, dh = ws
+        Ap = (c_void_p * M)(*[a.data_ptr() for a in A])
+        dAp = (c_void_p * M)(*[a.data_ptr() for a in dA])
+        so = (c_float * M)(*s_out)
+        self._c = (Ap, dAp, so)
+        tm = rt.tok_mod.data_ptr()
+        self.f1 = (x.data_ptr(), Ap, tm, h_part.data_ptr(), T, d_in, r, M, s_in, 0)
+        self.f2 = (h_part.data_ptr(), self.ks_in, byref(rt.struct), h.data_ptr(), hp.data_ptr(), r, w, c)
+        self.f3 = (hp.data_ptr(), Bw.data_ptr(), tm, so, y.data_ptr(), T, r, d_out, M, 0)
+        self.b1 = (y.data_ptr(), hp.data_ptr(), Bw.data_ptr(), tm, so, g_part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
+        self.b2 = (g_part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), dh.data_ptr(), r, w, c)
+        self.b3 = (dh.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, s_in, 0)
+
+
+def build_workload(args, dev, lib, bucket_factory):
+    from moka_amd import _lib
+    from moka_amd.routing import MokaRouting
+    from oracle import cases as C
+    B, S, r, M = args.batch, args.seq, args.rank, 3
+    d, ff, L = LLAMA7B["d"], LLAMA7B["ff"], args.layers
+    T = B * S
+    g = torch.Generator(device="cpu").manual_seed(42 + args.rank_id)
+    tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
+    masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
+    rt = MokaRouting.from_avt_masks(masks)
+    RP = _lib.rank_pad(r)
+    bf = torch.bfloat16
+
+    # flat parameter / gradient buckets (fp32 master, bf16 working copy, fp32 grads x2 for overlap)
+    per_layer = sum(M * r * (d if di == "d" else ff) + r * (d if do == "d" else ff) for _, di, do, _ in PROJS)
+    n_params = per_layer * L
+    bucket = bucket_factory(n_params, [per_layer * (l + 1) for l in range(L)])
+    gbuf = bucket.flat
+    master = torch.empty(n_params, dtype=torch.float32, device=dev)
+    work = torch.empty(n_params, dtype=bf, device=dev)
+
+    # activation buffers: `args.distinct` layer sets cycled (each set >> 256 MiB Infinity Cache)
+    nset = max(1, min(L, args.distinct))
+    sets = []
+    for _ in range(nset):
+        acts = {"hid": torch.randn(T, d, device=dev, dtype=bf), "attn": torch.randn(T, d, device=dev, dtype=bf),
+                "hid2": torch.randn(T, d, device=dev, dtype=bf), "act": torch.randn(T, ff, device=dev, dtype=bf)}
+        ys = [torch.randn(T, d if do == "d" else ff, device=dev, dtype=bf) for _, _, do, _ in PROJS]
+        dxs = [torch.randn(T, d if di == "d" else ff, device=dev, dtype=bf) for _, di, _, _ in PROJS]
+        sets.append((acts, ys, dxs))
+    max_ks = max(_lib.ksplit(ff, r, M), _lib.ksplit(ff, r, 1), _lib.ksplit(d, r, M))
+    ws = (torch.empty(max_ks, T, RP, dtype=torch.float32, device=dev), torch.empty(T, RP, dtype=torch.float32, device=dev),
+          torch.empty(T, RP, dtype=torch.float32, device=dev), torch.empty(max_ks, T, RP, dtype=torch.float32, device=dev),
+          torch.empty(T, RP, dtype=torch.float32, device=dev))
+    # per-layer h / hp must survive until the backward: one (h, hp) pair per projection
+    hh = [[(torch.empty(T, RP, dtype=torch.float32, device=dev), torch.empty(T, RP, dtype=torch.float32, device=dev))
+           for _ in PROJS] for _ in range(L)]
+
+    s = 16.0 / r
+    projs = []
+    layer_end = []
+    off = 0
+    bound = lambda n: 1.0 / math.sqrt(n)  # noqa: E731  kaiming_uniform(a=sqrt(5))
+    for l in range(L):
+        acts, ys, dxs = sets[l % nset]
+        for pi, (name, di, do, src) in enumerate(PROJS):
+            d_in = d if di == "d" else ff
+            d_out = d if do == "d" else ff
+            A, dA = [], []
+            for m in range(M):
+                n = r * d_in
+                master[off:off + n].uniform_(-bound(d_in), bound(d_in))
+                A.append(work[off:off + n].view(r, d_in))
+                dA.append(gbuf[off:off + n].view(r, d_in))
+                off += n
+            n = d_out * r
+            master[off:off + n].normal_(0, 0.02)
+            Bw = work[off:off + n].view(d_out, r)
+            dB = gbuf[off:off + n].view(d_out, r)
+            off += n
+            h, hp = hh[l][pi]
+            wsl = (ws[0], h, hp, ws[3], ws[4])
+            projs.append(Proj(lib, name, d_in, d_out, r, M, T, (acts[src], ys[pi], dxs[pi]), (A, Bw), (dA, dB), wsl, rt,
+                              s, [1.0] * M, 1.0, 1.0 / math.sqrt(r)))
+        layer_end.append(off)
+    assert off == n_params
+    work.copy_(master)
+    assert layer_end == bucket.layer_end
+    return dict(projs=projs, rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end,
+                keep=(sets, ws, hh, masks))
+
+
+def run_forward(lib, wl, sp):
+    for p in wl["projs"]:
+        rc = lib.moka_down_fwd(*p.f1, sp) or lib.moka_cross_fwd(*p.f2, sp) or lib.moka_up_fwd(*p.f3, sp)
+        if rc:
+            raise RuntimeError(lib.moka_last_error().decode())
+
+
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None):
+    """Reverse layer order; `on_layer_done(l)` fires after layer l's launches are enqueued."""
+    projs = wl["projs"]
+    per = len(PROJS)
+    for l in range(n_layers - 1, -1, -1):
+        for p in reversed(projs[l * per:(l + 1) * per]):
+            rc = lib.moka_up_bwd(*p.b1, sp) or lib.moka_cross_bwd(*p.b2, sp) or lib.moka_down_bwd(*p.b3, sp)
+            if rc:
+                raise RuntimeError(lib.moka_last_error().decode())
+        if on_layer_done is not None:
+            on_layer_done(l)
+
+
+def time_kernels(lib, wl, stream_ptr, iters=2):
+    """Per-entry-point launch durations with HIP events on the launch stream (torch's current
+    stream IS the stream the kernels are launched on)."""
+    names = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
+    tot = {n: 0.0 for n in names}
+    cnt = {n: 0 for n in names}
+    per_shape = {}
+    evs = []
+    for _ in range(iters):
+        for pr in wl["projs"]:
+            p = pr
+            for n, a in zip(names, (p.f1, p.f2, p.f3, p.b1, p.b2, p.b3)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = getattr(lib, n)(*a, stream_ptr)
+                e1.record()
+                assert rc == 0
+                evs.append((n, p.d_in, p.d_out, e0, e1))
+    torch.cuda.synchronize()
+    for n, di, do, e0, e1 in evs:
+        ms = e0.elapsed_time(e1)
+        tot[n] += ms
+        cnt[n] += 1
+        key = (n, di, do)
+        a, b = per_shape.get(key, (0.0, 0))
+        per_shape[key] = (a + ms, b + 1)
+    return tot, cnt, per_shape
+
+
+def cpu_baseline(args):
+    """The oracle port (torch fp32, all host cores) on a bounded sample: adapter fwd+bwd of ONE
+    decoder layer's 7 projections for ONE sequence, scaled to the 32 layers."""
+    from oracle import cases as C
+    from oracle import moka_oracle as O
+    S, r = args.seq, args.rank
+    d, ff = LLAMA7B["d"], LLAMA7B["ff"]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    masks = [(tok == m).to(torch.int32).reshape(1, S, 1) for m in range(3)] + [q.to(torch.int32).reshape(1, S, 1)]
+    rt = O.routing_from_avt_masks(masks)
+    g = torch.Generator().manual_seed(1)
+    data = []
+    for _, di, do, _ in PROJS:
+        d_in = d if di == "d" else ff
+        d_out = d if do == "d" else ff
+        data.append((torch.randn(1, S, d_in, generator=g), torch.randn(1, S, d_out, generator=g),
+                     [torch.randn(r, d_in, generator=g) * 0.01 for _ in range(3)], torch.randn(d_out, r, generator=g) * 0.02,
+                     torch.randn(1, S, d_out, generator=g)))
+
+    def one_layer():
+        for x, y0, A, Bw, gy in data:
+            y, ctx = O.adapter_forward(x, y0, A, Bw, rt, 16.0 / r, [1.0] * 3, 1.0, r, dtype=torch.float32)
+            O.adapter_backward(gy, ctx)
+
+    one_layer()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one_layer()
+        n += 1
+        if time.perf_counter() - t0 > args.cpu_seconds or n >= 50:
+            break
+    per_layer = (time.perf_counter() - t0) / n
+    return {"value": S / (per_layer * LLAMA7B["layers"]), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle port (torch fp32), adapter fwd+bwd of 1 decoder layer x 7 projections, 1 sequence of {S} tokens, "
+                      f"{n} repeats, scaled x{LLAMA7B['layers']} layers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="sequences per GPU (reference AVT micro-batch: ft_musicavqa.sh:12-13)")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=LLAMA7B["layers"])
+    ap.add_argument("--distinct", type=int, default=4, help="distinct activation buffer sets cycled over the layers")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.rank_id = rank
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from moka_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.moka_device_check(), "moka_device_check")
+    from moka_amd.parallel import FlatGradBucket
+    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8))
+    T = wl["T"]
+    torch.cuda.synchronize()
+
+    main_stream = torch.cuda.current_stream()
+    bucket = wl["bucket"]
+    opt = None
+    if not args.no_optimizer:
+        mp = torch.nn.Parameter(wl["master"])
+        mp.grad = bucket.flat
+        opt = torch.optim.AdamW([mp], lr=1e-4, fused=True)
+    L = args.layers
+
+    def step(i):
+        sp = c_void_p(main_stream.cuda_stream)
+        bucket.zero_()                               # same stream as the previous optimizer step
+        run_forward(lib, wl, sp)
+        run_backward(lib, wl, sp, L, bucket.layer_done)   # all-reduce of finished layer groups overlaps the rest
+        bucket.finish(average=True)
+        if opt is not None:
+            opt.step()
+            wl["work"].copy_(wl["master"])           # bf16 working copy read by the next forward
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    ms_per_step = el * 1e3 / args.steps
+    tokens_per_s = world * T * args.steps / el
+
+    out = None
+    if rank == 0:
+        fwd_b, bwd_b = algorithmic_bytes_per_token(LLAMA7B["d"], LLAMA7B["ff"], args.rank, args.layers)
+        algo_gbs = (fwd_b + bwd_b) * T / (ms_per_step * 1e-3) / 1e9
+        # per-kernel durations with HIP events on the launch stream, after the timed region
+        sp = c_void_p(torch.cuda.current_stream().cuda_stream)
+        tot, cnt, per_shape = time_kernels(lib, wl, sp)
+        d_, ff_, r_ = LLAMA7B["d"], LLAMA7B["ff"], args.rank
+        # algorithmic bytes per launch of each entry point (SURVEY 8(d) split by kernel):
+        #   down_fwd: read x                 E*T*d_in      up_fwd : read+write y      2*E*T*d_out
+        #   up_bwd  : read gy                E*T*d_out     down_bwd: read x, r+w dx   3*E*T*d_in
+        def algo(n, di, do):
+            return {"moka_down_fwd": E * T * di, "moka_up_fwd": 2 * E * T * do, "moka_up_bwd": E * T * do,
+                    "moka_down_bwd": 3 * E * T * di, "moka_cross_fwd": 3 * 4 * T * r_, "moka_cross_bwd": 3 * 4 * T * r_}[n]
+        table = {}
+        for (n, di, do), (ms, c_) in sorted(per_shape.items()):
+            avg = ms / c_
+            table[f"{n}[{di}->{do}]"] = {"avg_ms": round(avg, 4), "algo_GBps": round(algo(n, di, do) / (avg * 1e-3) / 1e9, 1)}
+        dom = max(tot, key=lambda n: tot[n])
+        dom_bytes = sum(algo(n, di, do) * c_ for (n, di, do), (ms, c_) in per_shape.items() if n == dom)
+        dom_avg_ms = tot[dom] / cnt[dom]
+        achieved = dom_bytes / cnt[dom] / (dom_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline",
+            "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Llama-2-7B dims, MokA r=16 M=3 (AVT semantics), adapter fwd+bwd of 7x%d projections, "
+                                   "seq=2048 (256 image + 128 audio + 64 question + text), batch %d seq/GPU, "
+                                   "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params" % (args.layers, args.batch),
+                       "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
+            "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
+            "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(dom_avg_ms, 4), "launches_timed": cnt[dom]},
+            "kernels": table,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""Data-parallel synchronisation of the adapter gradients (one process per GPU, RCCL over xGMI).
+
+The reference leaves this to DeepSpeed ZeRO-2 (bucketed reduce-scatter of the trainable
+gradients, ``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/deepspeed/
+stage2-offload.json:37-49``).  Only the adapter is trainable (7B, r=16, M=3: 76.4 M parameters),
+so here every adapter gradient lives in ONE flat fp32 buffer the weight-gradient kernels
+accumulate into directly (``dA_acc`` / ``dB_acc`` of include/moka_hip.h are views of it), and the
+buffer is all-reduced in a few contiguous slices ("buckets" of whole decoder layers):
+
+  * the backward walks the layers last -> first; as soon as the launches of a bucket's layers
+    are enqueued, ``layer_done`` records an event and starts ``all_reduce`` of that slice on a
+    side stream -- RCCL runs while the remaining layers' backward kernels stream HBM;
+  * ``finish`` joins the side stream and averages.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the payload is small (306 MB fp32 for the
+whole 7B adapter), so a handful of large slices keeps every collective bandwidth- rather than
+latency-bound, and nothing here depends on the backend: the same code runs over ``gloo`` on CPU
+tensors (tests/test_parallel_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    """Flat fp32 gradient buffer + per-layer slice boundaries + bucketed asynchronous all-reduce."""
+
+    def __init__(self, numel: int, layer_end: Sequence[int], device, n_buckets: int = 8,
+                 process_group=None, dtype=torch.float32):
+        if not layer_end or layer_end[-1] != numel:
+            raise ValueError("layer_end must be increasing offsets ending at numel")
+        self.flat = torch.zeros(numel, dtype=dtype, device=device)
+        self.layer_end = list(layer_end)
+        self.n_layers = len(self.layer_end)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.layers_per_bucket = max(1, -(-self.n_layers // max(1, n_buckets)))
+        self.is_cuda = self.flat.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and self.world > 1) else None
+        self._pending: List = []
+
+    # ---------------------------------------------------------------- views
+    def layer_slice(self, l: int) -> torch.Tensor:
+        lo = self.layer_end[l - 1] if l > 0 else 0
+        return self.flat[lo:self.layer_end[l]]
+
+    def bucket_bounds(self, l: int):
+        """Slice [lo, hi) of the bucket whose FIRST layer is l (buckets are aligned groups of layers)."""
+        hi_layer = min(self.n_layers, l + self.layers_per_bucket)
+        lo = self.layer_end[l - 1] if l > 0 else 0
+        return lo, self.layer_end[hi_layer - 1]
+
+    def zero_(self):
+        self.flat.zero_()
+
+    # ---------------------------------------------------------------- backward hooks
+    def layer_done(self, l: int):
+        """Call after layer l's backward launches are enqueued (layers arrive last -> first)."""
+        if self.world == 1 or (l % self.layers_per_bucket) != 0:
+            return
+        lo, hi = self.bucket_bounds(l)
+        sl = self.flat[lo:hi]
+        if self.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._pending.append(dist.all_reduce(sl, group=self.group, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(sl, group=self.group, async_op=True))
+
+    def finish(self, average: bool = True):
+        """Join the outstanding collectives; afterwards ``flat`` holds the (averaged) global gradient."""
+        if self.world == 1:
+            return
+        if self.is_cuda:
+            done = torch.cuda.Event()
+            with torch.cuda.stream(self.comm_stream):
+                for wk in self._pending:
+                    wk.wait()
+                done.record(self.comm_stream)
+            torch.cuda.current_stream(self.flat.device).wait_event(done)
+        else:
+            for wk in self._pending:
+                wk.wait()
+        self._pending.clear()
+        if average:
+            self.flat.div_(self.world)
+
+
+def bind_param_grads(params: Sequence[torch.nn.Parameter], bucket: FlatGradBucket, offsets: Sequence[int]):
+    """Make ``param.grad`` a view of the flat buffer (dtype must match) so optimizers / HF Trainer see
+    ordinary gradients while the kernels and the collective work on the flat storage."""
+    for p, off in zip(params, offsets):
+        view = bucket.flat[off:off + p.numel()].view_as(p)
+        if view.dtype != p.dtype:
+            raise TypeError(f"flat bucket is {view.dtype} but parameter is {p.dtype}")
+        p.grad = view

@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the bucketed flat-gradient all-reduce used for data-parallel
+training (moka_amd/parallel.py) gives every rank the averaged gradient, bucket by bucket."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_layers, n_buckets, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import FlatGradBucket
+    sizes = [37 + 11 * l for l in range(n_layers)]
+    ends = []
+    acc = 0
+    for s in sizes:
+        acc += s
+        ends.append(acc)
+    bucket = FlatGradBucket(acc, ends, "cpu", n_buckets=n_buckets)
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(acc, generator=g)
+    for step in range(2):                       # two steps: state must reset cleanly
+        bucket.zero_()
+        for l in range(n_layers - 1, -1, -1):   # backward order: last layer first
+            bucket.layer_slice(l).add_(local[(ends[l - 1] if l else 0):ends[l]] * (step + 1))
+            bucket.layer_done(l)
+        bucket.finish(average=True)
+        exp = sum(torch.randn(acc, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world * (step + 1)
+        ok = torch.allclose(bucket.flat, exp, rtol=1e-6, atol=1e-6)
+        q.put((rank, step, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_layers,n_buckets", [(8, 4), (5, 8), (7, 3)])
+def test_bucketed_allreduce_world2(n_layers, n_buckets):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_layers, n_buckets, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(4)]
+    assert all(ok for _, _, ok in res), res
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, ROOT)
+    from moka_amd.parallel import FlatGradBucket, bind_param_grads
+    b = FlatGradBucket(10, [4, 10], "cpu", n_buckets=2)
+    b.flat.fill_(3.0)
+    b.layer_done(1)
+    b.layer_done(0)
+    b.finish()
+    assert float(b.flat.sum()) == 30.0
+    p = torch.nn.Parameter(torch.zeros(2, 3))
+    bind_param_grads([p], b, [4])
+    assert p.grad.data_ptr() == b.flat[4:].data_ptr()
