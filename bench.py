@@ -61,25 +61,25 @@ class Proj:
     def __init__(self, lib, name, d_in, d_out, r, M, T, bufs, params, grads, ws, rt, s_in, s_out, w, c):
         from moka_amd import _lib
         self.name, self.d_in, self.d_out = name, d_in, d_out
-        RP = _lib.rank_pad(r)
-        self.ks_in = _lib.ksplit(d_in, r, M)
-        self.ks_out = _lib.ksplit(d_out, r, 1)
+        self.ks_in = _lib.ksplit(T, d_in, r)
+        self.ks_out = _lib.ksplit(T, d_out, r)
         x, y, dx = bufs
         A, Bw = params
         dA, dB = grads
-        self.keep = (x, y, dx, A, Bw, dA, dB)
-        h_part, h, hp, g_part, dh = ws
+        part, h, hp_tok, hp_kmj, BwT, dh_tok, dh_kmj = ws
+        self.keep = (x, y, dx, A, Bw, dA, dB, ws)
         Ap = (c_void_p * M)(*[a.data_ptr() for a in A])
         dAp = (c_void_p * M)(*[a.data_ptr() for a in dA])
         so = (c_float * M)(*s_out)
         self._c = (Ap, dAp, so)
         tm = rt.tok_mod.data_ptr()
-        self.f1 = (x.data_ptr(), Ap, tm, h_part.data_ptr(), T, d_in, r, M, s_in, 0)
-        self.f2 = (h_part.data_ptr(), self.ks_in, byref(rt.struct), h.data_ptr(), hp.data_ptr(), r, w, c)
-        self.f3 = (hp.data_ptr(), Bw.data_ptr(), tm, so, y.data_ptr(), T, r, d_out, M, 0)
-        self.b1 = (y.data_ptr(), hp.data_ptr(), Bw.data_ptr(), tm, so, g_part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
-        self.b2 = (g_part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), dh.data_ptr(), r, w, c)
-        self.b3 = (dh.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, s_in, 0)
+        self.f1 = (x.data_ptr(), Ap, tm, part.data_ptr(), T, d_in, r, M, s_in, 0)
+        self.f2 = (part.data_ptr(), self.ks_in, byref(rt.struct), so, Bw.data_ptr(), d_out, h.data_ptr(), None,
+                   hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), r, w, c)
+        self.f3 = (hp_tok.data_ptr(), Bw.data_ptr(), tm, y.data_ptr(), T, r, d_out, 0)
+        self.b1 = (y.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), tm, so, part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
+        self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), r, w, c)
+        self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, 0)
 
 
 def build_workload(args, dev, lib, bucket_factory):
@@ -114,13 +114,19 @@ def build_workload(args, dev, lib, bucket_factory):
         ys = [torch.randn(T, d if do == "d" else ff, device=dev, dtype=bf) for _, _, do, _ in PROJS]
         dxs = [torch.randn(T, d if di == "d" else ff, device=dev, dtype=bf) for _, di, _, _ in PROJS]
         sets.append((acts, ys, dxs))
-    max_ks = max(_lib.ksplit(ff, r, M), _lib.ksplit(ff, r, 1), _lib.ksplit(d, r, M))
-    ws = (torch.empty(max_ks, T, RP, dtype=torch.float32, device=dev), torch.empty(T, RP, dtype=torch.float32, device=dev),
-          torch.empty(T, RP, dtype=torch.float32, device=dev), torch.empty(max_ks, T, RP, dtype=torch.float32, device=dev),
-          torch.empty(T, RP, dtype=torch.float32, device=dev))
-    # per-layer h / hp must survive until the backward: one (h, hp) pair per projection
-    hh = [[(torch.empty(T, RP, dtype=torch.float32, device=dev), torch.empty(T, RP, dtype=torch.float32, device=dev))
-           for _ in PROJS] for _ in range(L)]
+    Tp = _lib.tok_pad(T)
+    max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r))
+    f32 = torch.float32
+    # scratch shared by all projections (consumed before the next projection overwrites it)
+    part = torch.empty(max_ks, T, RP, dtype=f32, device=dev)
+    hp_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
+    dh_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
+    dh_kmj = torch.empty(M, 2, RP, Tp, dtype=bf, device=dev)
+    # saved forward -> backward, one set per projection: h (fp32), the rank-major hp pack, BwT
+    saved = [[(torch.empty(T, RP, dtype=f32, device=dev), torch.empty(2, RP, Tp, dtype=bf, device=dev),
+               torch.empty(RP, d if do == "d" else ff, dtype=bf, device=dev)) for _, _, do, _ in PROJS] for _ in range(L)]
+    ws = None
+    hh = saved
 
     s = 16.0 / r
     projs = []
@@ -144,8 +150,8 @@ def build_workload(args, dev, lib, bucket_factory):
             Bw = work[off:off + n].view(d_out, r)
             dB = gbuf[off:off + n].view(d_out, r)
             off += n
-            h, hp = hh[l][pi]
-            wsl = (ws[0], h, hp, ws[3], ws[4])
+            h, hp_kmj, BwT = saved[l][pi]
+            wsl = (part, h, hp_tok, hp_kmj, BwT, dh_tok, dh_kmj)
             projs.append(Proj(lib, name, d_in, d_out, r, M, T, (acts[src], ys[pi], dxs[pi]), (A, Bw), (dA, dB), wsl, rt,
                               s, [1.0] * M, 1.0, 1.0 / math.sqrt(r)))
         layer_end.append(off)
@@ -153,7 +159,7 @@ def build_workload(args, dev, lib, bucket_factory):
     work.copy_(master)
     assert layer_end == bucket.layer_end
     return dict(projs=projs, rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end,
-                keep=(sets, ws, hh, masks))
+                keep=(sets, saved, masks, part, hp_tok, dh_tok, dh_kmj))
 
 
 def run_forward(lib, wl, sp):

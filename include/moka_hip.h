@@ -15,13 +15,22 @@
  *   - all work is enqueued on `stream` (the caller's current stream); no internal
  *     synchronisation, no default-stream use, no persistent device allocations: workspaces
  *     are owned by the caller.  Entry points are re-entrant (activation checkpointing
- *     re-runs the forward inside backward).
+ *     re-runs the forward inside backward) as long as two calls in flight do not share a
+ *     routing object's `dk_acc` scratch (one backward at a time per routing, the normal case).
  *   - token-major layouts: T = B*S flattened tokens, row-major, contiguous.
  *       x  [T, d_in]  bf16      y / gy [T, d_out] bf16      dx [T, d_in] bf16
  *       A_m [r, d_in] bf16 (lora_A{m}.weight / lora_A[name].weight)
  *       Bw [d_out, r] bf16 (lora_B0.weight / lora_B['text'].weight)
- *     rank-space tensors live in fp32 with a padded row of RP = moka_rank_pad(r) floats:
- *       h, hp, g, dh [T, RP] fp32;  split-K partials [KS, T, RP] fp32.
+ *   - rank space (RP = moka_rank_pad(r) in {16,32,64}, Tp = moka_tok_pad(T) = T rounded up to 32):
+ *       part          [KS, T, RP] fp32   split-K partial sums written by the reduce kernel
+ *       h, hp, dh     [T, RP]     fp32   rank-space activations / gradients
+ *       *_tok  pack   [Tp, 2*RP]  bf16   token-major  [hi(RP) | lo(RP)]  of an fp32 row (hi+lo == value
+ *                                        to 2^-17): the MFMA operand of the expand kernel
+ *       *_kmj  pack   [n, 2, RP, Tp] bf16  rank-major (hi plane, lo plane), tokens permuted inside
+ *                                        every group of 32 (position 8g+e holds token 4g+e for e<4,
+ *                                        16+4g+e-4 otherwise): the MFMA operand of the weight-gradient
+ *                                        kernel (n = 1 for hp, n = M per-modality-masked planes for dh)
+ *       BwT           [RP, d_out] bf16   transposed copy of Bw, zero padded, produced by moka_cross_fwd
  *   - dtype: MOKA_BF16 (=0) is the only storage type implemented (fp32 accumulate).
  *
  * Unified routed formulation (oracle/moka_oracle.py):
@@ -48,7 +57,7 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      100            /* 0.1.0 */
+#define MOKA_VERSION      200            /* 0.2.0 */
 #define MOKA_MAX_MOD      3
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
 #define MOKA_BF16         0
@@ -63,10 +72,13 @@ typedef void* moka_stream_t;            /* hipStream_t */
  * 224 adapter calls of a forward; replaces the per-call nonzero()/where() host syncs of
  * layer.py:603-667 and lora.py:489/:512). */
 typedef struct moka_routing {
-    const uint8_t* tok_mod;   /* [>= round_up(T,64)] modality id 0..M-1, MOKA_MOD_NONE otherwise;
+    const uint8_t* tok_mod;   /* [>= round_up(T,64)+64] modality id 0..M-1, MOKA_MOD_NONE otherwise;
                                  entries past T must be MOKA_MOD_NONE */
-    const int32_t* kpos;      /* [B, Lk_max] key positions inside the sample, -1 = zero key row */
+    const int32_t* kpos;      /* [B, max(Lk_max,1)] key positions inside the sample, -1 = zero key row */
     const int32_t* klen;      /* [B] number of key slots (0: sample has no interaction) */
+    const int32_t* kslot;     /* [T] key slot of token t inside its sample, -1 if t is not a key row */
+    float*         dk_acc;    /* [B, max(Lk_max,1), 64] fp32 scratch, ZERO on entry; moka_cross_bwd
+                                 leaves it zero again (self-cleaning) */
     int32_t B, S, Lk_max, M;
 } moka_routing;
 
@@ -77,54 +89,59 @@ int         moka_device_check(void);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
 int moka_rank_pad(int r);
-/* Number of split-K partial slices moka_down_fwd (C = d_in, M = n modalities) or
- * moka_up_bwd (C = d_out, M = 1) writes for width C.  The caller sizes the partial
- * buffer as ks * T * RP floats. */
-int moka_ksplit(int C, int r, int M);
+/* Token count rounded up to the pack granularity (32). */
+int moka_tok_pad(int T);
+/* Number of split-K partial slices the reduce kernel writes for T tokens of width C
+ * (moka_down_fwd: C = d_in; moka_up_bwd: C = d_out).  `part` holds ks * T * RP floats. */
+int moka_ksplit(int T, int C, int r);
 
 /* ---- forward ----------------------------------------------------------------------- */
 
-/* Per-modality masked down-projection  h_part[s][t] = partial over d_in slice s of
+/* Per-modality masked down-projection  part[s][t] = partial over d_in slice s of
  * s_in * x[t] A[mod(t)]^T.  Replaces lora.py:468-477 (3 dense masked GEMMs) and
- * layer.py:603-621 (gather + GEMM + index_put).  Tokens with MOKA_MOD_NONE are skipped
- * (their partial rows are left unwritten; consumers treat them as zero). */
+ * layer.py:603-621 (gather + GEMM + index_put).  Tiles made only of MOKA_MOD_NONE tokens are
+ * skipped (their partial rows stay unwritten; consumers treat such rows as zero). */
 int moka_down_fwd(const void* x, const void* const* A /*host array of M device ptrs*/,
-                  const uint8_t* tok_mod, float* h_part,
+                  const uint8_t* tok_mod, float* part,
                   int T, int d_in, int r, int M, float s_in, int dtype, moka_stream_t stream);
 
-/* Rank-r cross-modal interaction: sums the ks partials into h, then
- * hp = h + w * softmax(h K^T * inv_sqrt_dk) K for query rows.  Replaces the per-sample
- * Python loops lora.py:485-521 / layer.py:627-653.  h and hp are both written ([T,RP]). */
-int moka_cross_fwd(const float* h_part, int ks, const moka_routing* rt,
-                   float* h, float* hp, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+/* Rank-r cross-modal interaction: sums the ks partials into h, computes
+ * hp = h + w * softmax(h K^T * inv_sqrt_dk) K for query rows, and writes the operand packs of
+ * s_out[mod(t)] * hp[t] for the up-projection (hp_tok) and for dB (hp_kmj), plus BwT.
+ * Replaces the per-sample Python loops lora.py:485-521 / layer.py:627-653.
+ * hp (fp32) and BwT may be NULL (not written). */
+int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const float* s_out /*host, M floats*/,
+                   const void* Bw, int d_out,
+                   float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT,
+                   int r, float w, float inv_sqrt_dk, moka_stream_t stream);
 
-/* Shared up-projection + residual add  y[t] += s_out[mod(t)] * hp[t] Bw^T  (in place on the
+/* Shared up-projection + residual add  y[t] += (s_out[mod(t)] hp[t]) Bw^T  (in place on the
  * base output).  Replaces lora.py:524-530 and layer.py:656-669 (gather, GEMM, scatter-add). */
-int moka_up_fwd(const float* hp, const void* Bw, const uint8_t* tok_mod,
-                const float* s_out /*host, M floats*/, void* y_inout,
-                int T, int r, int d_out, int M, int dtype, moka_stream_t stream);
+int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void* y_inout,
+                int T, int r, int d_out, int dtype, moka_stream_t stream);
 
 /* ---- backward ---------------------------------------------------------------------- */
 
-/* One pass over gy:  g_part[s][t] = partial over d_out slice s of s_out[mod(t)] * gy[t] Bw
- * and dB_acc[o][k] += sum_t s_out[mod(t)] * gy[t][o] * hp[t][k]  (fp32 accumulate, the
- * caller zeroes / owns dB_acc [d_out, r]). */
-int moka_up_bwd(const void* gy, const float* hp, const void* Bw, const uint8_t* tok_mod,
-                const float* s_out /*host*/, float* g_part, float* dB_acc,
+/* g_part[s][t] = partial over d_out slice s of s_out[mod(t)] * gy[t] Bw   (needs BwT) and
+ * dB_acc[o][k] += sum_t gy[t][o] * (s_out[mod(t)] hp[t][k])   (needs hp_kmj; fp32 accumulate,
+ * the caller owns / zeroes dB_acc [d_out, r]; NULL skips it). */
+int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8_t* tok_mod,
+                const float* s_out /*host, M floats*/, float* g_part, float* dB_acc,
                 int T, int r, int d_out, int M, int dtype, moka_stream_t stream);
 
-/* Backward of the cross-modal interaction: sums the ks partials of g (= dL/dhp) and
- * produces dh = dL/dh [T,RP] (softmax backward for query rows, key/value gradients
- * scattered back onto the question rows). */
-int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routing* rt,
-                   float* dh, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+/* Backward of the cross-modal interaction: sums the ks partials of g (= dL/dhp), applies the
+ * softmax backward for query rows and scatters the key/value gradients back onto the question
+ * rows.  Writes the operand packs of s_in * dh for dx (dh_tok) and for dA_m (dh_kmj, one
+ * masked plane pair per modality).  dh (fp32) may be NULL. */
+int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routing* rt, float s_in,
+                   float* dh, void* dh_tok, void* dh_kmj,
+                   int r, float w, float inv_sqrt_dk, moka_stream_t stream);
 
-/* dA_acc[m][k][c] += s_in * sum_{t: mod(t)=m} dh[t][k] x[t][c]   (fp32 accumulate) and
- * dx[t] += s_in * dh[t] A[mod(t)]   (in place on the base input-gradient gy W). */
-int moka_down_bwd(const float* dh, const void* x, const void* const* A /*host array*/,
+/* dA_acc[m][k][c] += sum_{t: mod(t)=m} (s_in dh[t][k]) x[t][c]   (fp32 accumulate; NULL skips) and
+ * dx[t] += (s_in dh[t]) A[mod(t)]   (in place on the base input-gradient gy W; NULL skips). */
+int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* const* A /*host array*/,
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
-                  void* dx_inout /* may be NULL: skip dx */,
-                  int T, int d_in, int r, int M, float s_in, int dtype, moka_stream_t stream);
+                  void* dx_inout, int T, int d_in, int r, int M, int dtype, moka_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ MOKA_MAX_MOD = 3
 
 
 class MokaRoutingStruct(Structure):
-    _fields_ = [("tok_mod", c_void_p), ("kpos", c_void_p), ("klen", c_void_p),
+    _fields_ = [("tok_mod", c_void_p), ("kpos", c_void_p), ("klen", c_void_p), ("kslot", c_void_p), ("dk_acc", c_void_p),
                 ("B", c_int32), ("S", c_int32), ("Lk_max", c_int32), ("M", c_int32)]
 
 
@@ -36,19 +36,25 @@ SYMBOLS = {
     "moka_last_error": (c_char_p, []),
     "moka_device_check": (c_int, []),
     "moka_rank_pad": (c_int, [c_int]),
+    "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),
+    # x, A[], tok_mod, part, T, d_in, r, M, s_in, dtype, stream
     "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "moka_cross_fwd": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), c_void_p, c_void_p,
-                               c_int, c_float, c_float, c_void_p]),
-    "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    # part, ks, rt, s_out[], Bw, d_out, h, hp, hp_tok, hp_kmj, BwT, r, w, c, stream
+    "moka_cross_fwd": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), POINTER(c_float), c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
+    # hp_tok, Bw, tok_mod, y, T, r, d_out, dtype, stream
+    "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    # gy, hp_kmj, BwT, tok_mod, s_out[], g_part, dB_acc, T, r, d_out, M, dtype, stream
     "moka_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_void_p,
-                               c_int, c_float, c_float, c_void_p]),
-    "moka_down_bwd": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
-                              c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    # g_part, ks, h, rt, s_in, dh, dh_tok, dh_kmj, r, w, c, stream
+    "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_float,
+                               c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
+    # dh_tok, dh_kmj, x, A[], tok_mod, dA_acc[], dx, T, d_in, r, M, dtype, stream
+    "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -83,8 +89,12 @@ def rank_pad(r: int) -> int:
     return rp
 
 
-def ksplit(C: int, r: int, M: int) -> int:
-    ks = load().moka_ksplit(int(C), int(r), int(M))
+def ksplit(T: int, C: int, r: int) -> int:
+    ks = load().moka_ksplit(int(T), int(C), int(r))
     if ks < 0:
-        raise ValueError(f"unsupported shape for the HIP path: width={C} r={r} M={M}")
+        raise ValueError(f"unsupported shape for the HIP path: T={T} width={C} r={r} (width must be a multiple of 32)")
     return ks
+
+
+def tok_pad(T: int) -> int:
+    return (int(T) + 31) // 32 * 32

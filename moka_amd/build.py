@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I", INC, SRC, "-o", OUT + ".tmp"]
+           "-Wno-unused-value", "-munsafe-fp-atomics", "-I", INC, SRC, "-o", OUT + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -46,70 +46,94 @@ def _floats(vals: Sequence[float]):
 # 1:1 wrappers of the C entry points
 # --------------------------------------------------------------------------------------
 def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float) -> torch.Tensor:
-    """x2 [T,d_in] bf16 -> h_part [ks,T,RP] fp32."""
+    """x2 [T,d_in] bf16 -> part [ks,T,RP] fp32 (split-K partials of s_in * x A_mod^T)."""
     lib = _lib.load()
     T, d_in = x2.shape
-    M = len(A)
     RP = _lib.rank_pad(r)
-    ks = _lib.ksplit(d_in, r, M)
-    h_part = torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device)
-    _lib.check(lib.moka_down_fwd(x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(), h_part.data_ptr(),
-                                 T, d_in, r, M, float(s_in), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_fwd")
-    return h_part
+    ks = _lib.ksplit(T, d_in, r)
+    part = torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device)
+    _lib.check(lib.moka_down_fwd(x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(), part.data_ptr(),
+                                 T, d_in, r, len(A), float(s_in), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_fwd")
+    return part
 
 
-def cross_fwd(h_part: torch.Tensor, rt: MokaRouting, r: int, w: float, inv_sqrt_dk: float) -> Tuple[torch.Tensor, torch.Tensor]:
+class FwdState:
+    """Rank-space results of the forward that the up-projection and the backward consume."""
+    __slots__ = ("h", "hp", "hp_tok", "hp_kmj", "BwT")
+
+
+def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
+              Bw: Optional[torch.Tensor] = None, want_hp: bool = False) -> FwdState:
     lib = _lib.load()
-    ks, T, RP = h_part.shape
-    h = torch.empty((T, RP), dtype=torch.float32, device=h_part.device)
-    hp = torch.empty((T, RP), dtype=torch.float32, device=h_part.device)
-    _lib.check(lib.moka_cross_fwd(h_part.data_ptr(), ks, byref(rt.struct), h.data_ptr(), hp.data_ptr(),
-                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(h_part.device)), "moka_cross_fwd")
-    return h, hp
+    ks, T, RP = part.shape
+    dev = part.device
+    Tp = _lib.tok_pad(T)
+    st = FwdState()
+    st.h = torch.empty((T, RP), dtype=torch.float32, device=dev)
+    st.hp = torch.empty((T, RP), dtype=torch.float32, device=dev) if want_hp else None
+    st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
+    st.hp_kmj = torch.empty((2, RP, Tp), dtype=torch.bfloat16, device=dev)
+    st.BwT = torch.empty((RP, Bw.shape[0]), dtype=torch.bfloat16, device=dev) if Bw is not None else None
+    _lib.check(lib.moka_cross_fwd(part.data_ptr(), ks, byref(rt.struct), _floats(s_out),
+                                  None if Bw is None else Bw.data_ptr(), 0 if Bw is None else Bw.shape[0],
+                                  st.h.data_ptr(), None if st.hp is None else st.hp.data_ptr(),
+                                  st.hp_tok.data_ptr(), st.hp_kmj.data_ptr(), None if st.BwT is None else st.BwT.data_ptr(),
+                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_fwd")
+    return st
 
 
-def up_fwd_(y2: torch.Tensor, hp: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float]):
-    """In place: y2 [T,d_out] bf16 += s_out[mod] * hp Bw^T."""
+def up_fwd_(y2: torch.Tensor, hp_tok: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int):
+    """In place: y2 [T,d_out] bf16 += (s_out[mod] hp) Bw^T (the scale is already inside hp_tok)."""
     lib = _lib.load()
     T, d_out = y2.shape
-    _lib.check(lib.moka_up_fwd(hp.data_ptr(), Bw.data_ptr(), rt.tok_mod.data_ptr(), _floats(s_out), y2.data_ptr(),
-                               T, r, d_out, len(s_out), _lib.MOKA_BF16, _stream_ptr(y2.device)), "moka_up_fwd")
+    _lib.check(lib.moka_up_fwd(hp_tok.data_ptr(), Bw.data_ptr(), rt.tok_mod.data_ptr(), y2.data_ptr(),
+                               T, r, d_out, _lib.MOKA_BF16, _stream_ptr(y2.device)), "moka_up_fwd")
     return y2
 
 
-def up_bwd(gy2: torch.Tensor, hp: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float],
-           dB_acc: Optional[torch.Tensor]) -> torch.Tensor:
+def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: torch.Tensor, rt: MokaRouting, r: int,
+           s_out: Sequence[float], dB_acc: Optional[torch.Tensor]) -> torch.Tensor:
     """gy2 [T,d_out] bf16 -> g_part [ks,T,RP]; dB_acc [d_out,r] fp32 += (may be None: skip)."""
     lib = _lib.load()
     T, d_out = gy2.shape
     RP = _lib.rank_pad(r)
-    ks = _lib.ksplit(d_out, r, 1)
+    ks = _lib.ksplit(T, d_out, r)
     g_part = torch.empty((ks, T, RP), dtype=torch.float32, device=gy2.device)
-    _lib.check(lib.moka_up_bwd(gy2.data_ptr(), hp.data_ptr(), Bw.data_ptr(), rt.tok_mod.data_ptr(), _floats(s_out),
-                               g_part.data_ptr(), None if dB_acc is None else dB_acc.data_ptr(),
+    _lib.check(lib.moka_up_bwd(gy2.data_ptr(), None if hp_kmj is None else hp_kmj.data_ptr(), BwT.data_ptr(),
+                               rt.tok_mod.data_ptr(), _floats(s_out), g_part.data_ptr(),
+                               None if dB_acc is None else dB_acc.data_ptr(),
                                T, r, d_out, len(s_out), _lib.MOKA_BF16, _stream_ptr(gy2.device)), "moka_up_bwd")
     return g_part
 
 
-def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, w: float, inv_sqrt_dk: float) -> torch.Tensor:
+class BwdState:
+    __slots__ = ("dh", "dh_tok", "dh_kmj")
+
+
+def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, s_in: float, w: float, inv_sqrt_dk: float,
+              want_dh: bool = False) -> BwdState:
     lib = _lib.load()
     ks, T, RP = g_part.shape
-    dh = torch.empty((T, RP), dtype=torch.float32, device=g_part.device)
-    _lib.check(lib.moka_cross_bwd(g_part.data_ptr(), ks, h.data_ptr(), byref(rt.struct), dh.data_ptr(),
-                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(g_part.device)), "moka_cross_bwd")
-    return dh
+    dev = g_part.device
+    Tp = _lib.tok_pad(T)
+    st = BwdState()
+    st.dh = torch.empty((T, RP), dtype=torch.float32, device=dev) if want_dh else None
+    st.dh_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
+    st.dh_kmj = torch.empty((rt.M, 2, RP, Tp), dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.moka_cross_bwd(g_part.data_ptr(), ks, h.data_ptr(), byref(rt.struct), float(s_in),
+                                  None if st.dh is None else st.dh.data_ptr(), st.dh_tok.data_ptr(), st.dh_kmj.data_ptr(),
+                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_bwd")
+    return st
 
 
-def down_bwd_(dh: torch.Tensor, x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float,
+def down_bwd_(bst: BwdState, x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int,
               dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor]):
     """dA_acc[m] [r,d_in] fp32 += ; dx2 [T,d_in] bf16 += (either may be None)."""
     lib = _lib.load()
     T, d_in = x2.shape
-    M = len(A)
-    _lib.check(lib.moka_down_bwd(dh.data_ptr(), x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(),
-                                 None if dA_acc is None else _ptrs(dA_acc),
-                                 None if dx2 is None else dx2.data_ptr(),
-                                 T, d_in, r, M, float(s_in), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_bwd")
+    _lib.check(lib.moka_down_bwd(bst.dh_tok.data_ptr(), bst.dh_kmj.data_ptr(), x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(),
+                                 None if dA_acc is None else _ptrs(dA_acc), None if dx2 is None else dx2.data_ptr(),
+                                 T, d_in, r, len(A), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_bwd")
 
 
 # --------------------------------------------------------------------------------------
@@ -130,8 +154,8 @@ class MokaLinearFn(torch.autograd.Function):
     Forward: base GEMM (hipBLASLt through torch), then three launches -- down-projection,
     cross-modal interaction, up-projection with the residual add done in place on the base
     output.  Backward: base input-gradient GEMM (frozen W: no dW), then one pass over gy
-    (dB + dL/dhp), the rank-space backward, and one pass over x / dx (dA_m, dx += dh A_m).
-    Saves x, h, hp; nothing else (the softmax is recomputed in rank space).
+    (dL/dhp and dB), the rank-space backward, and one pass over x / dx (dA_m, dx += dh A_m).
+    Saves x, h and two small operand packs; the softmax is recomputed in rank space.
     """
 
     @staticmethod
@@ -141,6 +165,8 @@ class MokaLinearFn(torch.autograd.Function):
             _require_bf16(t_, n)
         for a in A:
             _require_bf16(a, "lora_A")
+        if len(spec.s_out) != rt.M or len(A) != rt.M:
+            raise ValueError(f"routing describes {rt.M} modalities but {len(A)} adapters / {len(spec.s_out)} scales were given")
         d_in = x.shape[-1]
         x2 = x.reshape(-1, d_in)
         if not x2.is_contiguous():
@@ -150,16 +176,16 @@ class MokaLinearFn(torch.autograd.Function):
         y = torch.nn.functional.linear(x2, W, bias)                   # frozen base, stock PyTorch-ROCm
         A = [a if a.is_contiguous() else a.contiguous() for a in A]
         Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
-        h_part = down_fwd(x2, A, rt, spec.r, spec.s_in)
-        h, hp = cross_fwd(h_part, rt, spec.r, spec.w, spec.inv_sqrt_dk)
-        up_fwd_(y, hp, Bw_c, rt, spec.r, spec.s_out)
-        ctx.save_for_backward(x2, W, Bw_c, h, hp, *A)
+        part = down_fwd(x2, A, rt, spec.r, spec.s_in)
+        st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c)
+        up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
+        ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, *A)
         ctx.rt, ctx.spec, ctx.x_shape, ctx.has_bias = rt, spec, x.shape, bias is not None
         return y.reshape(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
     def backward(ctx, gy):
-        x2, W, Bw, h, hp, *A = ctx.saved_tensors
+        x2, W, Bw, h, hp_kmj, BwT, *A = ctx.saved_tensors
         rt, spec = ctx.rt, ctx.spec
         r = spec.r
         gy2 = gy.reshape(-1, gy.shape[-1])
@@ -168,21 +194,20 @@ class MokaLinearFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         need_B = ctx.needs_input_grad[3]
         need_A = any(ctx.needs_input_grad[6:])
-        dB_acc = torch.zeros((Bw.shape[0], r), dtype=torch.float32, device=gy2.device) if need_B else None
-        g_part = up_bwd(gy2, hp, Bw, rt, r, spec.s_out, dB_acc)
-        dh = cross_bwd(g_part, h, rt, r, spec.w, spec.inv_sqrt_dk)
-        dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
-        dA_acc = [torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=gy2.device) for _ in A] if need_A else None
-        if need_A or need_x:
-            down_bwd_(dh, x2, A, rt, r, spec.s_in, dA_acc, dx2)
-        gbias = gy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        gW = None
         if ctx.needs_input_grad[1]:
             raise _lib.MokaError("moka_amd: the base weight is frozen in MokA; requires_grad on it is not supported")
+        dB_acc = torch.zeros((Bw.shape[0], r), dtype=torch.float32, device=gy2.device) if need_B else None
+        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc)
+        dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
         gA = [None] * len(A)
-        if need_A:
-            gA = [dA_acc[m].to(A[m].dtype) if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
-        return (None if dx2 is None else dx2.reshape(ctx.x_shape), gW, gbias,
+        if need_A or need_x:
+            bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+            dA_acc = [torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=gy2.device) for _ in A] if need_A else None
+            down_bwd_(bst, x2, A, rt, r, dA_acc, dx2)
+            if need_A:
+                gA = [dA_acc[m].to(A[m].dtype) if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
+        gbias = gy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return (None if dx2 is None else dx2.reshape(ctx.x_shape), None, gbias,
                 None if dB_acc is None else dB_acc.to(Bw.dtype), None, None, *gA)
 
 

@@ -25,10 +25,24 @@ class MokaRouting:
 
     def __init__(self, tok_mod: torch.Tensor, kpos: torch.Tensor, klen: torch.Tensor,
                  B: int, S: int, Lk_max: int, M: int):
-        self.tok_mod, self.kpos, self.klen = tok_mod, kpos, klen
+        dev = tok_mod.device
+        Lkp = max(Lk_max, 1)
+        if kpos.shape[1] != Lkp:
+            kpos = torch.full((B, Lkp), -1, dtype=torch.int32, device=dev)
+        self.tok_mod, self.kpos, self.klen = tok_mod, kpos.contiguous(), klen.contiguous()
         self.B, self.S, self.Lk_max, self.M = B, S, Lk_max, M
         self.T = B * S
-        self.struct = _lib.MokaRoutingStruct(tok_mod.data_ptr(), kpos.data_ptr(), klen.data_ptr(), B, S, Lk_max, M)
+        # inverse map token -> key slot (a key row is finished by the second half of moka_cross_bwd)
+        kslot = torch.full((B, S), -1, dtype=torch.int32, device=dev)
+        if Lk_max > 0:
+            live = (self.kpos >= 0) & (torch.arange(Lkp, device=dev)[None, :] < self.klen[:, None])
+            bidx = torch.arange(B, device=dev)[:, None].expand(B, Lkp)[live]
+            kslot[bidx, self.kpos[live].long()] = torch.arange(Lkp, device=dev, dtype=torch.int32)[None, :].expand(B, Lkp)[live]
+        self.kslot = kslot.reshape(-1).contiguous()
+        # fp32 scratch of the key/value gradients: zero on entry, left zero by moka_cross_bwd
+        self.dk_acc = torch.zeros((B, Lkp, 64), dtype=torch.float32, device=dev)
+        self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.kpos.data_ptr(), self.klen.data_ptr(),
+                                             self.kslot.data_ptr(), self.dk_acc.data_ptr(), B, S, Lk_max, M)
 
     @property
     def device(self):

@@ -33,17 +33,19 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_rank_pad(lib):
-    assert lib.moka_version() == 100
+    assert lib.moka_version() == 200
+    assert [lib.moka_tok_pad(t) for t in (1, 32, 33)] == [32, 32, 64]
     assert [lib.moka_rank_pad(r) for r in (1, 4, 8, 16, 17, 32, 33, 64)] == [16, 16, 16, 16, 32, 32, 64, 64]
     assert lib.moka_rank_pad(0) < 0 and lib.moka_rank_pad(65) < 0
 
 
 def test_ksplit_covers_width(lib):
-    for C, r, M in [(4096, 16, 3), (11008, 16, 3), (4096, 16, 1), (11008, 16, 1), (64, 4, 3), (5120, 64, 3), (8192, 16, 2), (28672, 16, 3)]:
-        ks = lib.moka_ksplit(C, r, M)
-        assert 1 <= ks <= 64
-    assert lib.moka_ksplit(16, 16, 3) < 0
-    assert lib.moka_ksplit(4096, 16, 4) < 0
+    for T, C, r in [(8192, 4096, 16), (8192, 11008, 16), (2048, 4096, 16), (96, 64, 4), (4096, 5120, 64), (10, 64, 8)]:
+        ks = lib.moka_ksplit(T, C, r)
+        assert 1 <= ks <= 8
+    assert lib.moka_ksplit(8192, 16, 16) < 0          # width below one MFMA K step
+    assert lib.moka_ksplit(8192, 4100, 16) < 0        # not a multiple of 32
+    assert lib.moka_ksplit(8192, 4096, 65) < 0
 
 
 def test_argument_validation_sets_error_message(lib):
@@ -56,7 +58,7 @@ def test_argument_validation_sets_error_message(lib):
     rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0, None)
     assert rc == -1 and b"multiple of 32" in lib.moka_last_error()
     # rank out of range
-    rc = lib.moka_up_fwd(dummy, dummy, dummy, (ctypes.c_float * 1)(1.0), dummy, 16, 65, 64, 1, 0, None)
+    rc = lib.moka_up_fwd(dummy, dummy, dummy, dummy, 16, 65, 64, 0, None)
     assert rc == -1 and b"rank" in lib.moka_last_error()
     # null pointer
     rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0, None)

@@ -55,7 +55,7 @@ def _spec_and_routing(cd, dev):
     c = cd.case
     s = c.alpha / c.r
     if cd.masks is None:
-        rt = MokaRouting.plain(c.B, c.S, dev, M=len(cd.A))
+        rt = MokaRouting.plain(c.B, c.S, dev, M=len(cd.A))       # every token routed to adapter 0 (text)
         ort = O.Routing(torch.zeros(c.B, c.S, dtype=torch.int64), torch.zeros(c.B, c.S, dtype=torch.bool),
                         [torch.zeros(0, dtype=torch.int64)] * c.B, [torch.zeros(0, dtype=torch.bool)] * c.B, len(cd.A))
         if c.variant == "avt":
@@ -119,32 +119,48 @@ def _stage_check(cd, y0=None, tol_f32=TOL_F32):
     r = c.r
 
     # ---------- forward stages
-    h_part = F.down_fwd(x2, A, rt, r, spec.s_in)
-    hsum = h_part.sum(0)[:, :r]
-    assert rel(hsum[valid.to(dev)], ctx.h.reshape(T, r)[valid]) < tol_f32, "down_fwd"
-    h, hp = F.cross_fwd(h_part, rt, r, spec.w, spec.inv_sqrt_dk)
-    assert rel(h[:, :r], ctx.h.reshape(T, r)) < tol_f32, "cross_fwd h"
-    assert rel(hp[:, :r], ctx.hp.reshape(T, r)) < tol_f32, "cross_fwd hp"
-    if h.shape[1] > r:
-        assert float(hp[:, r:].abs().max()) == 0.0
+    part = F.down_fwd(x2, A, rt, r, spec.s_in)
+    hsum = part.sum(0)[:, :r]
+    vdev = valid.to(dev)
+    assert rel(hsum[vdev], ctx.h.reshape(T, r)[valid]) < tol_f32, "down_fwd"
+    st = F.cross_fwd(part, rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, want_hp=True)
+    RP = st.h.shape[1]
+    assert rel(st.h[:, :r], ctx.h.reshape(T, r)) < tol_f32, "cross_fwd h"
+    assert rel(st.hp[:, :r], ctx.hp.reshape(T, r)) < tol_f32, "cross_fwd hp"
+    if RP > r:
+        assert float(st.hp[:, r:].abs().max()) == 0.0
+    # operand packs: hi + lo reproduces s_out[mod] * hp to 2^-16, in both layouts; BwT is the padded transpose
+    hps = (ctx.hp * scale).reshape(T, r)
+    tokpack = st.hp_tok[:T].float()
+    assert rel((tokpack[:, :RP] + tokpack[:, RP:])[:, :r], hps) < tol_f32, "hp_tok pack"
+    Tp = st.hp_kmj.shape[2]
+    tl = torch.arange(Tp) % 32
+    pos = torch.where(tl < 16, 8 * (tl // 4) + tl % 4, 8 * ((tl - 16) // 4) + 4 + tl % 4) + (torch.arange(Tp) // 32) * 32
+    kmj = (st.hp_kmj[0].float() + st.hp_kmj[1].float()).cpu()[:, pos]          # [RP, Tp] in natural token order
+    assert rel(kmj[:r, :T].t(), hps) < tol_f32, "hp_kmj pack"
+    assert float(kmj[:, T:].abs().max() if Tp > T else 0.0) == 0.0
+    assert torch.equal(st.BwT[:r].cpu(), cd.Bw.to(bf).t().contiguous()), "BwT"
     y2 = y0.reshape(T, c.d_out).to(dev, bf).contiguous()
-    F.up_fwd_(y2, hp, Bw, rt, r, spec.s_out)
+    F.up_fwd_(y2, st.hp_tok, Bw, rt, r)
     y_exact_bf = yo.reshape(T, c.d_out).to(bf)
     assert rel(y2, y_exact_bf) < TOL_BF16, "up_fwd"
     assert ulp_bf16_diff(y2, y_exact_bf, y0) <= 1.0 + 1e-6, "up_fwd ulp"
 
     # ---------- backward stages
     dB_acc = torch.zeros(c.d_out, r, dtype=torch.float32, device=dev)
-    g_part = F.up_bwd(gy2, hp, Bw, rt, r, spec.s_out, dB_acc)
+    g_part = F.up_bwd(gy2, st.hp_kmj, st.BwT, rt, r, spec.s_out, dB_acc)
     gsum = g_part.sum(0)[:, :r]
-    assert rel(gsum[valid.to(dev)], gpo.reshape(T, r)[valid]) < tol_f32, "up_bwd g"
+    assert rel(gsum[vdev], gpo.reshape(T, r)[valid]) < tol_f32, "up_bwd g"
     assert rel(dB_acc, dBo) < tol_f32, "up_bwd dB"
-    dh = F.cross_bwd(g_part, h, rt, r, spec.w, spec.inv_sqrt_dk)
+    bst = F.cross_bwd(g_part, st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk, want_dh=True)
     # rows of no modality feed nothing downstream (no A_m, no dx): compare routed rows only
-    assert rel(dh[:, :r][valid.to(dev)], dho.reshape(T, r)[valid]) < tol_f32, "cross_bwd"
+    assert rel(bst.dh[:, :r][vdev], dho.reshape(T, r)[valid]) < tol_f32, "cross_bwd"
+    assert float(rt.dk_acc.abs().max()) == 0.0, "dk_acc must be left zero"
+    dtok = bst.dh_tok[:T].float()
+    assert rel((dtok[:, :RP] + dtok[:, RP:])[:, :r][vdev], (spec.s_in * dho.reshape(T, r))[valid]) < tol_f32, "dh_tok pack"
     dA_acc = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]
     dx2 = dx0.reshape(T, c.d_in).to(dev, bf).contiguous()
-    F.down_bwd_(dh, x2, A, rt, r, spec.s_in, dA_acc, dx2)
+    F.down_bwd_(bst, x2, A, rt, r, dA_acc, dx2)
     for m in range(M):
         assert rel(dA_acc[m], dAo[m]) < tol_f32, f"down_bwd dA{m}"
     dx_exact_bf = (dx0.double() + dxo).reshape(T, c.d_in).to(bf)
@@ -245,8 +261,8 @@ def test_forward_is_reentrant_and_deterministic():
     outs = []
     for _ in range(2):
         y2 = torch.zeros(T, c.d_out, dtype=bf, device=dev)
-        hp = F.cross_fwd(F.down_fwd(x2, A, rt, c.r, spec.s_in), rt, c.r, spec.w, spec.inv_sqrt_dk)[1]
-        F.up_fwd_(y2, hp, Bw, rt, c.r, spec.s_out)
+        st = F.cross_fwd(F.down_fwd(x2, A, rt, c.r, spec.s_in), rt, c.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw)
+        F.up_fwd_(y2, st.hp_tok, Bw, rt, c.r)
         outs.append(y2)
     assert torch.equal(outs[0], outs[1])
 
