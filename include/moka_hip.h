@@ -35,7 +35,7 @@
  *
  * Unified routed formulation (oracle/moka_oracle.py):
  *     h[t]  = s_in * x[t] A[mod(t)]^T                 (0 when mod(t) == MOKA_MOD_NONE)
- *     K_b   = rows kpos[b][0..klen[b]) of h  (kpos == -1: zero row that still enters the softmax)
+ *     K_b   = rows ktok[b][0..klen[b]) of h  (ktok == -1: zero row that still enters the softmax)
  *     hp[t] = h[t] + w * softmax(h[t] K_b^T * inv_sqrt_dk) K_b    for query rows
  *             (query row: mod(t) in 1..M-1 and klen[b] > 0), hp[t] = h[t] otherwise
  *     y[t] += s_out[mod(t)] * hp[t] Bw^T
@@ -74,9 +74,10 @@ typedef void* moka_stream_t;            /* hipStream_t */
 typedef struct moka_routing {
     const uint8_t* tok_mod;   /* [>= round_up(T,64)+64] modality id 0..M-1, MOKA_MOD_NONE otherwise;
                                  entries past T must be MOKA_MOD_NONE */
-    const int32_t* kpos;      /* [B, max(Lk_max,1)] key positions inside the sample, -1 = zero key row */
+    const int32_t* ktok;      /* [B, max(Lk_max,1)] FLAT token index (b*S + position) of key slot j; -1 = zero key
+                                 row that still enters the softmax (also for keys whose token has no modality) */
     const int32_t* klen;      /* [B] number of key slots (0: sample has no interaction) */
-    const int32_t* kslot;     /* [T] key slot of token t inside its sample, -1 if t is not a key row */
+    const int32_t* kslot;     /* [T] key slot j with ktok[b][j] == t, -1 if token t is not a (non-zero) key row */
     float*         dk_acc;    /* [B, max(Lk_max,1), 64] fp32 scratch, ZERO on entry; moka_cross_bwd
                                  leaves it zero again (self-cleaning) */
     int32_t B, S, Lk_max, M;
@@ -86,6 +87,10 @@ int         moka_version(void);
 const char* moka_last_error(void);
 /* 0 when a gfx950 device is current, MOKA_ENODEV otherwise. */
 int         moka_device_check(void);
+
+/* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_ks", "expand_bpc", "wgrad_ct",
+ * "wgrad_bpc", "cross_rows"; value 0 restores the default).  Results never depend on it. */
+int moka_tune(const char* key, int value);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
 int moka_rank_pad(int r);

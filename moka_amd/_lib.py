@@ -20,7 +20,7 @@ MOKA_MAX_MOD = 3
 
 
 class MokaRoutingStruct(Structure):
-    _fields_ = [("tok_mod", c_void_p), ("kpos", c_void_p), ("klen", c_void_p), ("kslot", c_void_p), ("dk_acc", c_void_p),
+    _fields_ = [("tok_mod", c_void_p), ("ktok", c_void_p), ("klen", c_void_p), ("kslot", c_void_p), ("dk_acc", c_void_p),
                 ("B", c_int32), ("S", c_int32), ("Lk_max", c_int32), ("M", c_int32)]
 
 
@@ -35,6 +35,7 @@ SYMBOLS = {
     "moka_version": (c_int, []),
     "moka_last_error": (c_char_p, []),
     "moka_device_check": (c_int, []),
+    "moka_tune": (c_int, [c_char_p, c_int]),
     "moka_rank_pad": (c_int, [c_int]),
     "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),

@@ -136,20 +136,37 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
     const int S0 = (int)(((long)blockIdx.y * nst) / a.ks), S1 = (int)(((long)(blockIdx.y + 1) * nst) / a.ks);
     const int s_begin = S0 + (int)(((long)wave * (S1 - S0)) / NW), s_end = S0 + (int)(((long)(wave + 1) * (S1 - S0)) / NW);
 
-    // routing of the two 16-token sub-tiles (block uniform)
-    unsigned pres[2];                                     // bit m: modality m present in sub-tile
+    // The x stream does not depend on the routing: issue the first batch right away, the tok_mod
+    // bytes (which only select the weight rows / the skip) arrive underneath it.
+    const unsigned char* xrow[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+        xrow[st] = a.in + ((size_t)min(t0 + 16 * st + i, a.T - 1) * a.C + 8 * g) * 2;
+    int mrow2[2];
     unsigned mods4[2];                                    // modalities of my 4 result rows
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-        const int mrow = a.tok_mod[t0 + 16 * st + i];
+        mrow2[st] = a.tok_mod[t0 + 16 * st + i];
         mods4[st] = *(const unsigned*)(a.tok_mod + t0 + 16 * st + 4 * g);
+    }
+    bf16x8 xv[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (s_begin + u < s_end) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) xv[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s_begin + u) * 64);
+        }
+    }
+    unsigned pres[2];                                     // bit m: modality m present in sub-tile (block uniform)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
         unsigned p = 0;
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) p |= 1u << m;
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow2[st] == m)) p |= 1u << m;
         if (a.shared_w && p) p = 1u;                      // one chain, scale selected per row
         pres[st] = p;
     }
-    if ((pres[0] | pres[1]) == 0) return;                 // padding tile: no HBM traffic at all
+    if ((pres[0] | pres[1]) == 0) return;                 // padding tile (its speculative first batch is the only waste)
 
     f32x4 acc[2][MOKA_MAX_MOD][NT];
 #pragma unroll
@@ -159,19 +176,15 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[st][m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const unsigned char* xrow[2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-        xrow[st] = a.in + ((size_t)min(t0 + 16 * st + i, a.T - 1) * a.C + 8 * g) * 2;
-
     for (int s = s_begin; s < s_end; s += U) {
-        bf16x8 xv[U][2];
+        if (s != s_begin) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (s + u < s_end) {
+            for (int u = 0; u < U; ++u) {
+                if (s + u < s_end) {
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
-                    if (pres[st]) xv[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s + u) * 64);
+                    for (int st = 0; st < 2; ++st)
+                        if (pres[st]) xv[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s + u) * 64);
+                }
             }
         }
 #pragma unroll
@@ -244,7 +257,7 @@ struct CrossArgs {
     const float* part;              // [ks][T][RP] partials (h for fwd, g = dL/dhp for bwd)
     const float* hfull;             // bwd: h [T][RP]
     const unsigned char* tok_mod;
-    const int* kpos;                // [B][max(Lk_max,1)]
+    const int* ktok;                // [B][max(Lk_max,1)] flat token index of key slot j, -1 = zero row
     const int* klen;                // [B]
     const int* kslot;               // [T]
     float* dk_acc;                  // [B][max(Lk_max,1)][RP]
@@ -255,7 +268,7 @@ struct CrossArgs {
     const unsigned short* Bw;       // fwd: [C][r] or null
     unsigned short* BwT;            // fwd: [RP][C] or null
     float s_mod[4];                 // fwd: s_out per modality; bwd: s_in for every modality
-    int ks, B, S, T, Tp, Lk_max, Lkp, r, C, M;
+    int ks, B, S, T, Tp, Lk_max, Lkp, r, C, M, RB;
     float w, c;
 };
 
@@ -297,8 +310,8 @@ __global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) 
     float* Hp = Hs + 32 * KP;                  // [32][KP]  hp rows
     float* Ks = Hp + 32 * KP;                  // [Lkp][KP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, r0 = blockIdx.y << 5;
-    const int nrow = min(32, a.S - r0);
+    const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
+    const int nrow = min(a.RB, a.S - r0);
     const int Lk = min(a.klen[b], a.Lk_max);
 
     int anyq = 0;
@@ -321,13 +334,10 @@ __global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) 
     if (anyq) {
         for (int e = tid; e < Lk * RP; e += 512) {
             const int j = e / RP, k = e % RP;
-            const int p = a.kpos[b * a.Lkp + j];
+            const int t = a.ktok[b * a.Lkp + j];
             float v = 0.f;
-            if (p >= 0) {
-                const int t = b * a.S + p;
-                if (a.tok_mod[t] != MOKA_MOD_NONE)
-                    for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
-            }
+            if (t >= 0)
+                for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
             Ks[j * KP + k] = v;
         }
         __syncthreads();
@@ -414,8 +424,8 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
     float* Ks = Hs + 32 * KP;                  // [Lkp][KP]
     float* dKs = Ks + (size_t)a.Lkp * KP;      // [Lkp][KP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, r0 = blockIdx.y << 5;
-    const int nrow = min(32, a.S - r0);
+    const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
+    const int nrow = min(a.RB, a.S - r0);
     const int Lk = min(a.klen[b], a.Lk_max);
 
     int anyq = 0;
@@ -441,10 +451,8 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
     if (anyq) {
         for (int e = tid; e < Lk * RP; e += 512) {
             const int j = e / RP, k = e % RP;
-            const int p = a.kpos[b * a.Lkp + j];
-            float v = 0.f;
-            if (p >= 0 && a.tok_mod[b * a.S + p] != MOKA_MOD_NONE) v = a.hfull[((size_t)b * a.S + p) * RP + k];
-            Ks[j * KP + k] = v;
+            const int t = a.ktok[b * a.Lkp + j];
+            Ks[j * KP + k] = (t >= 0) ? a.hfull[(size_t)t * RP + k] : 0.f;
             dKs[j * KP + k] = 0.f;
         }
         __syncthreads();
@@ -530,7 +538,7 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
         const int m = a.tok_mod[t];
         const int slot = a.kslot[t];
         const float dv = Dh[row * KP + k];
-        if (slot >= 0 && m != MOKA_MOD_NONE) {
+        if (slot >= 0) {
             // key row: finished by part b; hand over the query contribution (if this row is also a query)
             const float dq = dv - Gs[row * KP + k];
             if (dq != 0.f) atomicAdd(&a.dk_acc[((size_t)b * a.Lkp + slot) * RP + k], dq);
@@ -544,29 +552,21 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
     }
 }
 
-// Backward, part b: the key rows  dh[kpos_j] = g[kpos_j] + dk_acc[j];  re-zeroes dk_acc.
+// Backward, part b: the key rows  dh[key_j] = g[key_j] + dk_acc[j];  re-zeroes dk_acc.
 template <int RP>
 __global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossArgs a) {
     const int b = blockIdx.x;
-    const int Lk = min(a.klen[b], a.Lk_max);
-    for (int e = threadIdx.x; e < a.Lkp * RP; e += 256) {
-        const int j = e / RP, k = e % RP;
-        float* acc = &a.dk_acc[((size_t)b * a.Lkp + j) * RP + k];
-        if (j < Lk) {
-            const int p = a.kpos[b * a.Lkp + j];
-            if (p >= 0) {
-                const int t = b * a.S + p;
-                const int m = a.tok_mod[t];
-                if (m != MOKA_MOD_NONE && a.kslot[t] == j) {
-                    float v = *acc;
-                    for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
-                    if (a.out_f32) a.out_f32[(size_t)t * RP + k] = v;
-                    write_packs_bwd<RP>(a, t, k, m, v * a.s_mod[0]);
-                }
-            }
-        }
-        *acc = 0.f;
-    }
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= a.Lkp * RP) return;
+    const int j = e / RP, k = e % RP;
+    float* acc = &a.dk_acc[((size_t)b * a.Lkp + j) * RP + k];
+    const int t = a.ktok[b * a.Lkp + j];
+    float v = *acc;
+    *acc = 0.f;
+    if (t < 0 || a.kslot[t] != j) return;           // zero key row / not the owner of that token
+    for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
+    if (a.out_f32) a.out_f32[(size_t)t * RP + k] = v;
+    write_packs_bwd<RP>(a, t, k, a.tok_mod[t], v * a.s_mod[0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -658,6 +658,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
 
     const int ntiles = (a.T + 15) >> 4;
     const size_t prow = (size_t)(2 * RP) * 2;                     // pack row bytes
+
     for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
         const int t = (tile << 4) + i;                            // operand / result lanes: token = lane & 15
         const bool valid = t < a.T;
@@ -734,120 +735,173 @@ struct WgradArgs {
     const unsigned char* tok_mod;
     float* acc[MOKA_MAX_MOD];       // OUT_CK: [C][r]   else: [r][C]     fp32, accumulated atomically
     int T, Tp, C, r, M, groups_per_block;
-    int per_mod;                    // 1: one pack plane + accumulator per modality (dA); 0: single (dB)
+    int per_mod;                    // 1: one pack plane per modality (dA); 0: single (dB)
 };
 
-// Block = NW waves owning CT*16 columns for a long run of tokens.  Each wave walks over groups of
-// 32 tokens: coalesced loads of its [32 tokens][CT*16 columns] tile, copy to a wave-private LDS
-// region, transpose reads as MFMA A operand (rows = columns of `in`, K = tokens), B operand = the
-// rank-major pack (16-byte loads from L2).  No block barrier until the final cross-wave reduction.
-template <int RP, int CT, int NW, bool OUT_CK>
+// Block = NW waves owning NSB*64 columns for a long run of tokens.  Each wave walks over groups of 32
+// tokens with a 2-deep software pipeline: tok_mod of group i+2 and the [32 tokens][NSB*64 columns]
+// tile of group i+1 are in flight while group i goes, 64 columns at a time, through a wave-private
+// 5 KB LDS region and is read back transposed (ds_read_b64_tr_b16) as the MFMA A operand (rows =
+// columns of `in`, K = tokens); B operand = the rank-major pack (16-byte loads from L2).
+// One accumulator set per wave: tokens arrive in modality runs, so the set leaves the wave only when
+// the modality changes (rare: straight to fp32 atomics) and once at the end (private LDS region,
+// plain stores; the block then sums the NW regions and issues one atomic per (column, rank)).
+template <int RP, int NSB, int NW, bool OUT_CK>
 __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
-    constexpr int CC = CT * 16;                     // columns per block
-    constexpr int PITCH = CC * 2 + 32;              // bytes; odd multiple of 32
-    constexpr int LPR = CC / 8;                     // 16-byte lanes per row
-    constexpr int RPI = 64 / LPR;                   // rows per wave load instruction
-    constexpr int NLD = 32 / RPI;                   // load instructions per 32-token group
+    constexpr int NM = OUT_CK ? 1 : MOKA_MAX_MOD;   // dB: one plane; dA: one plane per modality
+    constexpr int CT = 4;                           // 16-column tiles per 64-column sub-tile
+    constexpr int CCB = NSB * 64;                   // columns per block
+    constexpr int PITCH = 64 * 2 + 32;              // bytes per LDS row; odd multiple of 32
     constexpr int REGION = 32 * PITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int c_begin = blockIdx.x * CC;
+    const int c_begin = blockIdx.x * CCB;
     unsigned char* my = smem + wave * REGION;
+    float* red = (float*)(smem + NW * REGION);      // [NW][CCB][RP]  per-wave partial sums
+    int* tag = (int*)(red + (size_t)NW * CCB * RP); // [NW] modality of each wave's partial sum
     const int ngroups = a.Tp >> 5;
     const int grp_begin = blockIdx.y * a.groups_per_block;
     const int grp_end = min(ngroups, grp_begin + a.groups_per_block);
-    const int nmod = a.per_mod ? a.M : 1;
+    const int lrow = lane >> 3, lcol = lane & 7;
 
-    f32x4 acc[MOKA_MAX_MOD][CT][NT];
+    f32x4 acc[NSB][CT][NT];
+    int cur = -1;                                   // modality the accumulators currently belong to
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int m = 0; m < MOKA_MAX_MOD; ++m)
+        for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    unsigned ever = 0;
-    const int lrow = lane / LPR, lcol = lane % LPR;
-    const bool col_ok = c_begin + lcol * 8 < a.C;
-
-    for (int grp = grp_begin + wave; grp < grp_end; grp += NW) {
+                for (int nt = 0; nt < NT; ++nt) acc[sb][ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // D[row = column c (4g+reg)][col = rank k (i)]
+    auto flush_global = [&](int m) {               // rare: the modality run changed inside this wave
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int c = c_begin + sb * 64 + ct * 16 + 4 * g + reg, k = nt * 16 + i;
+                        if (c < a.C && k < a.r)
+                            atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), acc[sb][ct][nt][reg]);
+                    }
+    };
+    auto present_of = [&](int mym) -> unsigned {
+        unsigned p = 0;
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mym == m)) p |= 1u << m;
+        return p;
+    };
+    auto issue = [&](uint4 (&ld)[NSB][4], int grp) {
         const int t0 = grp << 5;
-        const int mym = a.tok_mod[t0 + (lane & 31)];
-        unsigned present = 0;
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mym == m)) present |= 1u << m;
-        if (present == 0) continue;                               // padding group: no HBM traffic
-        const unsigned pm = a.per_mod ? present : 1u;
-        ever |= pm;
-        uint4 ld[NLD];
+        for (int u = 0; u < 4; ++u) {
+            const size_t rowoff = (size_t)min(t0 + 8 * u + lrow, a.T - 1) * a.C;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int t = min(t0 + u * RPI + lrow, a.T - 1);
-            ld[u] = make_uint4(0, 0, 0, 0);
-            if (col_ok) ld[u] = *(const uint4*)(a.in + ((size_t)t * a.C + c_begin + lcol * 8) * 2);
-        }
-        // B operand fragments (rank-major pack): lane (k = i, g) -> tokens at positions 8g..8g+7 of the group
-        bf16x8 bh[MOKA_MAX_MOD][NT], bl[MOKA_MAX_MOD][NT];
-#pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-            if (m < nmod && (pm & (1u << m))) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned short* ph = a.pack + (((size_t)m * 2 + 0) * RP + nt * 16 + i) * a.Tp + t0 + 8 * g;
-                    bh[m][nt] = *(const bf16x8*)ph;
-                    bl[m][nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
-                }
+            for (int sb = 0; sb < NSB; ++sb) {
+                const int c = c_begin + sb * 64 + lcol * 8;
+                ld[sb][u] = make_uint4(0, 0, 0, 0);
+                if (c < a.C) ld[sb][u] = *(const uint4*)(a.in + (rowoff + c) * 2);
             }
         }
+    };
+    auto compute = [&](uint4 (&ld)[NSB][4], int grp, unsigned present) {
+        const int t0 = grp << 5;
+        const unsigned pm = a.per_mod ? present : 1u;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) *(uint4*)(my + (u * RPI + lrow) * PITCH + lcol * 16) = ld[u];
+        for (int m = 0; m < NM; ++m) {
+            if (!(pm & (1u << m))) continue;
+            if (m != cur) {                                       // modality run changed (wave uniform)
+                if (cur >= 0) { flush_global(cur); zero_acc(); }
+                cur = m;
+            }
+            // B operand fragments (rank-major pack): lane (k = i, g) -> tokens at positions 8g..8g+7 of the group
+            bf16x8 bh[NT], bl[NT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
-            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
-            const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned short* ph = a.pack + (((size_t)m * 2 + 0) * RP + nt * 16 + i) * a.Tp + t0 + 8 * g;
+                bh[nt] = *(const bf16x8*)ph;
+                bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
+            }
 #pragma unroll
-            for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-                if (m < nmod && (pm & (1u << m))) {
+            for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *(uint4*)(my + (8 * u + lrow) * PITCH + lcol * 16) = ld[sb][u];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
+                    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
+                    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
+                    const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[m][ct][nt] = MFMA16(av, bh[m][nt], acc[m][ct][nt]);
-                        acc[m][ct][nt] = MFMA16(av, bl[m][nt], acc[m][ct][nt]);
+                        acc[sb][ct][nt] = MFMA16(av, bh[nt], acc[sb][ct][nt]);
+                        acc[sb][ct][nt] = MFMA16(av, bl[nt], acc[sb][ct][nt]);
                     }
                 }
             }
         }
+    };
+    zero_acc();
+
+    // ---- 2-deep pipeline over this wave's CONTIGUOUS run of groups (few modality changes per wave)
+    uint4 ldA[NSB][4], ldB[NSB][4];
+    const int per_wave = (grp_end - grp_begin + NW - 1) / NW;
+    int grp = grp_begin + wave * per_wave;
+    const int wend = min(grp_end, grp + per_wave);
+    int mym_cur = (grp < wend) ? a.tok_mod[(grp << 5) + (lane & 31)] : MOKA_MOD_NONE;
+    int mym_nxt = (grp + 1 < wend) ? a.tok_mod[((grp + 1) << 5) + (lane & 31)] : MOKA_MOD_NONE;
+    unsigned pres_cur = present_of(mym_cur);
+    if (pres_cur) issue(ldA, grp);
+    while (grp < wend) {
+        int mym_nn = (grp + 2 < wend) ? a.tok_mod[((grp + 2) << 5) + (lane & 31)] : MOKA_MOD_NONE;
+        unsigned pres_nxt = present_of(mym_nxt);
+        if (pres_nxt) issue(ldB, grp + 1);
+        if (pres_cur) compute(ldA, grp, pres_cur);
+        grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
+        if (grp >= wend) break;
+        mym_nn = (grp + 2 < wend) ? a.tok_mod[((grp + 2) << 5) + (lane & 31)] : MOKA_MOD_NONE;
+        pres_nxt = present_of(mym_nxt);
+        if (pres_nxt) issue(ldA, grp + 1);
+        if (pres_cur) compute(ldB, grp, pres_cur);
+        grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
     }
 
-    // cross-wave reduction in LDS, then one fp32 atomic per (column, rank) of the block
-    __syncthreads();                                   // all waves are done with their private regions
-    float* red = (float*)smem;                         // [nmod][CC][RP]
-    unsigned* flag = (unsigned*)(smem + (size_t)MOKA_MAX_MOD * CC * RP * 4);
-    for (int e = tid; e < nmod * CC * RP; e += NW * 64) red[e] = 0.f;
-    if (tid == 0) *flag = 0;
-    __syncthreads();
+    // ---- block reduction: private regions (plain stores), then one atomic per (column, rank, modality)
+    float* mine = red + (size_t)wave * CCB * RP;
 #pragma unroll
-    for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-        if (!(ever & (1u << m))) continue;
+    for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
-                    atomicAdd(&red[((size_t)m * CC + ct * 16 + 4 * g + reg) * RP + nt * 16 + i], acc[m][ct][nt][reg]);
-    }
-    if (lane == 0 && ever) atomicOr(flag, ever);
+                    mine[(sb * 64 + ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = acc[sb][ct][nt][reg];
+    if (lane == 0) tag[wave] = cur;
     __syncthreads();
-    const unsigned any = *flag;
-    for (int e = tid; e < nmod * CC * RP; e += NW * 64) {
-        const int k = e % RP, cl = (e / RP) % CC, m = e / (RP * CC);
+    int tags[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tags[w] = tag[w];
+    for (int e = tid; e < CCB * RP; e += NW * 64) {
+        // consecutive threads -> consecutive addresses of the destination ([C][r] for dB, [r][C] for dA)
+        const int k = OUT_CK ? (e % RP) : (e / CCB), cl = OUT_CK ? (e / RP) : (e % CCB);
         const int c = c_begin + cl;
-        if (!(any & (1u << m)) || c >= a.C || k >= a.r) continue;
-        const size_t off = OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c);
-        atomicAdd(a.acc[m] + off, red[e]);
+        if (c >= a.C || k >= a.r) continue;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            float sum = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (tags[w] == m) { sum += red[((size_t)w * CCB + cl) * RP + k]; any = true; }
+            if (any) atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), sum);
+        }
     }
 }
 
@@ -887,6 +941,10 @@ static void ensure_lds(const void* kernel, size_t lds) {
     if (nslots < 96) { slots[nslots].k = kernel; slots[nslots].granted = want; ++nslots; }
 }
 
+// Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
+static int g_tune_reduce_nw = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+           g_tune_cross_rows = 0;
+
 static int num_cu() {
     static int n = 0;
     if (n == 0) {
@@ -911,6 +969,7 @@ static int reduce_ks(int T, int C) {
     if (ks > max_ks) ks = max_ks;
     if (ks > 8) ks = 8;
     if (ks < 1) ks = 1;
+    if (g_tune_reduce_ks > 0 && g_tune_reduce_ks <= max_ks && g_tune_reduce_ks <= 8) ks = g_tune_reduce_ks;
     return ks;
 }
 
@@ -932,15 +991,15 @@ static void launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
 }
 
 static int launch_reduce(const ReduceArgs& a, int RP, hipStream_t st) {
-    if (RP == 16) launch_reduce_t<16, 16>(a, st);
-    else if (RP == 32) launch_reduce_t<32, 16>(a, st);
+    if (RP == 16) { if (g_tune_reduce_nw == 16) launch_reduce_t<16, 16>(a, st); else launch_reduce_t<16, 8>(a, st); }
+    else if (RP == 32) launch_reduce_t<32, 8>(a, st);
     else launch_reduce_t<64, 8>(a, st);
     return check_launch("moka_reduce_kernel");
 }
 
 template <int RP, int KCH>
 static void launch_cross_t(bool bwd, const CrossArgs& a, hipStream_t st) {
-    dim3 grid(a.B, (a.S + 31) / 32), block(512);
+    dim3 grid(a.B, (a.S + a.RB - 1) / a.RB), block(512);
     if (!bwd) {
         const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4;
         ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH>, lds);
@@ -949,7 +1008,7 @@ static void launch_cross_t(bool bwd, const CrossArgs& a, hipStream_t st) {
         const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4;
         ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH>, lds);
         hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH>), grid, block, lds, st, a);
-        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 255) / 256), dim3(256), 0, st, a);
     }
 }
 
@@ -959,14 +1018,15 @@ static int launch_cross(bool bwd, CrossArgs& a, const moka_routing* rt, int r, h
     if (RP < 0) return fail(MOKA_EINVAL, "%s: rank %d not in 1..64", fn, r);
     if (!rt) return fail(MOKA_EINVAL, "%s: null routing", fn);
     if (a.ks < 1 || rt->B < 1 || rt->S < 1) return fail(MOKA_EINVAL, "%s: ks=%d B=%d S=%d", fn, a.ks, rt->B, rt->S);
-    if (!rt->tok_mod || !rt->klen || !rt->kpos || !rt->kslot || !rt->dk_acc) return fail(MOKA_EINVAL, "%s: null routing pointer", fn);
+    if (!rt->tok_mod || !rt->klen || !rt->ktok || !rt->kslot || !rt->dk_acc) return fail(MOKA_EINVAL, "%s: null routing pointer", fn);
     const int Lk = rt->Lk_max;
     if (Lk < 0 || Lk > 512) return fail(MOKA_EINVAL, "%s: Lk_max=%d not in 0..512", fn, Lk);
     const int kch = Lk <= 64 ? 1 : (Lk <= 128 ? 2 : (Lk <= 256 ? 4 : 8));
     if (kch * RP > 128) return fail(MOKA_EINVAL, "%s: Lk_max=%d with rank pad %d exceeds the register budget", fn, Lk, RP);
-    a.tok_mod = rt->tok_mod; a.kpos = rt->kpos; a.klen = rt->klen; a.kslot = rt->kslot; a.dk_acc = rt->dk_acc;
+    a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot; a.dk_acc = rt->dk_acc;
     a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
     a.r = r; a.M = rt->M;
+    a.RB = (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) ? g_tune_cross_rows : 8;
     if ((size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 > 150 * 1024) return fail(MOKA_EINVAL, "%s: key block does not fit LDS", fn);
     if (RP == 16) {
         if (kch == 1) launch_cross_t<16, 1>(bwd, a, st); else if (kch == 2) launch_cross_t<16, 2>(bwd, a, st);
@@ -985,7 +1045,8 @@ static void launch_expand_t(const ExpandArgs& a, hipStream_t st) {
     constexpr int CW = 4 * NQ * 32;
     const int nc = (a.C + CW - 1) / CW;
     const int ntiles = (a.T + 15) / 16;
-    int gy = (2 * num_cu() + nc - 1) / nc;             // ~2 blocks (8 waves) per CU, each walking many tiles
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (W_CK ? (a.C > 8192 ? 8 : 4) : 3);
+    int gy = (bpc * num_cu() + nc - 1) / nc;           // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
     const size_t lds = W_CK ? 0 : (size_t)a.M * RP * (CW * 2 + 32);
@@ -1001,28 +1062,31 @@ static int launch_expand(const ExpandArgs& a, int RP, hipStream_t st) {
     return check_launch("moka_expand_kernel");
 }
 
-template <int RP, int CT, int NW, bool OUT_CK>
+template <int RP, int NSB, int NW, bool OUT_CK>
 static void launch_wgrad_t(WgradArgs& a, hipStream_t st) {
-    constexpr int CC = CT * 16;
-    const int nc = (a.C + CC - 1) / CC;
+    constexpr int CCB = NSB * 64;
+    constexpr int NM = OUT_CK ? 1 : MOKA_MAX_MOD;
+    const int nc = (a.C + CCB - 1) / CCB;
     const int ngroups = a.Tp / 32;
-    int nb = (2 * num_cu() + nc - 1) / nc;             // ~2 blocks per CU
+    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : 1;
+    int nb = (bpc * num_cu() + nc - 1) / nc;
     if (nb > (ngroups + NW - 1) / NW) nb = (ngroups + NW - 1) / NW;
     if (nb < 1) nb = 1;
     a.groups_per_block = (ngroups + nb - 1) / nb;
     nb = (ngroups + a.groups_per_block - 1) / a.groups_per_block;
-    size_t lds = (size_t)NW * 32 * (CC * 2 + 32);
-    const size_t red = (size_t)MOKA_MAX_MOD * CC * RP * 4 + 16;
-    if (red > lds) lds = red;
-    ensure_lds((const void*)moka_wgrad_kernel<RP, CT, NW, OUT_CK>, lds);
-    hipLaunchKernelGGL((moka_wgrad_kernel<RP, CT, NW, OUT_CK>), dim3(nc, nb), dim3(NW * 64), lds, st, a);
+    (void)sizeof(char[NM]);
+    const size_t lds = (size_t)NW * 32 * 160 + (size_t)NW * CCB * RP * 4 + NW * 4 + 16;
+    ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK>, lds);
+    hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK>), dim3(nc, nb), dim3(NW * 64), lds, st, a);
 }
 
 template <bool OUT_CK>
 static int launch_wgrad(WgradArgs& a, int RP, hipStream_t st) {
-    if (RP == 16) launch_wgrad_t<16, 4, 8, OUT_CK>(a, st);
-    else if (RP == 32) launch_wgrad_t<32, 2, 8, OUT_CK>(a, st);
-    else launch_wgrad_t<64, 1, 8, OUT_CK>(a, st);
+    if (RP == 16) {
+        if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK>(a, st);
+        else launch_wgrad_t<16, 1, 8, OUT_CK>(a, st);
+    } else if (RP == 32) launch_wgrad_t<32, 1, 8, OUT_CK>(a, st);
+    else launch_wgrad_t<64, 1, 4, OUT_CK>(a, st);
     return check_launch("moka_wgrad_kernel");
 }
 
@@ -1038,6 +1102,18 @@ int moka_device_check(void) {
         return fail(MOKA_ENODEV, "no HIP device");
     if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return fail(MOKA_ENODEV, "device is %s, kernels are built for gfx950", p.gcnArchName);
+    return MOKA_OK;
+}
+
+int moka_tune(const char* key, int value) {
+    if (!key) return fail(MOKA_EINVAL, "moka_tune: null key");
+    if (!strcmp(key, "reduce_nw")) g_tune_reduce_nw = value;
+    else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
+    else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
+    else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
+    else if (!strcmp(key, "wgrad_bpc")) g_tune_wgrad_bpc = value;
+    else if (!strcmp(key, "cross_rows")) g_tune_cross_rows = value;
+    else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 }
 

@@ -32,16 +32,20 @@ class MokaRouting:
         self.tok_mod, self.kpos, self.klen = tok_mod, kpos.contiguous(), klen.contiguous()
         self.B, self.S, self.Lk_max, self.M = B, S, Lk_max, M
         self.T = B * S
+        # flat key token index per slot (-1: zero row -- padding slot, invalid key, or a key token of no modality)
+        live = (self.kpos >= 0) & (torch.arange(Lkp, device=dev)[None, :] < self.klen[:, None])
+        flat = (torch.arange(B, device=dev)[:, None] * S + self.kpos.clamp(min=0)).long()
+        live = live & (tok_mod[:B * S][flat.clamp(max=B * S - 1)] != MOD_NONE)
+        self.ktok = torch.where(live, flat, torch.full_like(flat, -1)).to(torch.int32).contiguous()
         # inverse map token -> key slot (a key row is finished by the second half of moka_cross_bwd)
-        kslot = torch.full((B, S), -1, dtype=torch.int32, device=dev)
+        kslot = torch.full((B * S,), -1, dtype=torch.int32, device=dev)
         if Lk_max > 0:
-            live = (self.kpos >= 0) & (torch.arange(Lkp, device=dev)[None, :] < self.klen[:, None])
-            bidx = torch.arange(B, device=dev)[:, None].expand(B, Lkp)[live]
-            kslot[bidx, self.kpos[live].long()] = torch.arange(Lkp, device=dev, dtype=torch.int32)[None, :].expand(B, Lkp)[live]
-        self.kslot = kslot.reshape(-1).contiguous()
+            slots = torch.arange(Lkp, device=dev, dtype=torch.int32)[None, :].expand(B, Lkp)
+            kslot[flat[live]] = slots[live]
+        self.kslot = kslot.contiguous()
         # fp32 scratch of the key/value gradients: zero on entry, left zero by moka_cross_bwd
         self.dk_acc = torch.zeros((B, Lkp, 64), dtype=torch.float32, device=dev)
-        self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.kpos.data_ptr(), self.klen.data_ptr(),
+        self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.ktok.data_ptr(), self.klen.data_ptr(),
                                              self.kslot.data_ptr(), self.dk_acc.data_ptr(), B, S, Lk_max, M)
 
     @property

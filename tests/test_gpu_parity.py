@@ -81,11 +81,13 @@ def _check_routing(rt, ort):
     assert (tm == ort.tok_mod).all()
     assert (rt.tok_mod[B * S:].cpu() == 255).all()
     klen = rt.klen.cpu()
-    kpos = rt.kpos.cpu()
+    ktok = rt.ktok.cpu()
     for b in range(B):
         assert int(klen[b]) == ort.kpos[b].numel()
-        exp = torch.where(ort.kvalid[b], ort.kpos[b], torch.full_like(ort.kpos[b], -1))
-        assert (kpos[b, :int(klen[b])].to(torch.int64) == exp).all()
+        # a key of no modality has h == 0: the device routing folds that into "zero row" (-1)
+        nz = ort.kvalid[b] & (ort.tok_mod[b, ort.kpos[b]] >= 0)
+        exp = torch.where(nz, b * S + ort.kpos[b], torch.full_like(ort.kpos[b], -1))
+        assert (ktok[b, :int(klen[b])].to(torch.int64) == exp).all()
 
 
 def _stage_check(cd, y0=None, tol_f32=TOL_F32):

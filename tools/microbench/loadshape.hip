@@ -141,15 +141,18 @@ static float time_ms(F f, int iters = 20) {
     return ms / iters;
 }
 
-int main() {
-    const int T = 32768, K = 4096;             // 268 MB: past the 256 MiB Infinity Cache
+int main(int argc, char** argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 32768, K = 4096;   // default 268 MB: past the 256 MiB Infinity Cache
+    const bool quick = argc > 2;
     const size_t bytes = (size_t)T * K * 2;
-    char* x; CK(hipMalloc(&x, bytes)); CK(hipMemset(x, 1, bytes));
+    const int NB = 6; char* xb[NB]; for (int b = 0; b < NB; ++b) { CK(hipMalloc(&xb[b], bytes)); CK(hipMemset(xb[b], 1, bytes)); }
+    int rot = 0; char* x = xb[0];
+#define ROT (x = xb[(rot++) % NB])
     unsigned* out; CK(hipMalloc(&out, 64));
     float* fout = (float*)out;
     printf("T=%d K=%d bytes=%.1f MB\n", T, K, bytes / 1e6);
     for (int grid : {512, 1024, 2048, 4096}) {
-        float ms = time_ms([&] { hipLaunchKernelGGL(read_linear, dim3(grid), dim3(256), 0, 0, (const u32x4*)x, bytes / 16, out); });
+        float ms = time_ms([&] { ROT; hipLaunchKernelGGL(read_linear, dim3(grid), dim3(256), 0, 0, (const u32x4*)x, bytes / 16, out); });
         printf("read_linear        grid=%5d  %.3f ms  %.0f GB/s\n", grid, ms, bytes / ms / 1e6);
     }
     for (int grid : {256, 512, 1024, 2048}) {
@@ -157,7 +160,7 @@ int main() {
         printf("read_frag16<8>     grid=%5d  %.3f ms  %.0f GB/s\n", grid, ms, bytes / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(read_frag16<16>, dim3(grid), dim3(256), 0, 0, x, T, K, out); });
         printf("read_frag16<16>    grid=%5d  %.3f ms  %.0f GB/s\n", grid, ms, bytes / ms / 1e6);
-        ms = time_ms([&] { hipLaunchKernelGGL(read_frag16_mfma<8>, dim3(grid), dim3(256), 0, 0, x, T, K, fout); });
+        ms = time_ms([&] { ROT; hipLaunchKernelGGL(read_frag16_mfma<8>, dim3(grid), dim3(256), 0, 0, x, T, K, fout); });
         printf("read_frag16_mfma<8> grid=%5d  %.3f ms  %.0f GB/s\n", grid, ms, bytes / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(read_frag16_mfma<16>, dim3(grid), dim3(256), 0, 0, x, T, K, fout); });
         printf("read_frag16_mfma<16> grid=%5d  %.3f ms  %.0f GB/s\n", grid, ms, bytes / ms / 1e6);
@@ -165,13 +168,13 @@ int main() {
     for (int grid : {1024, 2048, 4096}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(rmw_linear, dim3(grid), dim3(256), 0, 0, (u32x4*)x, bytes / 16); });
         printf("rmw_linear         grid=%5d  %.3f ms  %.0f GB/s (r+w)\n", grid, ms, 2 * bytes / ms / 1e6);
-        ms = time_ms([&] { hipLaunchKernelGGL(rmw_frag16<4>, dim3(grid), dim3(256), 0, 0, x, T, K); });
+        ms = time_ms([&] { ROT; hipLaunchKernelGGL(rmw_frag16<4>, dim3(grid), dim3(256), 0, 0, x, T, K); });
         printf("rmw_frag16<4>      grid=%5d  %.3f ms  %.0f GB/s (r+w)\n", grid, ms, 2 * bytes / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(rmw_frag16<8>, dim3(grid), dim3(256), 0, 0, x, T, K); });
         printf("rmw_frag16<8>      grid=%5d  %.3f ms  %.0f GB/s (r+w)\n", grid, ms, 2 * bytes / ms / 1e6);
     }
     // XCD-local atomics probe
-    {
+    if (!quick) {
         const int N = 65536, NB = 1024;
         float* buf; int* hist; CK(hipMalloc(&buf, 8 * N * 4)); CK(hipMalloc(&hist, 32));
         CK(hipMemset(buf, 0, 8 * N * 4)); CK(hipMemset(hist, 0, 32));
