@@ -78,7 +78,7 @@ class Proj:
                    hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), r, w, c)
         self.f3 = (hp_tok.data_ptr(), Bw.data_ptr(), tm, y.data_ptr(), T, r, d_out, 0)
         self.b1 = (y.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), tm, so, part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
-        self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), r, w, c)
+        self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), rt.cross_ws(r).data_ptr(), r, w, c)
         self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, 0)
 
 
@@ -211,6 +211,25 @@ def time_kernels(lib, wl, stream_ptr, iters=2):
     return tot, cnt, per_shape
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: min(affinity, cgroup quota).  (The GPU boxes expose 256 logical
+    CPUs but run the job under a 16-CPU cgroup quota; 256 OpenMP threads on 16 CPUs is ~60x slower.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args):
     """The oracle port (torch fp32, all host cores) on a bounded sample: adapter fwd+bwd of ONE
     decoder layer's 7 projections for ONE sequence, scaled to the 32 layers."""
@@ -218,7 +237,7 @@ def cpu_baseline(args):
     from oracle import moka_oracle as O
     S, r = args.seq, args.rank
     d, ff = LLAMA7B["d"], LLAMA7B["ff"]
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
     masks = [(tok == m).to(torch.int32).reshape(1, S, 1) for m in range(3)] + [q.to(torch.int32).reshape(1, S, 1)]

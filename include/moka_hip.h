@@ -14,9 +14,8 @@
  *     never exits; moka_last_error() returns a thread-local message for the last failure.
  *   - all work is enqueued on `stream` (the caller's current stream); no internal
  *     synchronisation, no default-stream use, no persistent device allocations: workspaces
- *     are owned by the caller.  Entry points are re-entrant (activation checkpointing
- *     re-runs the forward inside backward) as long as two calls in flight do not share a
- *     routing object's `dk_acc` scratch (one backward at a time per routing, the normal case).
+ *     are owned by the caller.  Entry points are re-entrant and stateless (activation
+ *     checkpointing re-runs the forward inside backward).
  *   - token-major layouts: T = B*S flattened tokens, row-major, contiguous.
  *       x  [T, d_in]  bf16      y / gy [T, d_out] bf16      dx [T, d_in] bf16
  *       A_m [r, d_in] bf16 (lora_A{m}.weight / lora_A[name].weight)
@@ -78,8 +77,6 @@ typedef struct moka_routing {
                                  row that still enters the softmax (also for keys whose token has no modality) */
     const int32_t* klen;      /* [B] number of key slots (0: sample has no interaction) */
     const int32_t* kslot;     /* [T] key slot j with ktok[b][j] == t, -1 if token t is not a (non-zero) key row */
-    float*         dk_acc;    /* [B, max(Lk_max,1), 64] fp32 scratch, ZERO on entry; moka_cross_bwd
-                                 leaves it zero again (self-cleaning) */
     int32_t B, S, Lk_max, M;
 } moka_routing;
 
@@ -136,11 +133,13 @@ int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8
 
 /* Backward of the cross-modal interaction: sums the ks partials of g (= dL/dhp), applies the
  * softmax backward for query rows and scatters the key/value gradients back onto the question
- * rows.  Writes the operand packs of s_in * dh for dx (dh_tok) and for dA_m (dh_kmj, one
+ * rows (deterministic: per-block partials summed in a fixed order, no atomics).  Writes the operand packs of s_in * dh for dx (dh_tok) and for dA_m (dh_kmj, one
  * masked plane pair per modality).  dh (fp32) may be NULL. */
 int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routing* rt, float s_in,
-                   float* dh, void* dh_tok, void* dh_kmj,
+                   float* dh, void* dh_tok, void* dh_kmj, void* ws /* moka_cross_ws_bytes() of scratch, no init needed */,
                    int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+/* Scratch size of moka_cross_bwd (per-block key/value gradient partials + flags). */
+size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r);
 
 /* dA_acc[m][k][c] += sum_{t: mod(t)=m} (s_in dh[t][k]) x[t][c]   (fp32 accumulate; NULL skips) and
  * dx[t] += (s_in dh[t]) A[mod(t)]   (in place on the base input-gradient gy W; NULL skips). */

@@ -20,7 +20,7 @@ MOKA_MAX_MOD = 3
 
 
 class MokaRoutingStruct(Structure):
-    _fields_ = [("tok_mod", c_void_p), ("ktok", c_void_p), ("klen", c_void_p), ("kslot", c_void_p), ("dk_acc", c_void_p),
+    _fields_ = [("tok_mod", c_void_p), ("ktok", c_void_p), ("klen", c_void_p), ("kslot", c_void_p),
                 ("B", c_int32), ("S", c_int32), ("Lk_max", c_int32), ("M", c_int32)]
 
 
@@ -50,9 +50,10 @@ SYMBOLS = {
     # gy, hp_kmj, BwT, tok_mod, s_out[], g_part, dB_acc, T, r, d_out, M, dtype, stream
     "moka_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    # g_part, ks, h, rt, s_in, dh, dh_tok, dh_kmj, r, w, c, stream
+    # g_part, ks, h, rt, s_in, dh, dh_tok, dh_kmj, ws, r, w, c, stream
     "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_float,
-                               c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "moka_cross_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     # dh_tok, dh_kmj, x, A[], tok_mod, dA_acc[], dx, T, d_in, r, M, dtype, stream
     "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -58,43 +58,38 @@ static __device__ __forceinline__ void split_hi_lo(float v, unsigned short& hi, 
     lo = f2bf(v - bf2f(hi));
 }
 
+// Wave-wide reductions on the VALU: 4 DPP steps inside each row of 16 lanes (quad swaps, half mirror,
+// row mirror), then the four row results are combined through v_readlane -- ~12 short instructions
+// instead of a chain of 6 dependent ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+static __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    v += dpp_f<0x140>(v);     // row_mirror  -> every lane holds its row's sum
+    const int iv = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
 }
 static __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    const int iv = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
 }
 
-// Sum N per-lane values across the 64 lanes of a wave with N-1 + (6 - log2 N) shuffles instead
-// of 6*N: each butterfly stage halves the number of components a lane still carries.
-// On return v[0] of lane L holds the wave total of component  L >> (6 - log2 N).
+// Sum N per-lane values across the wave; every lane gets all N totals (same DPP + readlane scheme:
+// measured 7800 -> ~1000 cycles per query row against a butterfly of ds_bpermute exchanges).
 template <int N>
-static __device__ __forceinline__ void wave_reduce_scatter(float (&v)[N], int lane) {
-    int off = 32;
-    int n = N;
+static __device__ __forceinline__ void wave_sum_vec(float (&v)[N]) {
 #pragma unroll
-    for (int stage = 0; stage < 6; ++stage) {
-        if (n > 1) {
-            const int half = n >> 1;
-            const bool upper = (lane & off) != 0;
-#pragma unroll
-            for (int k = 0; k < N / 2; ++k) {
-                if (k < half) {
-                    const float send = upper ? v[k] : v[k + half];
-                    const float keep = upper ? v[k + half] : v[k];
-                    v[k] = keep + __shfl_xor(send, off);
-                }
-            }
-            n = half;
-        } else {
-            v[0] += __shfl_xor(v[0], off);
-        }
-        off >>= 1;
-    }
+    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
 }
 
 // position of token (t & 31) inside its group of 32 in the rank-major packs
@@ -260,7 +255,8 @@ struct CrossArgs {
     const int* ktok;                // [B][max(Lk_max,1)] flat token index of key slot j, -1 = zero row
     const int* klen;                // [B]
     const int* kslot;               // [T]
-    float* dk_acc;                  // [B][max(Lk_max,1)][RP]
+    float* dk_part;                 // bwd: [B][nblk][Lkp][RP] per-block key/value gradient partials
+    int* dk_flag;                   // bwd: [B][nblk] 1 if the block wrote a partial
     float* out_f32;                 // fwd: h (never null)        bwd: dh or null
     float* out_f32b;                // fwd: hp or null
     unsigned short* pack_tok;       // [Tp][2*RP]
@@ -298,43 +294,52 @@ static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t
     }
 }
 
-// Forward.  Block = 8 waves, 32 token rows of one sample.  Phase A: sum the split-K partials of the
-// block's rows and of the sample's key rows (all loads in flight at once).  Phase B: one wave per
-// query row, one lane per key.  Phase C: fp32 outputs + operand packs.  Every block also
-// transposes a slice of Bw into BwT (weights do not change between forward and backward).
+// Forward.  Block = 8 waves, RB (<= 32) token rows of one sample.  Latency structure: ONE batch of
+// global loads at kernel start (routing bytes, key-token indices, the block's partial rows), one
+// dependent batch (the key rows), then LDS-only work: one wave per query row, one lane per key.
+// Every block also transposes a slice of Bw into BwT (weights do not change until the backward).
 template <int RP, int KCH>
-__global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) {
+__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cross_fwd_kernel(const CrossArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = RP + 1;
     float* Hs = (float*)smem;                  // [32][KP]  h rows
     float* Hp = Hs + 32 * KP;                  // [32][KP]  hp rows
     float* Ks = Hp + 32 * KP;                  // [Lkp][KP]
+    int* Kt = (int*)(Ks + (size_t)a.Lkp * KP); // [Lkp] flat key token indices
+    __shared__ int s_mod[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
     const int nrow = min(a.RB, a.S - r0);
-    const int Lk = min(a.klen[b], a.Lk_max);
-
-    int anyq = 0;
-    if (tid < nrow) {
-        const int m = a.tok_mod[b * a.S + r0 + tid];
-        anyq = (m != 0 && m != MOKA_MOD_NONE);
-    }
+    // ---- batch 1: everything that does not depend on other loads
+    const int klen_b = a.klen[b];
+    int my_mod = MOKA_MOD_NONE;
+    if (tid < nrow) my_mod = a.tok_mod[b * a.S + r0 + tid];
+    for (int j = tid; j < a.Lkp; j += 512) Kt[j] = a.ktok[b * a.Lkp + j];
     for (int e = tid; e < 32 * RP; e += 512) {
         const int row = e / RP, k = e % RP;
         float v = 0.f;
         if (row < nrow) {
             const int t = b * a.S + r0 + row;
-            if (a.tok_mod[t] != MOKA_MOD_NONE)
-                for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
+            for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];   // garbage for tokens of no modality
         }
+        Hs[row * KP + k] = v;
+    }
+    if (tid < 32) s_mod[tid] = my_mod;
+    const int Lk = min(klen_b, a.Lk_max);
+    const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
+    // tokens of no modality: h = 0 (their partial rows were never written)
+    for (int e = tid; e < 32 * RP; e += 512) {
+        const int row = e / RP, k = e % RP;
+        float v = Hs[row * KP + k];
+        if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;
         Hs[row * KP + k] = v;
         Hp[row * KP + k] = v;
     }
-    anyq = __syncthreads_or(anyq) && (Lk > 0);
     if (anyq) {
+        // ---- batch 2: the sample's key rows (indices are in LDS by now)
         for (int e = tid; e < Lk * RP; e += 512) {
             const int j = e / RP, k = e % RP;
-            const int t = a.ktok[b * a.Lkp + j];
+            const int t = Kt[j];
             float v = 0.f;
             if (t >= 0)
                 for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
@@ -342,7 +347,7 @@ __global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) 
         }
         __syncthreads();
         for (int row = wave; row < nrow; row += 8) {
-            const int m = a.tok_mod[b * a.S + r0 + row];
+            const int m = s_mod[row];
             if (m == 0 || m == MOKA_MOD_NONE) continue;           // wave uniform
             float q[RP];
 #pragma unroll
@@ -382,10 +387,12 @@ __global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) 
                     for (int k = 0; k < RP; ++k) o[k] = fmaf(sc[ch], Ks[j * KP + k], o[k]);
                 }
             }
-            wave_reduce_scatter<RP>(o, lane);
-            constexpr int SH = (RP == 16) ? 2 : (RP == 32 ? 1 : 0);
-            const int comp = lane >> SH;
-            if ((lane & ((1 << SH) - 1)) == 0) Hp[row * KP + comp] = Hs[row * KP + comp] + a.w * o[0] / l;
+            wave_sum_vec<RP>(o);
+            const float wl = a.w / l;
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < RP; ++k) Hp[row * KP + k] = q[k] + wl * o[k];
+            }
         }
     }
     __syncthreads();
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) 
         const float hv = Hs[row * KP + k], hpv = Hp[row * KP + k];
         a.out_f32[(size_t)t * RP + k] = hv;
         if (a.out_f32b) a.out_f32b[(size_t)t * RP + k] = hpv;
-        write_packs_fwd<RP>(a, t, k, hpv * mod_scale(a.s_mod, a.tok_mod[t]));
+        write_packs_fwd<RP>(a, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
     }
     // pack tail [T, Tp): zero (the weight-gradient kernel reads whole groups of 32 tokens)
     if (b == a.B - 1 && blockIdx.y == gridDim.y - 1) {
@@ -411,11 +418,12 @@ __global__ void __launch_bounds__(512) moka_cross_fwd_kernel(const CrossArgs a) 
     }
 }
 
-// Backward, part a.  Same block shape.  Query rows: recompute the softmax, dq, and per-lane key/value
-// gradients; the block's dK is combined in LDS and added to the sample's dk_acc with fp32 atomics.
-// Rows that are themselves key rows are finished by part b (their dq, if any, goes to dk_acc too).
+// Backward, part a.  Same block shape and latency structure.  Query rows: recompute the softmax, dq,
+// and per-lane key/value gradients; the block's dK is combined in LDS and written to the block's own
+// partial slot.  Rows that are themselves key rows are finished by part b (their dq, if any, joins
+// their dK slot).
 template <int RP, int KCH>
-__global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) {
+__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cross_bwd_kernel(const CrossArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = RP + 1;
     float* Gs = (float*)smem;                  // [32][KP]  g rows
@@ -423,35 +431,43 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
     float* Hs = Dh + 32 * KP;                  // [32][KP]  h rows (queries)
     float* Ks = Hs + 32 * KP;                  // [Lkp][KP]
     float* dKs = Ks + (size_t)a.Lkp * KP;      // [Lkp][KP]
+    int* Kt = (int*)(dKs + (size_t)a.Lkp * KP);// [Lkp]
+    __shared__ int s_mod[32], s_slot[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
     const int nrow = min(a.RB, a.S - r0);
-    const int Lk = min(a.klen[b], a.Lk_max);
 
-    int anyq = 0;
-    if (tid < nrow) {
-        const int m = a.tok_mod[b * a.S + r0 + tid];
-        anyq = (m != 0 && m != MOKA_MOD_NONE);
-    }
+    // ---- batch 1
+    const int klen_b = a.klen[b];
+    int my_mod = MOKA_MOD_NONE, my_slot = -1;
+    if (tid < nrow) { my_mod = a.tok_mod[b * a.S + r0 + tid]; my_slot = a.kslot[b * a.S + r0 + tid]; }
+    for (int j = tid; j < a.Lkp; j += 512) Kt[j] = a.ktok[b * a.Lkp + j];
     for (int e = tid; e < 32 * RP; e += 512) {
         const int row = e / RP, k = e % RP;
         float v = 0.f, hv = 0.f;
         if (row < nrow) {
             const int t = b * a.S + r0 + row;
-            if (a.tok_mod[t] != MOKA_MOD_NONE) {
-                for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
-                hv = a.hfull[(size_t)t * RP + k];
-            }
+            for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
+            hv = a.hfull[(size_t)t * RP + k];
         }
         Gs[row * KP + k] = v;
-        Dh[row * KP + k] = v;
         Hs[row * KP + k] = hv;
     }
-    anyq = __syncthreads_or(anyq) && (Lk > 0);
+    if (tid < 32) { s_mod[tid] = my_mod; s_slot[tid] = my_slot; }
+    const int Lk = min(klen_b, a.Lk_max);
+    const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
+    for (int e = tid; e < 32 * RP; e += 512) {
+        const int row = e / RP, k = e % RP;
+        float v = Gs[row * KP + k];
+        if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;   // unwritten partial rows
+        Gs[row * KP + k] = v;
+        Dh[row * KP + k] = v;
+    }
     if (anyq) {
+        // ---- batch 2: key rows of h
         for (int e = tid; e < Lk * RP; e += 512) {
             const int j = e / RP, k = e % RP;
-            const int t = a.ktok[b * a.Lkp + j];
+            const int t = Kt[j];
             Ks[j * KP + k] = (t >= 0) ? a.hfull[(size_t)t * RP + k] : 0.f;
             dKs[j * KP + k] = 0.f;
         }
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
 #pragma unroll
             for (int k = 0; k < RP; ++k) dK[ch][k] = 0.f;
         for (int row = wave; row < nrow; row += 8) {
-            const int m = a.tok_mod[b * a.S + r0 + row];
+            const int m = s_mod[row];
             if (m == 0 || m == MOKA_MOD_NONE) continue;
             float q[RP], dO[RP];
 #pragma unroll
@@ -511,39 +527,46 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
                     }
                 }
             }
-            wave_reduce_scatter<RP>(dq, lane);
-            constexpr int SH = (RP == 16) ? 2 : (RP == 32 ? 1 : 0);
-            const int comp = lane >> SH;
-            if ((lane & ((1 << SH) - 1)) == 0) Dh[row * KP + comp] = Gs[row * KP + comp] + dq[0];
-        }
+            wave_sum_vec<RP>(dq);
+            if (lane == 0) {
 #pragma unroll
-        for (int ch = 0; ch < KCH; ++ch) {
-            const int j = lane + 64 * ch;
-            if (j < Lk) {
-#pragma unroll
-                for (int k = 0; k < RP; ++k) atomicAdd(&dKs[j * KP + k], dK[ch][k]);
+                for (int k = 0; k < RP; ++k) Dh[row * KP + k] = Gs[row * KP + k] + dq[k];
             }
         }
-        __syncthreads();
-        for (int e = tid; e < Lk * RP; e += 512) {
-            const int j = e / RP, k = e % RP;
-            atomicAdd(&a.dk_acc[((size_t)b * a.Lkp + j) * RP + k], dKs[j * KP + k]);
+        // combine the 8 waves' key/value gradients: one wave at a time, plain LDS read-modify-write
+        // (measured: LDS fp32 atomics cost ~700 cycles per wave instruction under 8-wave contention)
+        for (int w = 0; w < 8; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int ch = 0; ch < KCH; ++ch) {
+                    const int j = lane + 64 * ch;
+                    if (j < Lk) {
+#pragma unroll
+                        for (int k = 0; k < RP; ++k) dKs[j * KP + k] += dK[ch][k];
+                    }
+                }
+            }
+            __syncthreads();
         }
+        // a key row that is also a query row (masks may overlap in VT): its dq joins its own dK slot
+        for (int e = tid; e < nrow * RP; e += 512) {
+            const int row = e / RP, k = e % RP;
+            const int slot = s_slot[row];
+            if (slot >= 0) dKs[slot * KP + k] += Dh[row * KP + k] - Gs[row * KP + k];
+        }
+        __syncthreads();
+        float* dst = a.dk_part + ((size_t)b * gridDim.y + blockIdx.y) * a.Lkp * RP;
+        for (int e = tid; e < Lk * RP; e += 512) dst[e] = dKs[(e / RP) * KP + (e % RP)];
     } else {
         __syncthreads();
     }
+    if (tid == 0) a.dk_flag[b * gridDim.y + blockIdx.y] = anyq ? 1 : 0;
     for (int e = tid; e < nrow * RP; e += 512) {
         const int row = e / RP, k = e % RP;
+        if (s_slot[row] >= 0) continue;                   // key row: finished by part b
         const int t = b * a.S + r0 + row;
-        const int m = a.tok_mod[t];
-        const int slot = a.kslot[t];
+        const int m = s_mod[row];
         const float dv = Dh[row * KP + k];
-        if (slot >= 0) {
-            // key row: finished by part b; hand over the query contribution (if this row is also a query)
-            const float dq = dv - Gs[row * KP + k];
-            if (dq != 0.f) atomicAdd(&a.dk_acc[((size_t)b * a.Lkp + slot) * RP + k], dq);
-            continue;
-        }
         if (a.out_f32) a.out_f32[(size_t)t * RP + k] = dv;
         write_packs_bwd<RP>(a, t, k, m, (m == MOKA_MOD_NONE) ? 0.f : dv * a.s_mod[0]);
     }
@@ -552,17 +575,40 @@ __global__ void __launch_bounds__(512) moka_cross_bwd_kernel(const CrossArgs a) 
     }
 }
 
-// Backward, part b: the key rows  dh[key_j] = g[key_j] + dk_acc[j];  re-zeroes dk_acc.
+// Backward, part b: the key rows  dh[key_j] = g[key_j] + sum over the sample's blocks of their dK partial.
+// Deterministic (fixed summation order), no atomics, no scratch that has to be zero on entry.
 template <int RP>
-__global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossArgs a) {
-    const int b = blockIdx.x;
-    const int e = blockIdx.y * 256 + threadIdx.x;
-    if (e >= a.Lkp * RP) return;
+__global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossArgs a, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* list = (int*)smem;                           // [nblk] indices of the blocks that wrote a partial
+    __shared__ int s_n;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {                                   // wave 0 compacts the flag list
+        int n = 0;
+        for (int base = 0; base < nblk; base += 64) {
+            const int blk = base + lane;
+            const bool f = blk < nblk && a.dk_flag[b * nblk + blk] != 0;
+            const unsigned long long mask = __ballot(f);
+            if (f) list[n + __popcll(mask & ((1ull << lane) - 1ull))] = blk;
+            n += __popcll(mask);
+        }
+        if (lane == 0) s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    // 16 lanes per (key slot, rank) element: each sums a strided share of the flagged partials
+    const int e = blockIdx.y * 16 + (tid >> 4), sub = tid & 15;
+    const bool live = e < a.Lkp * RP;
+    float v = 0.f;
+    if (live) {
+        const float* src = a.dk_part + (size_t)b * nblk * a.Lkp * RP + e;
+        for (int q = sub; q < n; q += 16) v += src[(size_t)list[q] * a.Lkp * RP];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (!live || sub != 0) return;
     const int j = e / RP, k = e % RP;
-    float* acc = &a.dk_acc[((size_t)b * a.Lkp + j) * RP + k];
     const int t = a.ktok[b * a.Lkp + j];
-    float v = *acc;
-    *acc = 0.f;
     if (t < 0 || a.kslot[t] != j) return;           // zero key row / not the owner of that token
     for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
     if (a.out_f32) a.out_f32[(size_t)t * RP + k] = v;
@@ -738,14 +784,15 @@ struct WgradArgs {
     int per_mod;                    // 1: one pack plane per modality (dA); 0: single (dB)
 };
 
-// Block = NW waves owning NSB*64 columns for a long run of tokens.  Each wave walks over groups of 32
-// tokens with a 2-deep software pipeline: tok_mod of group i+2 and the [32 tokens][NSB*64 columns]
-// tile of group i+1 are in flight while group i goes, 64 columns at a time, through a wave-private
-// 5 KB LDS region and is read back transposed (ds_read_b64_tr_b16) as the MFMA A operand (rows =
-// columns of `in`, K = tokens); B operand = the rank-major pack (16-byte loads from L2).
-// One accumulator set per wave: tokens arrive in modality runs, so the set leaves the wave only when
-// the modality changes (rare: straight to fp32 atomics) and once at the end (private LDS region,
-// plain stores; the block then sums the NW regions and issues one atomic per (column, rank)).
+// Block = NW waves owning NSB*64 columns for a long run of tokens.  Each wave walks over a contiguous
+// run of 32-token groups with a 2-deep software pipeline: tok_mod of group i+2 and the
+// [32 tokens][NSB*64 columns] tile + pack fragments of group i+1 are in flight while group i goes,
+// 64 columns at a time, through a wave-private 5 KB LDS region and is read back transposed
+// (ds_read_b64_tr_b16) as the MFMA A operand (rows = columns of `in`, K = tokens); B operand = the
+// rank-major pack of each modality present (masked planes: a plane only carries its own tokens).
+// One accumulator set per modality, so span boundaries cost nothing but an extra MFMA chain.
+// At the end the NW waves' tiles are summed through private LDS regions (plain stores), one
+// modality at a time, and leave the chip as one coalesced fp32 atomic per (column, rank).
 template <int RP, int NSB, int NW, bool OUT_CK>
 __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -760,44 +807,41 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
     const int c_begin = blockIdx.x * CCB;
     unsigned char* my = smem + wave * REGION;
     float* red = (float*)(smem + NW * REGION);      // [NW][CCB][RP]  per-wave partial sums
-    int* tag = (int*)(red + (size_t)NW * CCB * RP); // [NW] modality of each wave's partial sum
+    unsigned* touched = (unsigned*)(red + (size_t)NW * CCB * RP);
     const int ngroups = a.Tp >> 5;
     const int grp_begin = blockIdx.y * a.groups_per_block;
     const int grp_end = min(ngroups, grp_begin + a.groups_per_block);
     const int lrow = lane >> 3, lcol = lane & 7;
+    if (tid == 0) *touched = 0;
 
-    f32x4 acc[NSB][CT][NT];
-    int cur = -1;                                   // modality the accumulators currently belong to
-    auto zero_acc = [&]() {
+    f32x4 acc[NM][NSB][CT][NT];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[sb][ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-    // D[row = column c (4g+reg)][col = rank k (i)]
-    auto flush_global = [&](int m) {               // rare: the modality run changed inside this wave
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int c = c_begin + sb * 64 + ct * 16 + 4 * g + reg, k = nt * 16 + i;
-                        if (c < a.C && k < a.r)
-                            atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), acc[sb][ct][nt][reg]);
-                    }
-    };
+                for (int nt = 0; nt < NT; ++nt) acc[m][sb][ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned ever = 0;
+
     auto present_of = [&](int mym) -> unsigned {
         unsigned p = 0;
 #pragma unroll
         for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mym == m)) p |= 1u << m;
-        return p;
+        return a.per_mod ? p : (p ? 1u : 0u);
     };
-    auto issue = [&](uint4 (&ld)[NSB][4], int grp) {
+    // B operand fragments (rank-major pack): lane (k = i, g) -> tokens at positions 8g..8g+7 of the group
+    auto load_pack = [&](bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp, int m) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned short* ph = a.pack + (((size_t)m * 2 + 0) * RP + nt * 16 + i) * a.Tp + (grp << 5) + 8 * g;
+            bh[nt] = *(const bf16x8*)ph;
+            bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
+        }
+    };
+    // tile loads + the pack fragments of the group's first modality (the only one, except on span boundaries)
+    auto issue = [&](uint4 (&ld)[NSB][4], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp, unsigned pm) {
         const int t0 = grp << 5;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -809,99 +853,96 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
                 if (c < a.C) ld[sb][u] = *(const uint4*)(a.in + (rowoff + c) * 2);
             }
         }
+        load_pack(bh, bl, grp, __builtin_ctz(pm));
     };
-    auto compute = [&](uint4 (&ld)[NSB][4], int grp, unsigned present) {
-        const int t0 = grp << 5;
-        const unsigned pm = a.per_mod ? present : 1u;
+    auto compute = [&](uint4 (&ld)[NSB][4], bf16x8 (&bh0)[NT], bf16x8 (&bl0)[NT], int grp, unsigned pm) {
+        const int mfirst = __builtin_ctz(pm);
+        ever |= pm;
+        // span boundary inside the group (rare): fetch the other planes before touching LDS
+        bf16x8 bhx[NM][NT], blx[NM][NT];
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            if (!(pm & (1u << m))) continue;
-            if (m != cur) {                                       // modality run changed (wave uniform)
-                if (cur >= 0) { flush_global(cur); zero_acc(); }
-                cur = m;
-            }
-            // B operand fragments (rank-major pack): lane (k = i, g) -> tokens at positions 8g..8g+7 of the group
-            bf16x8 bh[NT], bl[NT];
+            if ((pm & (1u << m)) && m != mfirst) load_pack(bhx[m], blx[m], grp, m);
+        }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const unsigned short* ph = a.pack + (((size_t)m * 2 + 0) * RP + nt * 16 + i) * a.Tp + t0 + 8 * g;
-                bh[nt] = *(const bf16x8*)ph;
-                bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
-            }
+        for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) {
+            for (int u = 0; u < 4; ++u) *(uint4*)(my + (8 * u + lrow) * PITCH + lcol * 16) = ld[sb][u];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) *(uint4*)(my + (8 * u + lrow) * PITCH + lcol * 16) = ld[sb][u];
+            for (int ct = 0; ct < CT; ++ct) {
+                const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
+                const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
-                    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
-                    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
-                    const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                for (int m = 0; m < NM; ++m) {
+                    if (!(pm & (1u << m))) continue;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[sb][ct][nt] = MFMA16(av, bh[nt], acc[sb][ct][nt]);
-                        acc[sb][ct][nt] = MFMA16(av, bl[nt], acc[sb][ct][nt]);
+                        const bf16x8 bh = (m == mfirst) ? bh0[nt] : bhx[m][nt];
+                        const bf16x8 bl = (m == mfirst) ? bl0[nt] : blx[m][nt];
+                        acc[m][sb][ct][nt] = MFMA16(av, bh, acc[m][sb][ct][nt]);
+                        acc[m][sb][ct][nt] = MFMA16(av, bl, acc[m][sb][ct][nt]);
                     }
                 }
             }
         }
     };
-    zero_acc();
 
-    // ---- 2-deep pipeline over this wave's CONTIGUOUS run of groups (few modality changes per wave)
+    // ---- 2-deep pipeline over this wave's CONTIGUOUS run of groups
     uint4 ldA[NSB][4], ldB[NSB][4];
+    bf16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
     const int per_wave = (grp_end - grp_begin + NW - 1) / NW;
     int grp = grp_begin + wave * per_wave;
     const int wend = min(grp_end, grp + per_wave);
     int mym_cur = (grp < wend) ? a.tok_mod[(grp << 5) + (lane & 31)] : MOKA_MOD_NONE;
     int mym_nxt = (grp + 1 < wend) ? a.tok_mod[((grp + 1) << 5) + (lane & 31)] : MOKA_MOD_NONE;
     unsigned pres_cur = present_of(mym_cur);
-    if (pres_cur) issue(ldA, grp);
+    if (pres_cur) issue(ldA, bhA, blA, grp, pres_cur);
     while (grp < wend) {
         int mym_nn = (grp + 2 < wend) ? a.tok_mod[((grp + 2) << 5) + (lane & 31)] : MOKA_MOD_NONE;
         unsigned pres_nxt = present_of(mym_nxt);
-        if (pres_nxt) issue(ldB, grp + 1);
-        if (pres_cur) compute(ldA, grp, pres_cur);
+        if (pres_nxt) issue(ldB, bhB, blB, grp + 1, pres_nxt);
+        if (pres_cur) compute(ldA, bhA, blA, grp, pres_cur);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
         if (grp >= wend) break;
         mym_nn = (grp + 2 < wend) ? a.tok_mod[((grp + 2) << 5) + (lane & 31)] : MOKA_MOD_NONE;
         pres_nxt = present_of(mym_nxt);
-        if (pres_nxt) issue(ldA, grp + 1);
-        if (pres_cur) compute(ldB, grp, pres_cur);
+        if (pres_nxt) issue(ldA, bhA, blA, grp + 1, pres_nxt);
+        if (pres_cur) compute(ldB, bhB, blB, grp, pres_cur);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
     }
 
-    // ---- block reduction: private regions (plain stores), then one atomic per (column, rank, modality)
+    // ---- block reduction, one modality at a time through the private regions
+    if (lane == 0 && ever) atomicOr(touched, ever);
+    __syncthreads();
+    const unsigned any = *touched;
     float* mine = red + (size_t)wave * CCB * RP;
 #pragma unroll
-    for (int sb = 0; sb < NSB; ++sb)
+    for (int m = 0; m < NM; ++m) {
+        if (!(any & (1u << m))) continue;                         // block uniform
+        // D[row = column c (4g+reg)][col = rank k (i)]
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    mine[(sb * 64 + ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = acc[sb][ct][nt][reg];
-    if (lane == 0) tag[wave] = cur;
-    __syncthreads();
-    int tags[NW];
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int w = 0; w < NW; ++w) tags[w] = tag[w];
-    for (int e = tid; e < CCB * RP; e += NW * 64) {
-        // consecutive threads -> consecutive addresses of the destination ([C][r] for dB, [r][C] for dA)
-        const int k = OUT_CK ? (e % RP) : (e / CCB), cl = OUT_CK ? (e / RP) : (e % CCB);
-        const int c = c_begin + cl;
-        if (c >= a.C || k >= a.r) continue;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
+                    for (int reg = 0; reg < 4; ++reg)
+                        mine[(sb * 64 + ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = acc[m][sb][ct][nt][reg];
+        __syncthreads();
+        for (int e = tid; e < CCB * RP; e += NW * 64) {
+            // consecutive threads -> consecutive addresses of the destination ([C][r] for dB, [r][C] for dA)
+            const int k = OUT_CK ? (e % RP) : (e / CCB), cl = OUT_CK ? (e / RP) : (e % CCB);
+            const int c = c_begin + cl;
+            if (c >= a.C || k >= a.r) continue;
             float sum = 0.f;
-            bool any = false;
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
-                if (tags[w] == m) { sum += red[((size_t)w * CCB + cl) * RP + k]; any = true; }
-            if (any) atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), sum);
+            for (int w = 0; w < NW; ++w) sum += red[((size_t)w * CCB + cl) * RP + k];
+            atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), sum);
         }
+        __syncthreads();
     }
 }
 
@@ -973,6 +1014,8 @@ static int reduce_ks(int T, int C) {
     return ks;
 }
 
+static int cross_rows_per_block() { return (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) ? g_tune_cross_rows : 8; }
+
 static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     if (dtype != MOKA_BF16) return fail(MOKA_EDTYPE, "%s: only bf16 storage is implemented (dtype=%d)", fn, dtype);
     if (T < 1) return fail(MOKA_EINVAL, "%s: T=%d", fn, T);
@@ -1001,14 +1044,14 @@ template <int RP, int KCH>
 static void launch_cross_t(bool bwd, const CrossArgs& a, hipStream_t st) {
     dim3 grid(a.B, (a.S + a.RB - 1) / a.RB), block(512);
     if (!bwd) {
-        const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4;
+        const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
         ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH>, lds);
         hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH>), grid, block, lds, st, a);
     } else {
-        const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4;
+        const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
         ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH>, lds);
         hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH>), grid, block, lds, st, a);
-        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 255) / 256), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16), dim3(256), (size_t)grid.y * 4, st, a, (int)grid.y);
     }
 }
 
@@ -1018,15 +1061,15 @@ static int launch_cross(bool bwd, CrossArgs& a, const moka_routing* rt, int r, h
     if (RP < 0) return fail(MOKA_EINVAL, "%s: rank %d not in 1..64", fn, r);
     if (!rt) return fail(MOKA_EINVAL, "%s: null routing", fn);
     if (a.ks < 1 || rt->B < 1 || rt->S < 1) return fail(MOKA_EINVAL, "%s: ks=%d B=%d S=%d", fn, a.ks, rt->B, rt->S);
-    if (!rt->tok_mod || !rt->klen || !rt->ktok || !rt->kslot || !rt->dk_acc) return fail(MOKA_EINVAL, "%s: null routing pointer", fn);
+    if (!rt->tok_mod || !rt->klen || !rt->ktok || !rt->kslot) return fail(MOKA_EINVAL, "%s: null routing pointer", fn);
     const int Lk = rt->Lk_max;
     if (Lk < 0 || Lk > 512) return fail(MOKA_EINVAL, "%s: Lk_max=%d not in 0..512", fn, Lk);
     const int kch = Lk <= 64 ? 1 : (Lk <= 128 ? 2 : (Lk <= 256 ? 4 : 8));
     if (kch * RP > 128) return fail(MOKA_EINVAL, "%s: Lk_max=%d with rank pad %d exceeds the register budget", fn, Lk, RP);
-    a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot; a.dk_acc = rt->dk_acc;
+    a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot;
     a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
     a.r = r; a.M = rt->M;
-    a.RB = (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) ? g_tune_cross_rows : 8;
+    a.RB = cross_rows_per_block();
     if ((size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 > 150 * 1024) return fail(MOKA_EINVAL, "%s: key block does not fit LDS", fn);
     if (RP == 16) {
         if (kch == 1) launch_cross_t<16, 1>(bwd, a, st); else if (kch == 2) launch_cross_t<16, 2>(bwd, a, st);
@@ -1157,11 +1200,24 @@ int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const floa
     return launch_cross(false, a, rt, r, (hipStream_t)stream);
 }
 
+size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r) {
+    const int RP = rank_pad(r);
+    if (RP < 0 || B < 1 || S < 1 || Lk_max < 0) return 0;
+    const size_t nblk = (size_t)(S + 7) / 8;                       // smallest row block -> largest block count
+    const size_t flags = ((size_t)B * nblk * 4 + 255) / 256 * 256;
+    return flags + (size_t)B * nblk * (Lk_max > 0 ? Lk_max : 1) * RP * 4;
+}
+
 int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routing* rt, float s_in,
-                   float* dh, void* dh_tok, void* dh_kmj, int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
-    if (!g_part || !rt || !h || !dh_tok || !dh_kmj) return fail(MOKA_EINVAL, "moka_cross_bwd: null pointer");
+                   float* dh, void* dh_tok, void* dh_kmj, void* ws, int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
+    if (!g_part || !rt || !h || !dh_tok || !dh_kmj || !ws) return fail(MOKA_EINVAL, "moka_cross_bwd: null pointer");
     CrossArgs a;
     memset(&a, 0, sizeof(a));
+    {
+        const size_t nblk8 = (size_t)(rt->S + 7) / 8;
+        a.dk_flag = (int*)ws;
+        a.dk_part = (float*)((unsigned char*)ws + ((size_t)rt->B * nblk8 * 4 + 255) / 256 * 256);
+    }
     a.part = g_part; a.ks = ks; a.hfull = h; a.out_f32 = dh;
     a.pack_tok = (unsigned short*)dh_tok; a.pack_kmj = (unsigned short*)dh_kmj;
     for (int m = 0; m < MOKA_MAX_MOD; ++m) a.s_mod[m] = s_in;

@@ -122,7 +122,7 @@ def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, s_
     st.dh_kmj = torch.empty((rt.M, 2, RP, Tp), dtype=torch.bfloat16, device=dev)
     _lib.check(lib.moka_cross_bwd(g_part.data_ptr(), ks, h.data_ptr(), byref(rt.struct), float(s_in),
                                   None if st.dh is None else st.dh.data_ptr(), st.dh_tok.data_ptr(), st.dh_kmj.data_ptr(),
-                                  r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_bwd")
+                                  rt.cross_ws(r).data_ptr(), r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_bwd")
     return st
 
 

@@ -43,10 +43,20 @@ class MokaRouting:
             slots = torch.arange(Lkp, device=dev, dtype=torch.int32)[None, :].expand(B, Lkp)
             kslot[flat[live]] = slots[live]
         self.kslot = kslot.contiguous()
-        # fp32 scratch of the key/value gradients: zero on entry, left zero by moka_cross_bwd
-        self.dk_acc = torch.zeros((B, Lkp, 64), dtype=torch.float32, device=dev)
+        self._ws = {}
         self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.ktok.data_ptr(), self.klen.data_ptr(),
-                                             self.kslot.data_ptr(), self.dk_acc.data_ptr(), B, S, Lk_max, M)
+                                             self.kslot.data_ptr(), B, S, Lk_max, M)
+
+    def cross_ws(self, r: int) -> torch.Tensor:
+        """Scratch of moka_cross_bwd for rank r (no initialisation needed; one per routing and rank pad,
+        consumed inside the call, so consecutive layers share it)."""
+        rp = _lib.rank_pad(r)
+        ws = self._ws.get(rp)
+        if ws is None:
+            n = int(_lib.load().moka_cross_ws_bytes(self.B, self.S, self.Lk_max, int(r)))
+            ws = torch.empty(max(n, 256), dtype=torch.uint8, device=self.tok_mod.device)
+            self._ws[rp] = ws
+        return ws
 
     @property
     def device(self):

@@ -157,7 +157,6 @@ def _stage_check(cd, y0=None, tol_f32=TOL_F32):
     bst = F.cross_bwd(g_part, st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk, want_dh=True)
     # rows of no modality feed nothing downstream (no A_m, no dx): compare routed rows only
     assert rel(bst.dh[:, :r][vdev], dho.reshape(T, r)[valid]) < tol_f32, "cross_bwd"
-    assert float(rt.dk_acc.abs().max()) == 0.0, "dk_acc must be left zero"
     dtok = bst.dh_tok[:T].float()
     assert rel((dtok[:, :RP] + dtok[:, RP:])[:, :r][vdev], (spec.s_in * dho.reshape(T, r))[valid]) < tol_f32, "dh_tok pack"
     dA_acc = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]

@@ -63,7 +63,7 @@ def main():
             "up_bwd(g only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), None, T, r, d_out, M, 0, sp()),
             "up_bwd(g+dB)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
             "cross_bwd": lambda i: lib.moka_cross_bwd(w["part"].data_ptr(), _lib.ksplit(T, d_out, r), w["h"].data_ptr(), byref(rt.struct), 1.0, None,
-                                                      w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), r, 1.0, c, sp()),
+                                                      w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), rt.cross_ws(r).data_ptr(), r, 1.0, c, sp()),
             "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, dAp, None, T, d_in, r, M, 0, sp()),
             "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, 0, sp()),
         }
