@@ -58,7 +58,7 @@ def algorithmic_bytes_per_token(d, ff, r, layers):
 class Proj:
     """One adapted projection: device buffers + pre-built ctypes arguments for the six launches."""
 
-    def __init__(self, lib, name, d_in, d_out, r, M, T, bufs, params, grads, ws, rt, s_in, s_out, w, c):
+    def __init__(self, lib, name, d_in, d_out, r, M, T, bufs, params, grads, ws, rt, s_in, s_out, w, c, drop_p=0.0, seed=0):
         from moka_amd import _lib
         self.name, self.d_in, self.d_out = name, d_in, d_out
         self.ks_in = _lib.ksplit(T, d_in, r)
@@ -73,13 +73,13 @@ class Proj:
         so = (c_float * M)(*s_out)
         self._c = (Ap, dAp, so)
         tm = rt.tok_mod.data_ptr()
-        self.f1 = (x.data_ptr(), Ap, tm, part.data_ptr(), T, d_in, r, M, s_in, 0)
+        self.f1 = (x.data_ptr(), Ap, tm, part.data_ptr(), T, d_in, r, M, s_in, drop_p, seed, 0)
         self.f2 = (part.data_ptr(), self.ks_in, byref(rt.struct), so, Bw.data_ptr(), d_out, h.data_ptr(), None,
                    hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), r, w, c)
         self.f3 = (hp_tok.data_ptr(), Bw.data_ptr(), tm, y.data_ptr(), T, r, d_out, 0)
         self.b1 = (y.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), tm, so, part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
         self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), rt.cross_ws(r).data_ptr(), r, w, c)
-        self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, 0)
+        self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)
 
 
 def build_workload(args, dev, lib, bucket_factory):
@@ -153,7 +153,7 @@ def build_workload(args, dev, lib, bucket_factory):
             h, hp_kmj, BwT = saved[l][pi]
             wsl = (part, h, hp_tok, hp_kmj, BwT, dh_tok, dh_kmj)
             projs.append(Proj(lib, name, d_in, d_out, r, M, T, (acts[src], ys[pi], dxs[pi]), (A, Bw), (dA, dB), wsl, rt,
-                              s, [1.0] * M, 1.0, 1.0 / math.sqrt(r)))
+                              s, [1.0] * M, 1.0, 1.0 / math.sqrt(r), drop_p=args.dropout, seed=1000003 * l + pi))
         layer_end.append(off)
     assert off == n_params
     work.copy_(master)
@@ -280,6 +280,7 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--layers", type=int, default=LLAMA7B["layers"])
     ap.add_argument("--distinct", type=int, default=4, help="distinct activation buffer sets cycled over the layers")
+    ap.add_argument("--dropout", type=float, default=0.05, help="lora_dropout (both reference scripts train with 0.05)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
@@ -374,8 +375,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Llama-2-7B dims, MokA r=16 M=3 (AVT semantics), adapter fwd+bwd of 7x%d projections, "
-                                   "seq=2048 (256 image + 128 audio + 64 question + text), batch %d seq/GPU, "
-                                   "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params" % (args.layers, args.batch),
+                                   "seq=2048 (256 image + 128 audio + 64 question + text), lora_dropout %g, batch %d seq/GPU, "
+                                   "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params" % (args.layers, args.dropout, args.batch),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),

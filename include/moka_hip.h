@@ -102,10 +102,14 @@ int moka_ksplit(int T, int C, int r);
 /* Per-modality masked down-projection  part[s][t] = partial over d_in slice s of
  * s_in * x[t] A[mod(t)]^T.  Replaces lora.py:468-477 (3 dense masked GEMMs) and
  * layer.py:603-621 (gather + GEMM + index_put).  Tiles made only of MOKA_MOD_NONE tokens are
- * skipped (their partial rows stay unwritten; consumers treat such rows as zero). */
+ * skipped (their partial rows stay unwritten; consumers treat such rows as zero).
+ * Dropout (lora_dropout, lora.py:264-267 / layer.py:101-106): with dropout_p > 0 the kernel computes
+ * s_in/(1-p') * (keep .* x[t]) A^T where keep is the counter-based mask of (seed, t, column) and
+ * p' = round(p * 65536) / 65536; pass the SAME (dropout_p, seed) to moka_down_bwd. */
 int moka_down_fwd(const void* x, const void* const* A /*host array of M device ptrs*/,
                   const uint8_t* tok_mod, float* part,
-                  int T, int d_in, int r, int M, float s_in, int dtype, moka_stream_t stream);
+                  int T, int d_in, int r, int M, float s_in, float dropout_p, unsigned long long seed,
+                  int dtype, moka_stream_t stream);
 
 /* Rank-r cross-modal interaction: sums the ks partials into h, computes
  * hp = h + w * softmax(h K^T * inv_sqrt_dk) K for query rows, and writes the operand packs of
@@ -145,7 +149,13 @@ size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r);
  * dx[t] += (s_in dh[t]) A[mod(t)]   (in place on the base input-gradient gy W; NULL skips). */
 int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* const* A /*host array*/,
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
-                  void* dx_inout, int T, int d_in, int r, int M, int dtype, moka_stream_t stream);
+                  void* dx_inout, int T, int d_in, int r, int M,
+                  float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream);
+
+/* The keep mask (1 byte per element of x, 1 = kept) the kernels derive from (dropout_p, seed): lets a
+ * checker replay a dropout run exactly.  moka_dropout_scale returns 1/(1-p') (see moka_down_fwd). */
+int   moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in, uint8_t* keep_out, moka_stream_t stream);
+float moka_dropout_scale(float dropout_p);
 
 #ifdef __cplusplus
 }

@@ -39,9 +39,9 @@ SYMBOLS = {
     "moka_rank_pad": (c_int, [c_int]),
     "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),
-    # x, A[], tok_mod, part, T, d_in, r, M, s_in, dtype, stream
+    # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, stream
     "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
-                              c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                              c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
     # part, ks, rt, s_out[], Bw, d_out, h, hp, hp_tok, hp_kmj, BwT, r, w, c, stream
     "moka_cross_fwd": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), POINTER(c_float), c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
@@ -54,9 +54,12 @@ SYMBOLS = {
     "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
     "moka_cross_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
-    # dh_tok, dh_kmj, x, A[], tok_mod, dA_acc[], dx, T, d_in, r, M, dtype, stream
+    # dh_tok, dh_kmj, x, A[], tok_mod, dA_acc[], dx, T, d_in, r, M, dropout_p, seed, dtype, stream
     "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
-                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                              c_int, c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
+    # dropout_p, seed, T, d_in, keep_out, stream
+    "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
+    "moka_dropout_scale": (c_float, [c_float]),
 }
 
 

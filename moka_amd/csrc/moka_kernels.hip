@@ -92,6 +92,34 @@ static __device__ __forceinline__ void wave_sum_vec(float (&v)[N]) {
     for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
 }
 
+// ---- dropout: counter-based keep mask, one hash per 16-byte chunk (8 bf16 of one token row) -------
+// keep(e) = u16(seed, token, chunk, e) >= thr with thr = round(p * 65536).  The same function is
+// evaluated by the down-projection (x), the dA kernel (x) and the dx kernel (output), so nothing is
+// stored and a re-run of the forward (activation checkpointing) reproduces the mask bit for bit.
+struct DropArgs { unsigned thr, seed_lo, seed_hi; float inv_keep; };
+
+static __device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+// 8 keep bits of chunk `idx` (= token * (C/8) + column/8)
+static __device__ __forceinline__ unsigned drop_keep8(const DropArgs& d, unsigned idx) {
+    const unsigned base = fmix32(idx ^ d.seed_lo) + d.seed_hi;
+    unsigned m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned x = fmix32(base + (unsigned)w * 0x9E3779B9u);
+        m |= ((x & 0xffffu) >= d.thr ? 1u : 0u) << (2 * w);
+        m |= ((x >> 16) >= d.thr ? 1u : 0u) << (2 * w + 1);
+    }
+    return m;
+}
+static __device__ __forceinline__ bf16x8 drop_apply(bf16x8 v, unsigned keep) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] : (short)0;
+    return v;
+}
+
 // position of token (t & 31) inside its group of 32 in the rank-major packs
 static __device__ __forceinline__ int kmj_pos(int tl) {
     return (tl < 16) ? (8 * (tl >> 2) + (tl & 3)) : (8 * ((tl - 16) >> 2) + 4 + (tl & 3));
@@ -114,6 +142,7 @@ struct ReduceArgs {
     float s_mod[4];                 // scale per modality id
     int T, C, r, M, ks;
     int shared_w;                   // 1: W[0] serves every modality (gy.Bw); routing only picks the scale
+    DropArgs drop;                  // thr == 0: no dropout
 };
 
 // One block per (32-token tile, K slice).  The NW waves of the block split the slice's K steps;
@@ -179,6 +208,18 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
 #pragma unroll
                     for (int st = 0; st < 2; ++st)
                         if (pres[st]) xv[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s + u) * 64);
+                }
+            }
+        }
+        if (a.drop.thr) {                                     // wave uniform
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (s + u < s_end) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
+                        if (pres[st]) xv[u][st] = drop_apply(xv[u][st], drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((s + u) * 4 + g)));
+                    }
                 }
             }
         }
@@ -624,6 +665,7 @@ struct ExpandArgs {
     const unsigned char* tok_mod;
     unsigned char* out;             // [T][C] bf16, in/out
     int T, C, r, M;
+    DropArgs drop;                  // dx only: the adapter term passes through the dropout mask of x
 };
 
 // D^T orientation: MFMA rows = output columns, MFMA columns = tokens, so every lane ends up with 8
@@ -764,9 +806,16 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
                     }
                 }
             }
+            unsigned keep = 0xffu;
+            float dsc = 1.f;
+            if (a.drop.thr) {
+                keep = drop_keep8(a.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
+                dsc = a.drop.inv_keep;
+            }
             bf16x8 res;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + d[e >> 2][e & 3]);
+            for (int e = 0; e < 8; ++e)
+                res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (((keep >> e) & 1u) ? d[e >> 2][e & 3] * dsc : 0.f));
             if (valid) *(bf16x8*)(orow + 64 * q) = res;
         }
     }
@@ -782,6 +831,7 @@ struct WgradArgs {
     float* acc[MOKA_MAX_MOD];       // OUT_CK: [C][r]   else: [r][C]     fp32, accumulated atomically
     int T, Tp, C, r, M, groups_per_block;
     int per_mod;                    // 1: one pack plane per modality (dA); 0: single (dB)
+    DropArgs drop;                  // dA only: x passes through its dropout mask
 };
 
 // Block = NW waves owning NSB*64 columns for a long run of tokens.  Each wave walks over a contiguous
@@ -867,7 +917,16 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *(uint4*)(my + (8 * u + lrow) * PITCH + lcol * 16) = ld[sb][u];
+            for (int u = 0; u < 4; ++u) {
+                uint4 v = ld[sb][u];
+                if (a.drop.thr) {
+                    const unsigned trow = (unsigned)min((grp << 5) + 8 * u + lrow, a.T - 1);
+                    const unsigned keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((c_begin + sb * 64) >> 3) + (unsigned)lcol);
+                    bf16x8 t8 = drop_apply(*(bf16x8*)&v, keep);
+                    v = *(uint4*)&t8;
+                }
+                *(uint4*)(my + (8 * u + lrow) * PITCH + lcol * 16) = v;
+            }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
@@ -940,9 +999,19 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += red[((size_t)w * CCB + cl) * RP + k];
-            atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), sum);
+            atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), a.drop.thr ? sum * a.drop.inv_keep : sum);
         }
         __syncthreads();
+    }
+}
+
+// Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
+__global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
+    const size_t nchunk = (size_t)T * (C >> 3);
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nchunk; idx += (size_t)gridDim.x * 256) {
+        const unsigned keep = drop_keep8(d, (unsigned)idx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[idx * 8 + e] = (keep >> e) & 1u;
     }
 }
 
@@ -1012,6 +1081,21 @@ static int reduce_ks(int T, int C) {
     if (ks < 1) ks = 1;
     if (g_tune_reduce_ks > 0 && g_tune_reduce_ks <= max_ks && g_tune_reduce_ks <= 8) ks = g_tune_reduce_ks;
     return ks;
+}
+
+static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs* d) {
+    memset(d, 0, sizeof(*d));
+    d->inv_keep = 1.f;
+    if (p == 0.f) return MOKA_OK;
+    if (!(p > 0.f) || p >= 1.f) return fail(MOKA_EINVAL, "%s: dropout probability %g not in [0, 1)", fn, (double)p);
+    unsigned thr = (unsigned)(p * 65536.f + 0.5f);
+    if (thr < 1) thr = 1;
+    if (thr > 65535) thr = 65535;
+    d->thr = thr;
+    d->seed_lo = (unsigned)(seed & 0xffffffffull);
+    d->seed_hi = (unsigned)(seed >> 32);
+    d->inv_keep = 65536.f / (float)(65536u - thr);
+    return MOKA_OK;
 }
 
 static int cross_rows_per_block() { return (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) ? g_tune_cross_rows : 8; }
@@ -1169,9 +1253,16 @@ int moka_ksplit(int T, int C, int r) {
 }
 
 int moka_down_fwd(const void* x, const void* const* A, const uint8_t* tok_mod, float* part,
-                  int T, int d_in, int r, int M, float s_in, int dtype, moka_stream_t stream) {
+                  int T, int d_in, int r, int M, float s_in, float dropout_p, unsigned long long seed,
+                  int dtype, moka_stream_t stream) {
     int rc = check_common("moka_down_fwd", T, d_in, r, M, dtype);
     if (rc) return rc;
+    DropArgs drop;
+    rc = make_drop("moka_down_fwd", dropout_p, seed, &drop);
+    if (rc) return rc;
+    if ((unsigned long long)T * (unsigned long long)(d_in >> 3) > 0xffffffffull && drop.thr)
+        return fail(MOKA_EINVAL, "moka_down_fwd: T * d_in too large for the dropout counter");
+    s_in *= drop.inv_keep;
     if (!x || !A || !tok_mod || !part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
     ReduceArgs a;
     memset(&a, 0, sizeof(a));
@@ -1182,6 +1273,7 @@ int moka_down_fwd(const void* x, const void* const* A, const uint8_t* tok_mod, f
         a.s_mod[m] = s_in;
     }
     a.tok_mod = tok_mod; a.out = part; a.T = T; a.C = d_in; a.r = r; a.M = M; a.ks = reduce_ks(T, d_in);
+    a.drop = drop;
     return launch_reduce(a, rank_pad(r), (hipStream_t)stream);
 }
 
@@ -1263,8 +1355,12 @@ int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8
 }
 
 int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* const* A, const uint8_t* tok_mod,
-                  float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M, int dtype, moka_stream_t stream) {
+                  float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M,
+                  float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream) {
     int rc = check_common("moka_down_bwd", T, d_in, r, M, dtype);
+    if (rc) return rc;
+    DropArgs drop;
+    rc = make_drop("moka_down_bwd", dropout_p, seed, &drop);
     if (rc) return rc;
     if (!tok_mod) return fail(MOKA_EINVAL, "moka_down_bwd: null pointer");
     const int RP = rank_pad(r);
@@ -1277,7 +1373,7 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
             if (!dA_acc[m]) return fail(MOKA_EINVAL, "moka_down_bwd: dA_acc[%d] is null", m);
             ga.acc[m] = dA_acc[m];
         }
-        ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in; ga.r = r; ga.M = M; ga.per_mod = 1;
+        ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in; ga.r = r; ga.M = M; ga.per_mod = 1; ga.drop = drop;
         rc = launch_wgrad<false>(ga, RP, (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -1290,10 +1386,26 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
             if (!A[m]) return fail(MOKA_EINVAL, "moka_down_bwd: A[%d] is null", m);
             a.W[m] = (const unsigned char*)A[m];
         }
-        a.T = T; a.C = d_in; a.r = r; a.M = M;
+        a.T = T; a.C = d_in; a.r = r; a.M = M; a.drop = drop;
         rc = launch_expand<false>(a, RP, (hipStream_t)stream);
     }
     return rc;
+}
+
+int moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in, uint8_t* keep_out, moka_stream_t stream) {
+    if (!keep_out || T < 1 || d_in < 8 || (d_in % 8) != 0) return fail(MOKA_EINVAL, "moka_dropout_mask: bad argument");
+    DropArgs drop;
+    int rc = make_drop("moka_dropout_mask", dropout_p, seed, &drop);
+    if (rc) return rc;
+    if (!drop.thr) return (hipMemsetAsync(keep_out, 1, (size_t)T * d_in, (hipStream_t)stream) == hipSuccess) ? MOKA_OK : fail(MOKA_ELAUNCH, "memset");
+    hipLaunchKernelGGL(moka_dropout_mask_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, drop, T, d_in, keep_out);
+    return check_launch("moka_dropout_mask_kernel");
+}
+
+float moka_dropout_scale(float dropout_p) {
+    DropArgs drop;
+    if (make_drop("moka_dropout_scale", dropout_p, 0, &drop)) return -1.f;
+    return drop.inv_keep;
 }
 
 }  // extern "C"

@@ -45,15 +45,17 @@ def _floats(vals: Sequence[float]):
 # --------------------------------------------------------------------------------------
 # 1:1 wrappers of the C entry points
 # --------------------------------------------------------------------------------------
-def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float) -> torch.Tensor:
-    """x2 [T,d_in] bf16 -> part [ks,T,RP] fp32 (split-K partials of s_in * x A_mod^T)."""
+def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float,
+             dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """x2 [T,d_in] bf16 -> part [ks,T,RP] fp32 (split-K partials of s_in * drop(x) A_mod^T)."""
     lib = _lib.load()
     T, d_in = x2.shape
     RP = _lib.rank_pad(r)
     ks = _lib.ksplit(T, d_in, r)
     part = torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device)
     _lib.check(lib.moka_down_fwd(x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(), part.data_ptr(),
-                                 T, d_in, r, len(A), float(s_in), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_fwd")
+                                 T, d_in, r, len(A), float(s_in), float(dropout_p), int(seed), _lib.MOKA_BF16,
+                                 _stream_ptr(x2.device)), "moka_down_fwd")
     return part
 
 
@@ -127,13 +129,30 @@ def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, s_
 
 
 def down_bwd_(bst: BwdState, x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int,
-              dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor]):
+              dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor],
+              dropout_p: float = 0.0, seed: int = 0):
     """dA_acc[m] [r,d_in] fp32 += ; dx2 [T,d_in] bf16 += (either may be None)."""
     lib = _lib.load()
     T, d_in = x2.shape
     _lib.check(lib.moka_down_bwd(bst.dh_tok.data_ptr(), bst.dh_kmj.data_ptr(), x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(),
                                  None if dA_acc is None else _ptrs(dA_acc), None if dx2 is None else dx2.data_ptr(),
-                                 T, d_in, r, len(A), _lib.MOKA_BF16, _stream_ptr(x2.device)), "moka_down_bwd")
+                                 T, d_in, r, len(A), float(dropout_p), int(seed), _lib.MOKA_BF16,
+                                 _stream_ptr(x2.device)), "moka_down_bwd")
+
+
+def dropout_mask(dropout_p: float, seed: int, T: int, d_in: int, device) -> torch.Tensor:
+    """The keep mask (uint8 [T,d_in]) the kernels derive from (dropout_p, seed) -- for checkers."""
+    lib = _lib.load()
+    out = torch.empty((T, d_in), dtype=torch.uint8, device=device)
+    _lib.check(lib.moka_dropout_mask(float(dropout_p), int(seed), T, d_in, out.data_ptr(), _stream_ptr(device)), "moka_dropout_mask")
+    return out
+
+
+def draw_seed() -> int:
+    """Per-call dropout seed from torch's CPU generator (torch.manual_seed controls it; activation
+    checkpointing restores that generator before the re-forward, so the mask replays)."""
+    a, b = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()
+    return (a << 31) | b
 
 
 # --------------------------------------------------------------------------------------
@@ -142,10 +161,13 @@ def down_bwd_(bst: BwdState, x2: torch.Tensor, A: Sequence[torch.Tensor], rt: Mo
 class AdapterSpec:
     """Static description of one adapted projection (what varies between AVT and VT)."""
 
-    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk")
+    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed")
 
-    def __init__(self, r: int, s_in: float, s_out: Sequence[float], w: float, inv_sqrt_dk: float):
+    def __init__(self, r: int, s_in: float, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
+                 dropout_p: float = 0.0, seed: Optional[int] = None):
         self.r, self.s_in, self.s_out, self.w, self.inv_sqrt_dk = int(r), float(s_in), [float(s) for s in s_out], float(w), float(inv_sqrt_dk)
+        self.dropout_p = float(dropout_p)
+        self.seed = (draw_seed() if seed is None else int(seed)) if self.dropout_p > 0.0 else 0
 
 
 class MokaLinearFn(torch.autograd.Function):
@@ -176,7 +198,7 @@ class MokaLinearFn(torch.autograd.Function):
         y = torch.nn.functional.linear(x2, W, bias)                   # frozen base, stock PyTorch-ROCm
         A = [a if a.is_contiguous() else a.contiguous() for a in A]
         Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
-        part = down_fwd(x2, A, rt, spec.r, spec.s_in)
+        part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed)
         st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c)
         up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
         ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, *A)
@@ -203,7 +225,7 @@ class MokaLinearFn(torch.autograd.Function):
         if need_A or need_x:
             bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
             dA_acc = [torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=gy2.device) for _ in A] if need_A else None
-            down_bwd_(bst, x2, A, rt, r, dA_acc, dx2)
+            down_bwd_(bst, x2, A, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed)
             if need_A:
                 gA = [dA_acc[m].to(A[m].dtype) if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
         gbias = gy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

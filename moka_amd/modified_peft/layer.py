@@ -199,19 +199,22 @@ class Linear(nn.Module, LoraLayer):
         W = base.weight.T if self.fan_in_fan_out else base.weight
         A_t, A_i, B_t = self.lora_A["text"].weight, None, self.lora_B["text"].weight
         drop = self.lora_dropout["text"]
-        if isinstance(drop, nn.Dropout) and drop.p > 0 and self.training:
-            raise NotImplementedError("moka_amd: lora_dropout > 0 in training mode is not implemented yet "
-                                      "(set lora_dropout=0 or call .eval())")
+        p = float(drop.p) if (isinstance(drop, nn.Dropout) and self.training) else 0.0
+        if my_text_mask is not None and "image" in self.lora_dropout:
+            di = self.lora_dropout["image"]
+            pi = float(di.p) if (isinstance(di, nn.Dropout) and self.training) else 0.0
+            if pi != p:
+                raise ValueError("moka_amd: the text and image adapters must use the same lora_dropout")
         r = self.r["text"]
         if my_text_mask is not None:
             A_i = self.lora_A["image"].weight
             rt = GLOBAL_ROUTING_CACHE.get("vt", [my_text_mask, my_image_mask, question_mask])
-            spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r))
+            spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r), dropout_p=p)
             return moka_linear(x, W, base.bias, B_t, [A_t, A_i], rt, spec)
         # masks None (cached decode steps): plain LoRA with the text adapter (layer.py:672-678)
         B_, S_ = (x.shape[0], x.shape[1]) if x.dim() == 3 else (1, x.shape[0])
         rt = GLOBAL_ROUTING_CACHE.plain(B_, S_, x.device, 1)
-        spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r))
+        spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r), dropout_p=p)
         return moka_linear(x, W, base.bias, B_t, [A_t], rt, spec)
 
     def __repr__(self) -> str:

@@ -74,7 +74,9 @@ class Linear(nn.Linear, LoraLayer):
 
     # -- the hot path -------------------------------------------------------------------------
     def _spec(self) -> AdapterSpec:
-        return AdapterSpec(self.d_k, self.scaling[0], [1.0] * self.lora_num, self.blc_weight, 1.0 / math.sqrt(self.d_k))
+        # lora_dropout acts on x before every A_m (lora.py:477); one counter-based mask per call
+        p = self.lora_dropout_p if self.training else 0.0
+        return AdapterSpec(self.d_k, self.scaling[0], [1.0] * self.lora_num, self.blc_weight, 1.0 / math.sqrt(self.d_k), dropout_p=p)
 
     def _adapter_weights(self, dtype):
         A = [getattr(self, f"lora_A{i}").weight for i in range(self.lora_num)]
@@ -83,9 +85,6 @@ class Linear(nn.Linear, LoraLayer):
         return A, (Bw if Bw.dtype == dtype else Bw.to(dtype))
 
     def forward(self, x: torch.Tensor, modality_mask: Optional[List[torch.Tensor]] = None):
-        if self.lora_dropout_p > 0.0 and self.training:
-            raise NotImplementedError("moka_amd: lora_dropout > 0 in training mode is not implemented yet "
-                                      "(set lora_dropout=0 or call .eval())")
         method = self.loramethod or ""
         W = self.weight.T if self.fan_in_fan_out else self.weight
         A, Bw = self._adapter_weights(x.dtype)
@@ -93,7 +92,8 @@ class Linear(nn.Linear, LoraLayer):
         if "test" in method and x.size(1) == 1:
             # decode step: only the text adapter, no masks (lora.py:373-381)
             rt = GLOBAL_ROUTING_CACHE.plain(x.shape[0], x.shape[1], x.device, 1)
-            return moka_linear(x, W, self.bias, Bw, A[:1], rt, AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk))
+            return moka_linear(x, W, self.bias, Bw, A[:1], rt,
+                               AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed))
         if "test" in method or "train" in method:
             # prefill / train: token-routed adapters + cross-modal interaction (lora.py:385-532)
             rt = GLOBAL_ROUTING_CACHE.get("avt", list(modality_mask[:4]))

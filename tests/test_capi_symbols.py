@@ -52,16 +52,20 @@ def test_argument_validation_sets_error_message(lib):
     dummy = ctypes.c_void_p(64)
     arr = (ctypes.c_void_p * 1)(64)
     # unsupported dtype
-    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 1, None)
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 1, None)
     assert rc == -2 and b"bf16" in lib.moka_last_error()
     # width not a multiple of 32
-    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0, None)
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0.0, 0, 0, None)
     assert rc == -1 and b"multiple of 32" in lib.moka_last_error()
     # rank out of range
     rc = lib.moka_up_fwd(dummy, dummy, dummy, dummy, 16, 65, 64, 0, None)
     assert rc == -1 and b"rank" in lib.moka_last_error()
+    # dropout probability out of range
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 1.5, 7, 0, None)
+    assert rc == -1 and b"dropout" in lib.moka_last_error()
+    assert abs(lib.moka_dropout_scale(0.05) - 65536.0 / (65536 - 3277)) < 1e-6
     # null pointer
-    rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0, None)
+    rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 0, None)
     assert rc == -1 and b"null" in lib.moka_last_error()
 
 

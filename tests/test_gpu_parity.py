@@ -277,3 +277,75 @@ def test_cpu_tensor_fails_loudly():
     with pytest.raises(_lib.MokaError):
         moka_linear(x, torch.zeros(64, 64, dtype=torch.bfloat16), None, torch.zeros(64, 4, dtype=torch.bfloat16),
                     [torch.zeros(4, 64, dtype=torch.bfloat16)], rt, AdapterSpec(4, 1.0, [1.0], 0.0, 0.5))
+
+
+# ------------------------------------------------------------------------------------------
+# dropout (lora_dropout): exact replay through the materialised mask, keep rate, determinism
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,p", [("avt_tiny", 0.25), ("avt_r16_q", 0.05), ("vt_r16_q", 0.05), ("avt_r16_down", 0.1)])
+def test_dropout_replays_exactly_through_the_mask(name, p):
+    """y, dA_m, dB, dx with in-kernel dropout == oracle fed with x * keep / (1 - p'), keep from moka_dropout_mask."""
+    from moka_amd import functional as F
+    from moka_amd import _lib
+    dev = _dev()
+    cd = C.make_case_data(name)
+    c = cd.case
+    M = len(cd.A)
+    spec, rt, ort = _spec_and_routing(cd, dev)
+    T = c.B * c.S
+    bf = torch.bfloat16
+    seed = 0x1234567 + c.seed
+    x2 = cd.x.reshape(T, c.d_in).to(dev, bf).contiguous()
+    A = [a.to(dev, bf).contiguous() for a in cd.A]
+    Bw = cd.Bw.to(dev, bf).contiguous()
+    gy2 = cd.gy.reshape(T, c.d_out).to(dev, bf).contiguous()
+    keep = F.dropout_mask(p, seed, T, c.d_in, dev).cpu().double().reshape(c.B, c.S, c.d_in)
+    inv_keep = float(_lib.load().moka_dropout_scale(p))
+    rate = 1.0 - keep.mean().item()
+    assert abs(rate - p) < 4 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"drop rate {rate} vs p {p}"
+    xm = cd.x.double() * keep * inv_keep
+    y0 = torch.zeros(c.B, c.S, c.d_out)
+    yo, ctx = O.adapter_forward(xm, y0, cd.A, cd.Bw, ort, spec.s_in, spec.s_out, spec.w, c.r)
+    dxm, dAo, dBo, _ = O.adapter_backward(cd.gy, ctx)
+    dxo = dxm * keep * inv_keep
+    r = c.r
+    st = F.cross_fwd(F.down_fwd(x2, A, rt, r, spec.s_in, p, seed), rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw)
+    y2 = torch.zeros(T, c.d_out, dtype=bf, device=dev)
+    F.up_fwd_(y2, st.hp_tok, Bw, rt, r)
+    assert rel(y2, yo.reshape(T, c.d_out).to(bf)) < TOL_BF16
+    dB_acc = torch.zeros(c.d_out, r, dtype=torch.float32, device=dev)
+    bst = F.cross_bwd(F.up_bwd(gy2, st.hp_kmj, st.BwT, rt, r, spec.s_out, dB_acc), st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+    dA_acc = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]
+    dx2 = torch.zeros(T, c.d_in, dtype=bf, device=dev)
+    F.down_bwd_(bst, x2, A, rt, r, dA_acc, dx2, p, seed)
+    assert rel(dB_acc, dBo) < TOL_F32
+    for m in range(M):
+        assert rel(dA_acc[m], dAo[m]) < TOL_F32, f"dA{m}"
+    assert rel(dx2, dxo.reshape(T, c.d_in).to(bf)) < TOL_BF16
+    # a different seed gives a different mask, the same seed the same bits
+    assert torch.equal(F.dropout_mask(p, seed, T, c.d_in, dev), F.dropout_mask(p, seed, T, c.d_in, dev))
+    assert not torch.equal(F.dropout_mask(p, seed, T, c.d_in, dev), F.dropout_mask(p, seed + 1, T, c.d_in, dev))
+
+
+def test_dropout_layer_train_vs_eval():
+    """peft_hyper.Linear: eval() ignores lora_dropout, train() applies it and replays under the same torch seed."""
+    from moka_amd.peft_hyper import Linear
+    dev = _dev()
+    cd = C.make_case_data("avt_r16_q")
+    c = cd.case
+    lin = Linear(c.d_in, c.d_out, r=(16, 16, 16), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.3,
+                 loramethod="train", bias=False).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(cd.W)
+        for i in range(3):
+            getattr(lin, f"lora_A{i}").weight.copy_(cd.A[i])
+        lin.lora_B0.weight.copy_(cd.Bw)
+    x = cd.x.to(dev, torch.bfloat16)
+    masks = [m.to(dev) for m in cd.masks]
+    lin.eval()
+    y_eval = lin(x, masks)
+    lin.train()
+    torch.manual_seed(5); y1 = lin(x, masks)
+    torch.manual_seed(5); y2 = lin(x, masks)
+    torch.manual_seed(6); y3 = lin(x, masks)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3) and not torch.equal(y1, y_eval)

@@ -15,10 +15,15 @@ from moka_amd.routing import MokaRouting  # noqa: E402
 from oracle import cases as C  # noqa: E402
 
 
+DROP = 0.0
+
+
 def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
     B, S, r, M = int(os.environ.get("B", 4)), 2048, 16, 3
+    global DROP
+    DROP = float(os.environ.get("DROP", 0.0))
     T = B * S
     tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
     masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
@@ -56,7 +61,7 @@ def main():
         c = 1 / math.sqrt(r)
         sp = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
         return {
-            "down_fwd": lambda i: lib.moka_down_fwd(w["xs"][i % NBUF].data_ptr(), Ap, tm, w["part"].data_ptr(), T, d_in, r, M, 1.0, 0, sp()),
+            "down_fwd": lambda i: lib.moka_down_fwd(w["xs"][i % NBUF].data_ptr(), Ap, tm, w["part"].data_ptr(), T, d_in, r, M, 1.0, DROP, 1234, 0, sp()),
             "cross_fwd": lambda i: lib.moka_cross_fwd(w["part"].data_ptr(), _lib.ksplit(T, d_in, r), byref(rt.struct), so, w["Bw"].data_ptr(), d_out,
                                                       w["h"].data_ptr(), None, w["hp_tok"].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), r, 1.0, c, sp()),
             "up_fwd": lambda i: lib.moka_up_fwd(w["hp_tok"].data_ptr(), w["Bw"].data_ptr(), tm, w["ys"][i % NBUF].data_ptr(), T, r, d_out, 0, sp()),
@@ -64,8 +69,8 @@ def main():
             "up_bwd(g+dB)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
             "cross_bwd": lambda i: lib.moka_cross_bwd(w["part"].data_ptr(), _lib.ksplit(T, d_out, r), w["h"].data_ptr(), byref(rt.struct), 1.0, None,
                                                       w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), rt.cross_ws(r).data_ptr(), r, 1.0, c, sp()),
-            "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, dAp, None, T, d_in, r, M, 0, sp()),
-            "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, 0, sp()),
+            "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, dAp, None, T, d_in, r, M, DROP, 1234, 0, sp()),
+            "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, DROP, 1234, 0, sp()),
         }
 
     def timeit(fn, iters=24):

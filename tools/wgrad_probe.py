@@ -28,6 +28,6 @@ for name, rt, M in (("synthetic AVT routing M=3", MokaRouting.from_avt_masks(mas
     dA = [torch.zeros(r, d, dtype=f32, device=dev) for _ in range(M)]
     Ap = (c_void_p * M)(*[a.data_ptr() for a in A]); dAp = (c_void_p * M)(*[a.data_ptr() for a in dA])
     tm = rt.tok_mod.data_ptr(); sp = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)
-    f = lambda i: lib.moka_down_bwd(dh_tok.data_ptr(), dh_kmj.data_ptr(), xs[i % 6].data_ptr(), Ap, tm, dAp, None, T, d, r, M, 0, sp())
-    fwarm = lambda i: lib.moka_down_bwd(dh_tok.data_ptr(), dh_kmj.data_ptr(), xs[0].data_ptr(), Ap, tm, dAp, None, T, d, r, M, 0, sp())
+    f = lambda i: lib.moka_down_bwd(dh_tok.data_ptr(), dh_kmj.data_ptr(), xs[i % 6].data_ptr(), Ap, tm, dAp, None, T, d, r, M, 0.0, 0, 0, sp())
+    fwarm = lambda i: lib.moka_down_bwd(dh_tok.data_ptr(), dh_kmj.data_ptr(), xs[0].data_ptr(), Ap, tm, dAp, None, T, d, r, M, 0.0, 0, 0, sp())
     print(f"{name:30s} cold {timeit(f):7.1f} us   same-buffer {timeit(fwarm):7.1f} us")
