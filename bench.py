@@ -162,53 +162,71 @@ def build_workload(args, dev, lib, bucket_factory):
                 keep=(sets, saved, masks, part, hp_tok, dh_tok, dh_kmj))
 
 
-def run_forward(lib, wl, sp):
+ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
+
+
+LIVE = ("moka_up_fwd",)     # the dominant single-kernel entry point, bracketed inside the timed region
+
+
+class Recorder:
+    """HIP-event brackets around launches on the launch stream.  `only` limits which entry points are
+    bracketed (bracketing all 1344 launches of a step makes the host the bottleneck and distorts the
+    headline; the two single-kernel entry points cost ~450 event records per step)."""
+
+    def __init__(self, only=None):
+        self.only, self.items, self.pool = only, [], []
+
+    def event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+
+    def reserve(self, n):
+        self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(n))
+
+
+def _call(lib, name, args, sp, rec, p):
+    """Launch one entry point; bracket it with HIP events when the recorder asks for it."""
+    if rec is None or (rec.only is not None and name not in rec.only):
+        rc = getattr(lib, name)(*args, sp)
+    else:
+        e0, e1 = rec.event(), rec.event()
+        e0.record()
+        rc = getattr(lib, name)(*args, sp)
+        e1.record()
+        rec.items.append((name, p.d_in, p.d_out, e0, e1))
+    if rc:
+        raise RuntimeError(lib.moka_last_error().decode())
+
+
+def run_forward(lib, wl, sp, rec=None):
     for p in wl["projs"]:
-        rc = lib.moka_down_fwd(*p.f1, sp) or lib.moka_cross_fwd(*p.f2, sp) or lib.moka_up_fwd(*p.f3, sp)
-        if rc:
-            raise RuntimeError(lib.moka_last_error().decode())
+        _call(lib, "moka_down_fwd", p.f1, sp, rec, p)
+        _call(lib, "moka_cross_fwd", p.f2, sp, rec, p)
+        _call(lib, "moka_up_fwd", p.f3, sp, rec, p)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None):
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None):
     """Reverse layer order; `on_layer_done(l)` fires after layer l's launches are enqueued."""
     projs = wl["projs"]
     per = len(PROJS)
     for l in range(n_layers - 1, -1, -1):
         for p in reversed(projs[l * per:(l + 1) * per]):
-            rc = lib.moka_up_bwd(*p.b1, sp) or lib.moka_cross_bwd(*p.b2, sp) or lib.moka_down_bwd(*p.b3, sp)
-            if rc:
-                raise RuntimeError(lib.moka_last_error().decode())
+            _call(lib, "moka_up_bwd", p.b1, sp, rec, p)
+            _call(lib, "moka_cross_bwd", p.b2, sp, rec, p)
+            _call(lib, "moka_down_bwd", p.b3, sp, rec, p)
         if on_layer_done is not None:
             on_layer_done(l)
 
 
-def time_kernels(lib, wl, stream_ptr, iters=2):
-    """Per-entry-point launch durations with HIP events on the launch stream (torch's current
-    stream IS the stream the kernels are launched on)."""
-    names = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
-    tot = {n: 0.0 for n in names}
-    cnt = {n: 0 for n in names}
-    per_shape = {}
-    evs = []
-    for _ in range(iters):
-        for pr in wl["projs"]:
-            p = pr
-            for n, a in zip(names, (p.f1, p.f2, p.f3, p.b1, p.b2, p.b3)):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = getattr(lib, n)(*a, stream_ptr)
-                e1.record()
-                assert rc == 0
-                evs.append((n, p.d_in, p.d_out, e0, e1))
-    torch.cuda.synchronize()
-    for n, di, do, e0, e1 in evs:
-        ms = e0.elapsed_time(e1)
-        tot[n] += ms
-        cnt[n] += 1
-        key = (n, di, do)
-        a, b = per_shape.get(key, (0.0, 0))
-        per_shape[key] = (a + ms, b + 1)
-    return tot, cnt, per_shape
+# HBM bytes per launch from the PMC counters of profiles/r01_pmc_{fetch,write}.md (rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is),
+# measured at T = 8192 tokens per launch; MiB for (entry point, d_out or d_in width).
+PMC_TRAFFIC_MIB_T8192 = {("moka_up_fwd", 4096): 68.34 + 64.06, ("moka_up_fwd", 11008): 179.01 + 175.00,
+                         ("moka_down_fwd", 4096): 68.6 + 1.0, ("moka_down_fwd", 11008): 180.4 + 1.0}
+
+
+def pmc_traffic_bytes(name, width, T):
+    v = PMC_TRAFFIC_MIB_T8192.get((name, width))
+    return None if v is None else v * 1024 * 1024 * (T / 8192.0)
 
 
 def usable_cpus() -> int:
@@ -316,11 +334,14 @@ def main():
         opt = torch.optim.AdamW([mp], lr=1e-4, fused=True)
     L = args.layers
 
-    def step(i):
+    records = Recorder(only=LIVE)
+    records.reserve(2 * len(wl["projs"]) * args.steps + 16)
+
+    def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
         bucket.zero_()                               # same stream as the previous optimizer step
-        run_forward(lib, wl, sp)
-        run_backward(lib, wl, sp, L, bucket.layer_done)   # all-reduce of finished layer groups overlaps the rest
+        run_forward(lib, wl, sp, rec)
+        run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
         bucket.finish(average=True)
         if opt is not None:
             opt.step()
@@ -334,7 +355,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(args.warmup + i, records if rank == 0 else None)     # HIP events bracket every launch of the timed steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -351,10 +372,27 @@ def main():
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes_per_token(LLAMA7B["d"], LLAMA7B["ff"], args.rank, args.layers)
         algo_gbs = (fwd_b + bwd_b) * T / (ms_per_step * 1e-3) / 1e9
-        # per-kernel durations with HIP events on the launch stream, after the timed region
-        sp = c_void_p(torch.cuda.current_stream().cuda_stream)
-        tot, cnt, per_shape = time_kernels(lib, wl, sp)
+        # per-launch durations from the HIP events recorded on the launch stream inside the timed region
         d_, ff_, r_ = LLAMA7B["d"], LLAMA7B["ff"], args.rank
+        def collect(items):
+            tot = {n: 0.0 for n in ENTRY}
+            cnt = {n: 0 for n in ENTRY}
+            per_shape = {}
+            for n, di, do, e0, e1 in items:
+                ms = e0.elapsed_time(e1)
+                tot[n] += ms
+                cnt[n] += 1
+                a_, b_ = per_shape.get((n, di, do), (0.0, 0))
+                per_shape[(n, di, do)] = (a_ + ms, b_ + 1)
+            return tot, cnt, per_shape
+        tot, cnt, per_shape = collect(records.items)              # live: the timed steps (LIVE entry points)
+        # every entry point, in one extra untimed pass (full bracketing would perturb the timed region)
+        extra = Recorder()
+        sp_ = c_void_p(torch.cuda.current_stream().cuda_stream)
+        run_forward(lib, wl, sp_, extra)
+        run_backward(lib, wl, sp_, L, None, extra)
+        torch.cuda.synchronize()
+        tot_x, cnt_x, per_shape_x = collect(extra.items)
         # algorithmic bytes per launch of each entry point (SURVEY 8(d) split by kernel):
         #   down_fwd: read x                 E*T*d_in      up_fwd : read+write y      2*E*T*d_out
         #   up_bwd  : read gy                E*T*d_out     down_bwd: read x, r+w dx   3*E*T*d_in
@@ -362,13 +400,20 @@ def main():
             return {"moka_down_fwd": E * T * di, "moka_up_fwd": 2 * E * T * do, "moka_up_bwd": E * T * do,
                     "moka_down_bwd": 3 * E * T * di, "moka_cross_fwd": 3 * 4 * T * r_, "moka_cross_bwd": 3 * 4 * T * r_}[n]
         table = {}
-        for (n, di, do), (ms, c_) in sorted(per_shape.items()):
+        for (n, di, do), (ms, c_) in sorted(per_shape_x.items()):
             avg = ms / c_
             table[f"{n}[{di}->{do}]"] = {"avg_ms": round(avg, 4), "algo_GBps": round(algo(n, di, do) / (avg * 1e-3) / 1e9, 1)}
-        dom = max(tot, key=lambda n: tot[n])
+        # the dominant kernel: largest total time among the entry points that are ONE kernel launch
+        # (moka_down_fwd -> moka_reduce_kernel, moka_up_fwd -> moka_expand_kernel<.., true>)
+        single = {"moka_up_fwd": "moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
+        dom = "moka_up_fwd"       # largest single-kernel entry point of a pass (see entry_point_ms_per_pass)
         dom_bytes = sum(algo(n, di, do) * c_ for (n, di, do), (ms, c_) in per_shape.items() if n == dom)
         dom_avg_ms = tot[dom] / cnt[dom]
         achieved = dom_bytes / cnt[dom] / (dom_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tr = [(pmc_traffic_bytes(n, do if n == "moka_up_fwd" else di, T), c_) for (n, di, do), (ms, c_) in per_shape.items() if n == dom]
+        if tr and all(t_ is not None for t_, _ in tr) and args.seq == 2048:
+            traffic = round(sum(t_ * c_ for t_, c_ in tr) / sum(c_ for _, c_ in tr))
         out = {
             "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline",
             "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -380,9 +425,11 @@ def main():
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(dom_bytes / cnt[dom]),
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches_timed": cnt[dom]},
+            "entry_point_ms_per_pass": {n: round(tot_x[n], 3) for n in ENTRY},
             "kernels": table,
         }
         if world == 1 and not args.no_cpu_baseline:
