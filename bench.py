@@ -66,7 +66,7 @@ class Proj:
         x, y, dx = bufs
         A, Bw = params
         dA, dB = grads
-        part, h, hp_tok, hp_kmj, BwT, dh_tok, dh_kmj = ws
+        part, h, hp_tok, hp_kmj, BwT, AT, dh_tok, dh_kmj = ws
         self.keep = (x, y, dx, A, Bw, dA, dB, ws)
         Ap = (c_void_p * M)(*[a.data_ptr() for a in A])
         dAp = (c_void_p * M)(*[a.data_ptr() for a in dA])
@@ -74,12 +74,12 @@ class Proj:
         self._c = (Ap, dAp, so)
         tm = rt.tok_mod.data_ptr()
         self.f1 = (x.data_ptr(), Ap, tm, part.data_ptr(), T, d_in, r, M, s_in, drop_p, seed, 0)
-        self.f2 = (part.data_ptr(), self.ks_in, byref(rt.struct), so, Bw.data_ptr(), d_out, h.data_ptr(), None,
-                   hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), r, w, c)
+        self.f2 = (part.data_ptr(), self.ks_in, byref(rt.struct), so, Bw.data_ptr(), d_out, Ap, d_in, h.data_ptr(), None,
+                   hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), AT.data_ptr(), r, w, c)
         self.f3 = (hp_tok.data_ptr(), Bw.data_ptr(), tm, y.data_ptr(), T, r, d_out, 0)
         self.b1 = (y.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), tm, so, part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
         self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), rt.cross_ws(r).data_ptr(), r, w, c)
-        self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), Ap, tm, dAp, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)
+        self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), AT.data_ptr(), tm, dAp, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)
 
 
 def build_workload(args, dev, lib, bucket_factory):
@@ -124,7 +124,8 @@ def build_workload(args, dev, lib, bucket_factory):
     dh_kmj = torch.empty(M, 2, RP, Tp, dtype=bf, device=dev)
     # saved forward -> backward, one set per projection: h (fp32), the rank-major hp pack, BwT
     saved = [[(torch.empty(T, RP, dtype=f32, device=dev), torch.empty(2, RP, Tp, dtype=bf, device=dev),
-               torch.empty(RP, d if do == "d" else ff, dtype=bf, device=dev)) for _, _, do, _ in PROJS] for _ in range(L)]
+               torch.empty(RP, d if do == "d" else ff, dtype=bf, device=dev),
+               torch.empty(M, d if di == "d" else ff, RP, dtype=bf, device=dev)) for _, di, do, _ in PROJS] for _ in range(L)]
     ws = None
     hh = saved
 
@@ -150,8 +151,8 @@ def build_workload(args, dev, lib, bucket_factory):
             Bw = work[off:off + n].view(d_out, r)
             dB = gbuf[off:off + n].view(d_out, r)
             off += n
-            h, hp_kmj, BwT = saved[l][pi]
-            wsl = (part, h, hp_tok, hp_kmj, BwT, dh_tok, dh_kmj)
+            h, hp_kmj, BwT, AT = saved[l][pi]
+            wsl = (part, h, hp_tok, hp_kmj, BwT, AT, dh_tok, dh_kmj)
             projs.append(Proj(lib, name, d_in, d_out, r, M, T, (acts[src], ys[pi], dxs[pi]), (A, Bw), (dA, dB), wsl, rt,
                               s, [1.0] * M, 1.0, 1.0 / math.sqrt(r), drop_p=args.dropout, seed=1000003 * l + pi))
         layer_end.append(off)

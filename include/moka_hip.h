@@ -30,6 +30,7 @@
  *                                        16+4g+e-4 otherwise): the MFMA operand of the weight-gradient
  *                                        kernel (n = 1 for hp, n = M per-modality-masked planes for dh)
  *       BwT           [RP, d_out] bf16   transposed copy of Bw, zero padded, produced by moka_cross_fwd
+ *       AT            [M, d_in, RP] bf16 transposed copies of the A_m, zero padded, produced by moka_cross_fwd
  *   - dtype: MOKA_BF16 (=0) is the only storage type implemented (fp32 accumulate).
  *
  * Unified routed formulation (oracle/moka_oracle.py):
@@ -113,12 +114,13 @@ int moka_down_fwd(const void* x, const void* const* A /*host array of M device p
 
 /* Rank-r cross-modal interaction: sums the ks partials into h, computes
  * hp = h + w * softmax(h K^T * inv_sqrt_dk) K for query rows, and writes the operand packs of
- * s_out[mod(t)] * hp[t] for the up-projection (hp_tok) and for dB (hp_kmj), plus BwT.
+ * s_out[mod(t)] * hp[t] for the up-projection (hp_tok) and for dB (hp_kmj), plus the weight
+ * shadows BwT / AT the backward kernels read (the weights do not change before the backward).
  * Replaces the per-sample Python loops lora.py:485-521 / layer.py:627-653.
- * hp (fp32) and BwT may be NULL (not written). */
+ * hp (fp32), BwT and AT may be NULL (not written). */
 int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const float* s_out /*host, M floats*/,
-                   const void* Bw, int d_out,
-                   float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT,
+                   const void* Bw, int d_out, const void* const* A /*host array, may be NULL with AT*/, int d_in,
+                   float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT, void* AT,
                    int r, float w, float inv_sqrt_dk, moka_stream_t stream);
 
 /* Shared up-projection + residual add  y[t] += (s_out[mod(t)] hp[t]) Bw^T  (in place on the
@@ -146,8 +148,8 @@ int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routi
 size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r);
 
 /* dA_acc[m][k][c] += sum_{t: mod(t)=m} (s_in dh[t][k]) x[t][c]   (fp32 accumulate; NULL skips) and
- * dx[t] += (s_in dh[t]) A[mod(t)]   (in place on the base input-gradient gy W; NULL skips). */
-int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* const* A /*host array*/,
+ * dx[t] += (s_in dh[t]) A[mod(t)]   (in place on the base input-gradient gy W; NULL skips; needs AT). */
+int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* AT /*from moka_cross_fwd*/,
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
                   void* dx_inout, int T, int d_in, int r, int M,
                   float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream);

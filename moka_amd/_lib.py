@@ -42,9 +42,10 @@ SYMBOLS = {
     # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, stream
     "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
-    # part, ks, rt, s_out[], Bw, d_out, h, hp, hp_tok, hp_kmj, BwT, r, w, c, stream
+    # part, ks, rt, s_out[], Bw, d_out, A[], d_in, h, hp, hp_tok, hp_kmj, BwT, AT, r, w, c, stream
     "moka_cross_fwd": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), POINTER(c_float), c_void_p, c_int,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
+                               POINTER(c_void_p), c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
     # hp_tok, Bw, tok_mod, y, T, r, d_out, dtype, stream
     "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     # gy, hp_kmj, BwT, tok_mod, s_out[], g_part, dB_acc, T, r, d_out, M, dtype, stream
@@ -54,8 +55,8 @@ SYMBOLS = {
     "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
     "moka_cross_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
-    # dh_tok, dh_kmj, x, A[], tok_mod, dA_acc[], dx, T, d_in, r, M, dropout_p, seed, dtype, stream
-    "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
+    # dh_tok, dh_kmj, x, AT, tok_mod, dA_acc[], dx, T, d_in, r, M, dropout_p, seed, dtype, stream
+    "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p,
                               c_int, c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
     # dropout_p, seed, T, d_in, keep_out, stream
     "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),

@@ -304,6 +304,9 @@ struct CrossArgs {
     unsigned short* pack_kmj;       // fwd: [2][RP][Tp]   bwd: [M][2][RP][Tp]
     const unsigned short* Bw;       // fwd: [C][r] or null
     unsigned short* BwT;            // fwd: [RP][C] or null
+    const unsigned short* Aw[MOKA_MAX_MOD];   // fwd: A_m [r][Cin] or null
+    unsigned short* AT;             // fwd: [M][Cin][RP] or null (transposed, zero padded)
+    int Cin;
     float s_mod[4];                 // fwd: s_out per modality; bwd: s_in for every modality
     int ks, B, S, T, Tp, Lk_max, Lkp, r, C, M, RB;
     float w, c;
@@ -449,12 +452,40 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     if (b == a.B - 1 && blockIdx.y == gridDim.y - 1) {
         for (int e = tid; e < (a.Tp - a.T) * RP; e += 512) write_packs_fwd<RP>(a, a.T + e / RP, e % RP, 0.f);
     }
-    // BwT[k][c] = Bw[c][k]
+    // weight shadows for the backward (weights do not change before it runs):
+    // BwT[k][c] = Bw[c][k]   and   AT[m][c][k] = A_m[k][c]
+    const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
     if (a.BwT) {
-        const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
         for (int c = bid * 512 + tid; c < a.C; c += nblk * 512) {
-#pragma unroll 4
-            for (int k = 0; k < RP; ++k) a.BwT[(size_t)k * a.C + c] = (k < a.r) ? a.Bw[(size_t)c * a.r + k] : (unsigned short)0;
+            // one contiguous row of Bw per thread (vector loads when r == RP), coalesced column writes
+            unsigned short row[RP];
+            if (a.r == RP) {
+#pragma unroll
+                for (int k8 = 0; k8 < RP / 8; ++k8) {
+                    const bf16x8 v = *(const bf16x8*)(a.Bw + (size_t)c * RP + 8 * k8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) row[8 * k8 + k] = (unsigned short)v[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RP; ++k) row[k] = (k < a.r) ? a.Bw[(size_t)c * a.r + k] : (unsigned short)0;
+            }
+#pragma unroll
+            for (int k = 0; k < RP; ++k) a.BwT[(size_t)k * a.C + c] = row[k];
+        }
+    }
+    if (a.AT) {
+        for (int e = bid * 512 + tid; e < a.M * a.Cin; e += nblk * 512) {
+            const int m = e / a.Cin, c = e % a.Cin;
+            bf16x8* dst = (bf16x8*)(a.AT + (size_t)e * RP);
+            const unsigned short* src = a.Aw[m] + c;
+#pragma unroll
+            for (int k8 = 0; k8 < RP / 8; ++k8) {
+                bf16x8 v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (8 * k8 + k < a.r) ? (short)src[(size_t)(8 * k8 + k) * a.Cin] : (short)0;
+                dst[k8] = v;
+            }
         }
     }
 }
@@ -670,83 +701,48 @@ struct ExpandArgs {
 
 // D^T orientation: MFMA rows = output columns, MFMA columns = tokens, so every lane ends up with 8
 // consecutive bf16 of one token row (16 B) and a wave touches 16 rows x 64 B per instruction (the
-// read-modify-write microbenchmark streams this shape at 6.6 TB/s).  Tile pair p = 0,1 of column
+// read-modify-write microbenchmark streams this shape at 4.9-5.4 TB/s).  Tile pair p = 0,1 of column
 // block q covers 32 columns: MFMA row (4g+reg) of tile p <-> column 32q + 8g + 4p + reg.
-// Block = 4 waves, each owning NQ*32 columns whose weight fragments live in registers.
+// Block = 4 waves, each owning NQ*32 columns.  Weights arrive column-major with the rank contiguous
+// ([C][r]: Bw itself, or the AT shadow of A_m written by moka_cross_fwd), so a fragment is one 16-byte
+// load: the fragments of weight set 0 (the only one for y; the text adapter for dx) stay in registers
+// for the whole block, other modalities' fragments are fetched from L2 for the (few) tiles that need them.
 template <int RP, int NQ, bool W_CK>
 __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KH = (RP + 31) / 32;                 // 32-wide rank blocks per hi (or lo) plane
-    constexpr int NMW = W_CK ? 1 : MOKA_MAX_MOD;       // weight sets held in registers
     constexpr int WC = NQ * 32;                        // columns per wave
     constexpr int CW = 4 * WC;                         // columns per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int c_blk = blockIdx.x * CW;
-    const int c_wave = c_blk + wave * WC;
-    const bool wave_live = c_wave < a.C;               // C % 32 == 0, WC may overshoot in the last block
+    const int c_wave = blockIdx.x * CW + wave * WC;
+    if (c_wave >= a.C) return;                         // C % 32 == 0, WC may overshoot in the last block
+    const int wr = W_CK ? a.r : RP;                    // row length of the weight source (AT is padded to RP)
 
-    // ---- weight fragments -> registers
-    bf16x8 wf[NMW][NQ][2][KH];
-    if (W_CK) {
-        // Bw [C][r]: row c holds the r rank values contiguously
+    auto load_frag = [&](const unsigned char* W, int q, int p, int kh) -> bf16x8 {
+        const int c = c_wave + 32 * q + 8 * (i >> 2) + 4 * p + (i & 3);
+        const int k0 = (RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < a.C) {
+            const unsigned short* src = (const unsigned short*)W + (size_t)c * wr;
+            if (wr == RP) {
+                v = *(const bf16x8*)(src + k0);
+            } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int kh = 0; kh < KH; ++kh) {
-                    const int c = c_wave + 32 * q + 8 * (i >> 2) + 4 * p + (i & 3);
-                    const int k0 = (RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g;
-                    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (c < a.C) {
-                        const unsigned short* src = (const unsigned short*)a.W[0] + (size_t)c * a.r;
-                        if (a.r == RP) {
-                            v = *(const bf16x8*)(src + k0);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (k0 + e < a.r) ? (short)src[k0 + e] : (short)0;
-                        }
-                    }
-                    wf[0][q][p][kh] = v;
-                }
-    } else {
-        // A_m [r][C]: stage the block's column range row-major in LDS, read it back transposed
-        constexpr int PITCH = CW * 2 + 32;
-        for (int e = tid; e < a.M * RP * (CW / 8); e += 256) {
-            const int ch = e % (CW / 8), k = (e / (CW / 8)) % RP, m = e / ((CW / 8) * RP);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (k < a.r && c_blk + ch * 8 < a.C) v = *(const uint4*)(a.W[m] + ((size_t)k * a.C + c_blk + ch * 8) * 2);
-            *(uint4*)(smem + ((size_t)m * RP + k) * PITCH + ch * 16) = v;
+                for (int e = 0; e < 8; ++e) v[e] = (k0 + e < wr) ? (short)src[k0 + e] : (short)0;
+            }
         }
-        __syncthreads();
+        return v;
+    };
+    bf16x8 wf0[NQ][2][KH];
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int kh = 0; kh < KH; ++kh) {
-                        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (m < a.M) {
-                            // lane (4e'+q') supplies (rank row kb+e', columns 8q'+4p..+3) and receives, as lane i,
-                            // column 8(i>>2)+4p+(i&3) for 4 consecutive ranks
-                            const int kb = (RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g;
-                            const int col = wave * WC + 32 * q + 8 * (i & 3) + 4 * p;
-                            const unsigned char* base = smem + ((size_t)m * RP + kb + (i >> 2)) * PITCH + col * 2;
-                            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
-                            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 4 * PITCH));
-                            v = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        }
-                        wf[m][q][p][kh] = v;
-                    }
-    }
-    if (!wave_live) return;
+            for (int kh = 0; kh < KH; ++kh) wf0[q][p][kh] = load_frag(a.W[0], q, p, kh);
 
     const int ntiles = (a.T + 15) >> 4;
     const size_t prow = (size_t)(2 * RP) * 2;                     // pack row bytes
-
     for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
         const int t = (tile << 4) + i;                            // operand / result lanes: token = lane & 15
         const bool valid = t < a.T;
@@ -754,7 +750,6 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
         const int m0 = __builtin_amdgcn_readfirstlane(mrow);
         const bool same = __all(mrow == m0);
         if (same && m0 == MOKA_MOD_NONE) continue;
-        const bool single = W_CK || same;
         // B operand: my token's pack row.  RP == 16: K = 32 is [hi(16) | lo(16)] = elements 8g..8g+7 of the row.
         bf16x8 bh[KH], bl[KH];
         const unsigned char* prp = (const unsigned char*)a.pack + (size_t)min(t, a.T - 1) * prow;
@@ -773,39 +768,47 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             if (c_wave + 32 * q < a.C) o[q] = *(const bf16x8*)(orow + 64 * q);
+
+        f32x4 d[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) d[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (W_CK || (same && m0 == 0)) {
+            // shared Bw (the modality scale is in the pack) / all-text tile: resident fragments
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int kh = 0; kh < KH; ++kh) {
+                        d[q][p] = MFMA16(wf0[q][p][kh], bh[kh], d[q][p]);
+                        if (RP != 16) d[q][p] = MFMA16(wf0[q][p][kh], bl[kh], d[q][p]);
+                    }
+        } else {
+            // a non-text or mixed tile of the dx pass: one chain per modality present, tokens of the other
+            // modalities masked out of the B operand; non-text fragments come from the L2-resident shadow
+#pragma unroll
+            for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                if (m < a.M && __any(mrow == m)) {
+                    const bool mine = mrow == m;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int kh = 0; kh < KH; ++kh) {
+                                const bf16x8 wv = (m == 0) ? wf0[q][p][kh] : load_frag(a.W[m], q, p, kh);
+                                d[q][p] = MFMA16(wv, mine ? bh[kh] : z8, d[q][p]);
+                                if (RP != 16) d[q][p] = MFMA16(wv, mine ? bl[kh] : z8, d[q][p]);
+                            }
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (c_wave + 32 * q >= a.C) continue;
-            f32x4 d[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (single) {
-#pragma unroll
-                    for (int m = 0; m < NMW; ++m) {
-                        if (NMW == 1 || m == m0) {
-#pragma unroll
-                            for (int kh = 0; kh < KH; ++kh) {
-                                d[p] = MFMA16(wf[m][q][p][kh], bh[kh], d[p]);
-                                if (RP != 16) d[p] = MFMA16(wf[m][q][p][kh], bl[kh], d[p]);
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < NMW; ++m) {
-                        if (m < a.M && __any(mrow == m)) {
-                            const bool mine = (mrow == m);        // mask tokens of other modalities
-                            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                            for (int kh = 0; kh < KH; ++kh) {
-                                d[p] = MFMA16(wf[m][q][p][kh], mine ? bh[kh] : z, d[p]);
-                                if (RP != 16) d[p] = MFMA16(wf[m][q][p][kh], mine ? bl[kh] : z, d[p]);
-                            }
-                        }
-                    }
-                }
-            }
             unsigned keep = 0xffu;
             float dsc = 1.f;
             if (a.drop.thr) {
@@ -815,7 +818,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
             bf16x8 res;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (((keep >> e) & 1u) ? d[e >> 2][e & 3] * dsc : 0.f));
+                res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (((keep >> e) & 1u) ? d[q][e >> 2][e & 3] * dsc : 0.f));
             if (valid) *(bf16x8*)(orow + 64 * q) = res;
         }
     }
@@ -1172,13 +1175,11 @@ static void launch_expand_t(const ExpandArgs& a, hipStream_t st) {
     constexpr int CW = 4 * NQ * 32;
     const int nc = (a.C + CW - 1) / CW;
     const int ntiles = (a.T + 15) / 16;
-    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (W_CK ? (a.C > 8192 ? 8 : 4) : 3);
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (a.C > 8192 ? 8 : 4);
     int gy = (bpc * num_cu() + nc - 1) / nc;           // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
-    const size_t lds = W_CK ? 0 : (size_t)a.M * RP * (CW * 2 + 32);
-    ensure_lds((const void*)moka_expand_kernel<RP, NQ, W_CK>, lds);
-    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK>), dim3(nc, gy), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK>), dim3(nc, gy), dim3(256), 0, st, a);
 }
 
 template <bool W_CK>
@@ -1278,16 +1279,25 @@ int moka_down_fwd(const void* x, const void* const* A, const uint8_t* tok_mod, f
 }
 
 int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const float* s_out, const void* Bw, int d_out,
-                   float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT,
+                   const void* const* A, int d_in,
+                   float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT, void* AT,
                    int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
     if (!part || !rt || !s_out || !h || !hp_tok || !hp_kmj) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer");
     if (BwT && (!Bw || d_out < 32)) return fail(MOKA_EINVAL, "moka_cross_fwd: BwT requested without Bw / d_out");
+    if (AT && (!A || d_in < 32)) return fail(MOKA_EINVAL, "moka_cross_fwd: AT requested without A / d_in");
     CrossArgs a;
     memset(&a, 0, sizeof(a));
     a.part = part; a.ks = ks; a.out_f32 = h; a.out_f32b = hp;
     a.pack_tok = (unsigned short*)hp_tok; a.pack_kmj = (unsigned short*)hp_kmj;
     a.Bw = (const unsigned short*)Bw; a.BwT = (unsigned short*)BwT; a.C = d_out;
-    for (int m = 0; m < rt->M && m < MOKA_MAX_MOD; ++m) a.s_mod[m] = s_out[m];
+    a.AT = (unsigned short*)AT; a.Cin = d_in;
+    for (int m = 0; m < rt->M && m < MOKA_MAX_MOD; ++m) {
+        a.s_mod[m] = s_out[m];
+        if (AT) {
+            if (!A[m]) return fail(MOKA_EINVAL, "moka_cross_fwd: A[%d] is null", m);
+            a.Aw[m] = (const unsigned short*)A[m];
+        }
+    }
     a.w = w; a.c = inv_sqrt_dk;
     return launch_cross(false, a, rt, r, (hipStream_t)stream);
 }
@@ -1354,7 +1364,7 @@ int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8
     return rc;
 }
 
-int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* const* A, const uint8_t* tok_mod,
+int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* AT, const uint8_t* tok_mod,
                   float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M,
                   float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream) {
     int rc = check_common("moka_down_bwd", T, d_in, r, M, dtype);
@@ -1378,14 +1388,11 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
         if (rc) return rc;
     }
     if (dx_inout) {
-        if (!dh_tok || !A) return fail(MOKA_EINVAL, "moka_down_bwd: dx requested without dh_tok / A");
+        if (!dh_tok || !AT) return fail(MOKA_EINVAL, "moka_down_bwd: dx requested without dh_tok / AT");
         ExpandArgs a;
         memset(&a, 0, sizeof(a));
         a.pack = (const unsigned short*)dh_tok; a.tok_mod = tok_mod; a.out = (unsigned char*)dx_inout;
-        for (int m = 0; m < M; ++m) {
-            if (!A[m]) return fail(MOKA_EINVAL, "moka_down_bwd: A[%d] is null", m);
-            a.W[m] = (const unsigned char*)A[m];
-        }
+        for (int m = 0; m < M; ++m) a.W[m] = (const unsigned char*)AT + (size_t)m * d_in * RP * 2;
         a.T = T; a.C = d_in; a.r = r; a.M = M; a.drop = drop;
         rc = launch_expand<false>(a, RP, (hipStream_t)stream);
     }

@@ -61,11 +61,11 @@ def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: in
 
 class FwdState:
     """Rank-space results of the forward that the up-projection and the backward consume."""
-    __slots__ = ("h", "hp", "hp_tok", "hp_kmj", "BwT")
+    __slots__ = ("h", "hp", "hp_tok", "hp_kmj", "BwT", "AT")
 
 
 def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
-              Bw: Optional[torch.Tensor] = None, want_hp: bool = False) -> FwdState:
+              Bw: Optional[torch.Tensor] = None, want_hp: bool = False, A: Optional[Sequence[torch.Tensor]] = None) -> FwdState:
     lib = _lib.load()
     ks, T, RP = part.shape
     dev = part.device
@@ -76,10 +76,13 @@ def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float
     st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
     st.hp_kmj = torch.empty((2, RP, Tp), dtype=torch.bfloat16, device=dev)
     st.BwT = torch.empty((RP, Bw.shape[0]), dtype=torch.bfloat16, device=dev) if Bw is not None else None
+    st.AT = torch.empty((len(A), A[0].shape[1], RP), dtype=torch.bfloat16, device=dev) if A is not None else None
     _lib.check(lib.moka_cross_fwd(part.data_ptr(), ks, byref(rt.struct), _floats(s_out),
                                   None if Bw is None else Bw.data_ptr(), 0 if Bw is None else Bw.shape[0],
+                                  None if A is None else _ptrs(A), 0 if A is None else A[0].shape[1],
                                   st.h.data_ptr(), None if st.hp is None else st.hp.data_ptr(),
                                   st.hp_tok.data_ptr(), st.hp_kmj.data_ptr(), None if st.BwT is None else st.BwT.data_ptr(),
+                                  None if st.AT is None else st.AT.data_ptr(),
                                   r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_fwd")
     return st
 
@@ -128,15 +131,16 @@ def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, s_
     return st
 
 
-def down_bwd_(bst: BwdState, x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int,
+def down_bwd_(bst: BwdState, x2: torch.Tensor, AT: Optional[torch.Tensor], rt: MokaRouting, r: int,
               dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor],
               dropout_p: float = 0.0, seed: int = 0):
     """dA_acc[m] [r,d_in] fp32 += ; dx2 [T,d_in] bf16 += (either may be None)."""
     lib = _lib.load()
     T, d_in = x2.shape
-    _lib.check(lib.moka_down_bwd(bst.dh_tok.data_ptr(), bst.dh_kmj.data_ptr(), x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(),
+    _lib.check(lib.moka_down_bwd(bst.dh_tok.data_ptr(), bst.dh_kmj.data_ptr(), x2.data_ptr(),
+                                 None if AT is None else AT.data_ptr(), rt.tok_mod.data_ptr(),
                                  None if dA_acc is None else _ptrs(dA_acc), None if dx2 is None else dx2.data_ptr(),
-                                 T, d_in, r, len(A), float(dropout_p), int(seed), _lib.MOKA_BF16,
+                                 T, d_in, r, rt.M, float(dropout_p), int(seed), _lib.MOKA_BF16,
                                  _stream_ptr(x2.device)), "moka_down_bwd")
 
 
@@ -199,15 +203,15 @@ class MokaLinearFn(torch.autograd.Function):
         A = [a if a.is_contiguous() else a.contiguous() for a in A]
         Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
         part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed)
-        st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c)
+        st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
         up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
-        ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, *A)
+        ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
         ctx.rt, ctx.spec, ctx.x_shape, ctx.has_bias = rt, spec, x.shape, bias is not None
         return y.reshape(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
     def backward(ctx, gy):
-        x2, W, Bw, h, hp_kmj, BwT, *A = ctx.saved_tensors
+        x2, W, Bw, h, hp_kmj, BwT, AT, *A = ctx.saved_tensors
         rt, spec = ctx.rt, ctx.spec
         r = spec.r
         gy2 = gy.reshape(-1, gy.shape[-1])
@@ -225,7 +229,7 @@ class MokaLinearFn(torch.autograd.Function):
         if need_A or need_x:
             bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
             dA_acc = [torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=gy2.device) for _ in A] if need_A else None
-            down_bwd_(bst, x2, A, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed)
+            down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed)
             if need_A:
                 gA = [dA_acc[m].to(A[m].dtype) if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
         gbias = gy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

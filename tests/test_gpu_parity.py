@@ -125,7 +125,7 @@ def _stage_check(cd, y0=None, tol_f32=TOL_F32):
     hsum = part.sum(0)[:, :r]
     vdev = valid.to(dev)
     assert rel(hsum[vdev], ctx.h.reshape(T, r)[valid]) < tol_f32, "down_fwd"
-    st = F.cross_fwd(part, rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, want_hp=True)
+    st = F.cross_fwd(part, rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, want_hp=True, A=A)
     RP = st.h.shape[1]
     assert rel(st.h[:, :r], ctx.h.reshape(T, r)) < tol_f32, "cross_fwd h"
     assert rel(st.hp[:, :r], ctx.hp.reshape(T, r)) < tol_f32, "cross_fwd hp"
@@ -142,6 +142,8 @@ def _stage_check(cd, y0=None, tol_f32=TOL_F32):
     assert rel(kmj[:r, :T].t(), hps) < tol_f32, "hp_kmj pack"
     assert float(kmj[:, T:].abs().max() if Tp > T else 0.0) == 0.0
     assert torch.equal(st.BwT[:r].cpu(), cd.Bw.to(bf).t().contiguous()), "BwT"
+    for m in range(M):
+        assert torch.equal(st.AT[m, :, :r].cpu(), cd.A[m].to(bf).t().contiguous()), "AT"
     y2 = y0.reshape(T, c.d_out).to(dev, bf).contiguous()
     F.up_fwd_(y2, st.hp_tok, Bw, rt, r)
     y_exact_bf = yo.reshape(T, c.d_out).to(bf)
@@ -161,7 +163,7 @@ def _stage_check(cd, y0=None, tol_f32=TOL_F32):
     assert rel((dtok[:, :RP] + dtok[:, RP:])[:, :r][vdev], (spec.s_in * dho.reshape(T, r))[valid]) < tol_f32, "dh_tok pack"
     dA_acc = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]
     dx2 = dx0.reshape(T, c.d_in).to(dev, bf).contiguous()
-    F.down_bwd_(bst, x2, A, rt, r, dA_acc, dx2)
+    F.down_bwd_(bst, x2, st.AT, rt, r, dA_acc, dx2)
     for m in range(M):
         assert rel(dA_acc[m], dAo[m]) < tol_f32, f"down_bwd dA{m}"
     dx_exact_bf = (dx0.double() + dxo).reshape(T, c.d_in).to(bf)
@@ -309,7 +311,7 @@ def test_dropout_replays_exactly_through_the_mask(name, p):
     dxm, dAo, dBo, _ = O.adapter_backward(cd.gy, ctx)
     dxo = dxm * keep * inv_keep
     r = c.r
-    st = F.cross_fwd(F.down_fwd(x2, A, rt, r, spec.s_in, p, seed), rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw)
+    st = F.cross_fwd(F.down_fwd(x2, A, rt, r, spec.s_in, p, seed), rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, A=A)
     y2 = torch.zeros(T, c.d_out, dtype=bf, device=dev)
     F.up_fwd_(y2, st.hp_tok, Bw, rt, r)
     assert rel(y2, yo.reshape(T, c.d_out).to(bf)) < TOL_BF16
@@ -317,7 +319,7 @@ def test_dropout_replays_exactly_through_the_mask(name, p):
     bst = F.cross_bwd(F.up_bwd(gy2, st.hp_kmj, st.BwT, rt, r, spec.s_out, dB_acc), st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
     dA_acc = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]
     dx2 = torch.zeros(T, c.d_in, dtype=bf, device=dev)
-    F.down_bwd_(bst, x2, A, rt, r, dA_acc, dx2, p, seed)
+    F.down_bwd_(bst, x2, st.AT, rt, r, dA_acc, dx2, p, seed)
     assert rel(dB_acc, dBo) < TOL_F32
     for m in range(M):
         assert rel(dA_acc[m], dAo[m]) < TOL_F32, f"dA{m}"

@@ -44,11 +44,12 @@ def main():
         hp_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
         hp_kmj = torch.empty(2, RP, Tp, dtype=bf, device=dev)
         BwT = torch.empty(RP, d_out, dtype=bf, device=dev)
+        AT = torch.empty(M, d_in, RP, dtype=bf, device=dev)
         dh_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
         dh_kmj = torch.empty(M, 2, RP, Tp, dtype=bf, device=dev)
         dA = [torch.zeros(r, d_in, dtype=f32, device=dev) for _ in range(M)]
         dB = torch.zeros(d_out, r, dtype=f32, device=dev)
-        return dict(xs=xs, ys=ys, dxs=dxs, A=A, Bw=Bw, part=part, h=h, hp_tok=hp_tok, hp_kmj=hp_kmj, BwT=BwT,
+        return dict(xs=xs, ys=ys, dxs=dxs, A=A, Bw=Bw, part=part, h=h, hp_tok=hp_tok, hp_kmj=hp_kmj, BwT=BwT, AT=AT,
                     dh_tok=dh_tok, dh_kmj=dh_kmj, dA=dA, dB=dB, d_in=d_in, d_out=d_out)
 
     def calls(w):
@@ -62,15 +63,15 @@ def main():
         sp = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
         return {
             "down_fwd": lambda i: lib.moka_down_fwd(w["xs"][i % NBUF].data_ptr(), Ap, tm, w["part"].data_ptr(), T, d_in, r, M, 1.0, DROP, 1234, 0, sp()),
-            "cross_fwd": lambda i: lib.moka_cross_fwd(w["part"].data_ptr(), _lib.ksplit(T, d_in, r), byref(rt.struct), so, w["Bw"].data_ptr(), d_out,
-                                                      w["h"].data_ptr(), None, w["hp_tok"].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), r, 1.0, c, sp()),
+            "cross_fwd": lambda i: lib.moka_cross_fwd(w["part"].data_ptr(), _lib.ksplit(T, d_in, r), byref(rt.struct), so, w["Bw"].data_ptr(), d_out, Ap, d_in,
+                                                      w["h"].data_ptr(), None, w["hp_tok"].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), w["AT"].data_ptr(), r, 1.0, c, sp()),
             "up_fwd": lambda i: lib.moka_up_fwd(w["hp_tok"].data_ptr(), w["Bw"].data_ptr(), tm, w["ys"][i % NBUF].data_ptr(), T, r, d_out, 0, sp()),
             "up_bwd(g only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), None, T, r, d_out, M, 0, sp()),
             "up_bwd(g+dB)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
             "cross_bwd": lambda i: lib.moka_cross_bwd(w["part"].data_ptr(), _lib.ksplit(T, d_out, r), w["h"].data_ptr(), byref(rt.struct), 1.0, None,
                                                       w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), rt.cross_ws(r).data_ptr(), r, 1.0, c, sp()),
-            "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, dAp, None, T, d_in, r, M, DROP, 1234, 0, sp()),
-            "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), Ap, tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, DROP, 1234, 0, sp()),
+            "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, dAp, None, T, d_in, r, M, DROP, 1234, 0, sp()),
+            "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, DROP, 1234, 0, sp()),
         }
 
     def timeit(fn, iters=24):
