@@ -106,7 +106,7 @@ int moka_ksplit(int T, int C, int r);
  * skipped (their partial rows stay unwritten; consumers treat such rows as zero).
  * Dropout (lora_dropout, lora.py:264-267 / layer.py:101-106): with dropout_p > 0 the kernel computes
  * s_in/(1-p') * (keep .* x[t]) A^T where keep is the counter-based mask of (seed, t, column) and
- * p' = round(p * 65536) / 65536; pass the SAME (dropout_p, seed) to moka_down_bwd. */
+ * p' = round(p * 32768) / 32768; pass the SAME (dropout_p, seed) to moka_down_bwd. */
 int moka_down_fwd(const void* x, const void* const* A /*host array of M device ptrs*/,
                   const uint8_t* tok_mod, float* part,
                   int T, int d_in, int r, int M, float s_in, float dropout_p, unsigned long long seed,

@@ -92,33 +92,46 @@ static __device__ __forceinline__ void wave_sum_vec(float (&v)[N]) {
     for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
 }
 
-// ---- dropout: counter-based keep mask, one hash per 16-byte chunk (8 bf16 of one token row) -------
-// keep(e) = u16(seed, token, chunk, e) >= thr with thr = round(p * 65536).  The same function is
-// evaluated by the down-projection (x), the dA kernel (x) and the dx kernel (output), so nothing is
-// stored and a re-run of the forward (activation checkpointing) reproduces the mask bit for bit.
-struct DropArgs { unsigned thr, seed_lo, seed_hi; float inv_keep; };
+// ---- dropout: counter-based keep mask, one base hash per 16-byte chunk (8 bf16 of one token row) ----
+// chunk idx = token * (C/8) + column/8;  base = fmix32(idx ^ seed_lo) + seed_hi;  dword w of the chunk
+// gets x_w = base * K_w, x_w ^= x_w >> 15, and its two elements keep iff the 15-bit fields
+// x_w[14:0] / x_w[30:16] are >= thr = round(p * 32768).  The compare runs packed (v_pk_sub_i16 +
+// v_pk_ashrrev_i16 -> 0xffff per kept element), ~35 VALU instructions per chunk -- the stream budget
+// is ~130 per 16-byte load.  The same function is evaluated by the down-projection (x), the dA kernel
+// (x) and the dx kernel (output), so nothing is stored and a re-run of the forward (activation
+// checkpointing) reproduces the mask bit for bit.
+struct DropArgs { unsigned thr, seed_lo, seed_hi, thrm1_pk; float inv_keep; };
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+struct KeepMask { unsigned w[4]; };          // 0xffff in each kept 16-bit half
 
 static __device__ __forceinline__ unsigned fmix32(unsigned h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
-// 8 keep bits of chunk `idx` (= token * (C/8) + column/8)
-static __device__ __forceinline__ unsigned drop_keep8(const DropArgs& d, unsigned idx) {
+static __device__ __forceinline__ KeepMask drop_keep8(const DropArgs& d, unsigned idx) {
     const unsigned base = fmix32(idx ^ d.seed_lo) + d.seed_hi;
-    unsigned m = 0;
+    constexpr unsigned K[4] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu};
+    KeepMask km;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const unsigned x = fmix32(base + (unsigned)w * 0x9E3779B9u);
-        m |= ((x & 0xffffu) >= d.thr ? 1u : 0u) << (2 * w);
-        m |= ((x >> 16) >= d.thr ? 1u : 0u) << (2 * w + 1);
+        unsigned x = base * K[w];
+        x ^= x >> 15;
+        x &= 0x7fff7fffu;
+        union { unsigned u; s16x2 v; } r, t, m;
+        r.u = x; t.u = d.thrm1_pk;
+        m.v = (t.v - r.v) >> 15;                     // (thr-1 - field) < 0  <=>  field >= thr  <=>  keep
+        km.w[w] = m.u;
     }
-    return m;
+    return km;
 }
-static __device__ __forceinline__ bf16x8 drop_apply(bf16x8 v, unsigned keep) {
+static __device__ __forceinline__ bf16x8 drop_apply(bf16x8 v, const KeepMask& km) {
+    union { bf16x8 b; unsigned u[4]; } x;
+    x.b = v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] : (short)0;
-    return v;
+    for (int w = 0; w < 4; ++w) x.u[w] &= km.w[w];
+    return x.b;
 }
+static __device__ __forceinline__ bool drop_kept(const KeepMask& km, int e) { return (km.w[e >> 1] >> (16 * (e & 1))) & 1u; }
 
 // position of token (t & 31) inside its group of 32 in the rank-major packs
 static __device__ __forceinline__ int kmj_pos(int tl) {
@@ -809,7 +822,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (c_wave + 32 * q >= a.C) continue;
-            unsigned keep = 0xffu;
+            KeepMask keep = {{~0u, ~0u, ~0u, ~0u}};
             float dsc = 1.f;
             if (a.drop.thr) {
                 keep = drop_keep8(a.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
@@ -818,7 +831,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
             bf16x8 res;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (((keep >> e) & 1u) ? d[q][e >> 2][e & 3] * dsc : 0.f));
+                res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (drop_kept(keep, e) ? d[q][e >> 2][e & 3] * dsc : 0.f));
             if (valid) *(bf16x8*)(orow + 64 * q) = res;
         }
     }
@@ -924,7 +937,7 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
                 uint4 v = ld[sb][u];
                 if (a.drop.thr) {
                     const unsigned trow = (unsigned)min((grp << 5) + 8 * u + lrow, a.T - 1);
-                    const unsigned keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((c_begin + sb * 64) >> 3) + (unsigned)lcol);
+                    const KeepMask keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((c_begin + sb * 64) >> 3) + (unsigned)lcol);
                     bf16x8 t8 = drop_apply(*(bf16x8*)&v, keep);
                     v = *(uint4*)&t8;
                 }
@@ -1012,9 +1025,9 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
 __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
     const size_t nchunk = (size_t)T * (C >> 3);
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nchunk; idx += (size_t)gridDim.x * 256) {
-        const unsigned keep = drop_keep8(d, (unsigned)idx);
+        const KeepMask keep = drop_keep8(d, (unsigned)idx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) out[idx * 8 + e] = (keep >> e) & 1u;
+        for (int e = 0; e < 8; ++e) out[idx * 8 + e] = drop_kept(keep, e) ? 1 : 0;
     }
 }
 
@@ -1091,13 +1104,14 @@ static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs*
     d->inv_keep = 1.f;
     if (p == 0.f) return MOKA_OK;
     if (!(p > 0.f) || p >= 1.f) return fail(MOKA_EINVAL, "%s: dropout probability %g not in [0, 1)", fn, (double)p);
-    unsigned thr = (unsigned)(p * 65536.f + 0.5f);
+    unsigned thr = (unsigned)(p * 32768.f + 0.5f);
     if (thr < 1) thr = 1;
-    if (thr > 65535) thr = 65535;
+    if (thr > 32767) thr = 32767;
     d->thr = thr;
+    d->thrm1_pk = (thr - 1) | ((thr - 1) << 16);
     d->seed_lo = (unsigned)(seed & 0xffffffffull);
     d->seed_hi = (unsigned)(seed >> 32);
-    d->inv_keep = 65536.f / (float)(65536u - thr);
+    d->inv_keep = 32768.f / (float)(32768u - thr);
     return MOKA_OK;
 }
 

@@ -63,7 +63,7 @@ def test_argument_validation_sets_error_message(lib):
     # dropout probability out of range
     rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 1.5, 7, 0, None)
     assert rc == -1 and b"dropout" in lib.moka_last_error()
-    assert abs(lib.moka_dropout_scale(0.05) - 65536.0 / (65536 - 3277)) < 1e-6
+    assert abs(lib.moka_dropout_scale(0.05) - 32768.0 / (32768 - 1638)) < 1e-6
     # null pointer
     rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 0, None)
     assert rc == -1 and b"null" in lib.moka_last_error()
