@@ -4,7 +4,7 @@ kernels consume (``moka_routing`` in include/moka_hip.h).
 The reference re-derives indices from the masks inside every one of the 224 adapter calls
 of a forward, with ~10 host syncs per call (VT ``layer.py:603-667``: ``.any()``,
 ``.nonzero()``, ``torch.where``; AVT ``lora.py:489,512``: ``torch.where`` per sample).  Here
-the masks are turned into ``tok_mod`` / ``kpos`` / ``klen`` on the device with a single
+the masks are turned into ``tok_mod`` / key positions / ``klen`` on the device with a single
 host read-back per batch (needed for the key-block size and to raise the reference's
 errors), and the result is cached on the identity of the mask tensors.
 """
