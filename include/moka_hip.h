@@ -86,7 +86,7 @@ const char* moka_last_error(void);
 /* 0 when a gfx950 device is current, MOKA_ENODEV otherwise. */
 int         moka_device_check(void);
 
-/* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_ks", "expand_bpc", "wgrad_ct",
+/* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_u", "reduce_ks", "expand_bpc", "wgrad_ct",
  * "wgrad_bpc", "cross_rows"; value 0 restores the default).  Results never depend on it. */
 int moka_tune(const char* key, int value);
 

@@ -159,13 +159,14 @@ struct ReduceArgs {
 };
 
 // One block per (32-token tile, K slice).  The NW waves of the block split the slice's K steps;
-// every wave issues its loads in batches of U steps (x: HBM, 16 rows x 64 B per instruction;
-// W: L2), then the 16x16 partial tiles are summed through LDS.
-template <int RP, int NW>
+// every wave keeps TWO batches of U steps in flight (x: HBM, 16 rows x 64 B per instruction; W: L2):
+// batch i+1 (x and the weight fragments of the tile's first modality) is issued before batch i is
+// consumed, so the memory pipe never waits for the MFMA / weight round trip.  At the end the 16x16
+// partial tiles are summed through LDS.
+template <int RP, int NW, int U>
 __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
-    constexpr int U = 4;                                  // K steps per load batch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int t0 = blockIdx.x << 5;
@@ -173,12 +174,47 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
     const int S0 = (int)(((long)blockIdx.y * nst) / a.ks), S1 = (int)(((long)(blockIdx.y + 1) * nst) / a.ks);
     const int s_begin = S0 + (int)(((long)wave * (S1 - S0)) / NW), s_end = S0 + (int)(((long)(wave + 1) * (S1 - S0)) / NW);
 
-    // The x stream does not depend on the routing: issue the first batch right away, the tok_mod
-    // bytes (which only select the weight rows / the skip) arrive underneath it.
     const unsigned char* xrow[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
         xrow[st] = a.in + ((size_t)min(t0 + 16 * st + i, a.T - 1) * a.C + 8 * g) * 2;
+    unsigned pres[2] = {1u, 1u};                          // bit m: modality m present in sub-tile (block uniform)
+    auto issue_x = [&](bf16x8 (&xb)[U][2], int s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s + u < s_end) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    if (pres[st]) xb[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s + u) * 64);
+            }
+        }
+    };
+    auto issue_w1 = [&](bf16x8 (&wb)[U][NT], int s, int m) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s + u < s_end) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    // rank rows >= r do not exist: clamp the row, its products are zeroed at the end
+                    const int krow = min(nt * 16 + i, a.r - 1);
+                    wb[u][nt] = *(const bf16x8*)(a.W[m] + ((size_t)krow * a.C + 8 * g) * 2 + (size_t)(s + u) * 64);
+                }
+            }
+        }
+    };
+
+    // Weight fragments of the tile's first modality travel with the x batch; the other modalities of a
+    // tile that straddles a span boundary are fetched on demand.  (Measured: prefetching a second set
+    // unconditionally costs 7 % on single-modality tiles -- the weight fragments are 1 KB of L2 traffic
+    // per 2 KB of x -- and conditionally issued loads make the vmcnt bookkeeping conservative, so the
+    // ~3 % boundary tiles run ~14 % longer either way.)
+    int mfirst = 0;
+    auto issue_w = [&](bf16x8 (&wb)[U][NT], int s) { issue_w1(wb, s, mfirst); };
+
+    // The x stream does not depend on the routing: issue the first batch right away, the tok_mod
+    // bytes (which only select the weight rows / the skip) arrive underneath it.
+    bf16x8 xA[U][2], xB[U][2], wA[U][NT], wB[U][NT];
+    issue_x(xA, s_begin);
     int mrow2[2];
     unsigned mods4[2];                                    // modalities of my 4 result rows
 #pragma unroll
@@ -186,15 +222,6 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
         mrow2[st] = a.tok_mod[t0 + 16 * st + i];
         mods4[st] = *(const unsigned*)(a.tok_mod + t0 + 16 * st + 4 * g);
     }
-    bf16x8 xv[U][2];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (s_begin + u < s_end) {
-#pragma unroll
-            for (int st = 0; st < 2; ++st) xv[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s_begin + u) * 64);
-        }
-    }
-    unsigned pres[2];                                     // bit m: modality m present in sub-tile (block uniform)
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         unsigned p = 0;
@@ -203,7 +230,10 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
         if (a.shared_w && p) p = 1u;                      // one chain, scale selected per row
         pres[st] = p;
     }
-    if ((pres[0] | pres[1]) == 0) return;                 // padding tile (its speculative first batch is the only waste)
+    const unsigned pany = pres[0] | pres[1];
+    if (pany == 0) return;                                // padding tile (its speculative first batch is the only waste)
+    mfirst = __builtin_ctz(pany);
+    issue_w(wA, s_begin);
 
     f32x4 acc[2][MOKA_MAX_MOD][NT];
 #pragma unroll
@@ -213,17 +243,7 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[st][m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int s = s_begin; s < s_end; s += U) {
-        if (s != s_begin) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (s + u < s_end) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-                        if (pres[st]) xv[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s + u) * 64);
-                }
-            }
-        }
+    auto consume = [&](bf16x8 (&xb)[U][2], bf16x8 (&wb)[U][NT], int s) {
         if (a.drop.thr) {                                     // wave uniform
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -231,26 +251,16 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
                         const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
-                        if (pres[st]) xv[u][st] = drop_apply(xv[u][st], drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((s + u) * 4 + g)));
+                        if (pres[st]) xb[u][st] = drop_apply(xb[u][st], drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((s + u) * 4 + g)));
                     }
                 }
             }
         }
 #pragma unroll
         for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-            if (!((pres[0] | pres[1]) & (1u << m))) continue;
-            bf16x8 wv[U][NT];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (s + u < s_end) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        // rank rows >= r do not exist: clamp the row, its products are zeroed below
-                        const int krow = min(nt * 16 + i, a.r - 1);
-                        wv[u][nt] = *(const bf16x8*)(a.W[m] + ((size_t)krow * a.C + 8 * g) * 2 + (size_t)(s + u) * 64);
-                    }
-                }
-            }
+            if (!(pany & (1u << m))) continue;
+            bf16x8 wx[U][NT];
+            if (m != mfirst) issue_w1(wx, s, m);               // span boundary inside the tile (rare)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (s + u < s_end) {
@@ -258,12 +268,23 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
                     for (int st = 0; st < 2; ++st) {
                         if (pres[st] & (1u << m)) {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) acc[st][m][nt] = MFMA16(xv[u][st], wv[u][nt], acc[st][m][nt]);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[st][m][nt] = MFMA16(xb[u][st], (m == mfirst) ? wb[u][nt] : wx[u][nt], acc[st][m][nt]);
                         }
                     }
                 }
             }
         }
+    };
+
+    for (int s = s_begin; s < s_end;) {
+        if (s + U < s_end) { issue_x(xB, s + U); issue_w(wB, s + U); }
+        consume(xA, wA, s);
+        s += U;
+        if (s >= s_end) break;
+        if (s + U < s_end) { issue_x(xA, s + U); issue_w(wA, s + U); }
+        consume(xB, wB, s);
+        s += U;
     }
 
     // select per row, scale, and reduce the NW partial tiles through LDS
@@ -1068,7 +1089,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_reduce_nw = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1126,18 +1147,22 @@ static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     return MOKA_OK;
 }
 
-template <int RP, int NW>
+template <int RP, int NW, int U>
 static void launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NW * 2 * (RP / 16) * 256 * 4;
     dim3 grid((a.T + 31) / 32, a.ks), block(NW * 64);
-    ensure_lds((const void*)moka_reduce_kernel<RP, NW>, lds);
-    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW>), grid, block, lds, st, a);
+    ensure_lds((const void*)moka_reduce_kernel<RP, NW, U>, lds);
+    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U>), grid, block, lds, st, a);
 }
 
 static int launch_reduce(const ReduceArgs& a, int RP, hipStream_t st) {
-    if (RP == 16) { if (g_tune_reduce_nw == 16) launch_reduce_t<16, 16>(a, st); else launch_reduce_t<16, 8>(a, st); }
-    else if (RP == 32) launch_reduce_t<32, 8>(a, st);
-    else launch_reduce_t<64, 8>(a, st);
+    if (RP == 16) {
+        const int nw = g_tune_reduce_nw == 8 ? 8 : 4, u = g_tune_reduce_u == 4 ? 4 : 2;
+        if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4>(a, st); else launch_reduce_t<16, 4, 2>(a, st); }
+        else { if (u == 4) launch_reduce_t<16, 8, 4>(a, st); else launch_reduce_t<16, 8, 2>(a, st); }
+    }
+    else if (RP == 32) launch_reduce_t<32, 8, 2>(a, st);
+    else launch_reduce_t<64, 8, 1>(a, st);
     return check_launch("moka_reduce_kernel");
 }
 
@@ -1250,6 +1275,7 @@ int moka_device_check(void) {
 int moka_tune(const char* key, int value) {
     if (!key) return fail(MOKA_EINVAL, "moka_tune: null key");
     if (!strcmp(key, "reduce_nw")) g_tune_reduce_nw = value;
+    else if (!strcmp(key, "reduce_u")) g_tune_reduce_u = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;

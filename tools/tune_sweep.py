@@ -26,6 +26,14 @@ def main():
     DROP = float(os.environ.get("DROP", 0.0))
     T = B * S
     tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    if os.environ.get("ALLTEXT"):
+        tok = torch.zeros_like(tok)
+    if os.environ.get("ALLIMG"):
+        tok = torch.ones_like(tok)
+    if os.environ.get("ALIGNED"):       # same proportions, every span boundary on a multiple of 32
+        tok = torch.zeros_like(tok)
+        tok[32:288] = 1
+        tok[320:448] = 2
     masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
     masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
     rt = MokaRouting.from_avt_masks(masks)
@@ -87,6 +95,7 @@ def main():
         return e0.elapsed_time(e1) / iters * 1e3
 
     E = 2
+    only = os.environ.get("ONLY")
     for (d_in, d_out) in [(4096, 4096), (4096, 11008), (11008, 4096)]:
         w = shapes(d_in, d_out)
         cs = calls(w)
@@ -97,8 +106,8 @@ def main():
         algo = {"down_fwd": E * T * d_in, "up_fwd": 2 * E * T * d_out, "up_bwd(g only)": E * T * d_out, "up_bwd(g+dB)": E * T * d_out,
                 "down_bwd(dA only)": E * T * d_in, "down_bwd(dx only)": 2 * E * T * d_in, "cross_fwd": 0, "cross_bwd": 0}
         sweeps = {
-            "down_fwd": [("reduce_nw", v) for v in (8, 16)] + [("reduce_ks", v) for v in (1, 2, 4)],
-            "up_bwd(g only)": [("reduce_nw", v) for v in (8, 16)],
+            "down_fwd": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
+            "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_fwd": [("expand_bpc", v) for v in (2, 4, 6, 8)],
             "down_bwd(dx only)": [("expand_bpc", v) for v in (2, 3, 4)],
             "up_bwd(g+dB)": [("wgrad_ct", v) for v in (1, 2)] + [("wgrad_bpc", v) for v in (1, 2, 4)],
@@ -108,6 +117,8 @@ def main():
         }
         print(f"\n=== {d_in} -> {d_out}  (T={T}) ===")
         for name, fn in cs.items():
+            if only and only not in name:
+                continue
             base = timeit(fn)
             gb = algo[name] / (base * 1e-6) / 1e9 if algo[name] else 0
             print(f"{name:20s} default            {base:8.1f} us  {gb:7.0f} GB/s algorithmic")
