@@ -55,6 +55,22 @@ def algorithmic_bytes_per_token(d, ff, r, layers):
     return fwd * layers, bwd * layers
 
 
+def synthetic_layout(S):
+    """[16 text][256 image/video][16 text][128 audio][64 question][rest text] per 2048 tokens.
+    Returns (tok_mod int64[S] with 0 = text, 1 = image, 2 = audio; question bool[S])."""
+    k = S / 2048.0
+    n_pre, n_img, n_mid, n_aud, n_q = int(16 * k), int(256 * k), int(16 * k), int(128 * k), int(64 * k)
+    tok = torch.zeros(S, dtype=torch.int64)
+    q = torch.zeros(S, dtype=torch.bool)
+    p = n_pre
+    tok[p:p + n_img] = 1
+    p += n_img + n_mid
+    tok[p:p + n_aud] = 2
+    p += n_aud
+    q[p:p + n_q] = True
+    return tok, q
+
+
 class Proj:
     """One adapted projection: device buffers + pre-built ctypes arguments for the six launches."""
 
@@ -78,19 +94,21 @@ class Proj:
                    hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), AT.data_ptr(), r, w, c)
         self.f3 = (hp_tok.data_ptr(), Bw.data_ptr(), tm, y.data_ptr(), T, r, d_out, 0)
         self.b1 = (y.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), tm, so, part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
+        self.b1g = (y.data_ptr(), None, BwT.data_ptr(), tm, so, part.data_ptr(), None, T, r, d_out, M, 0)          # gy.Bw only
+        self.b1w = (y.data_ptr(), hp_kmj.data_ptr(), None, tm, so, None, dB.data_ptr(), T, r, d_out, M, 0)         # dB only
         self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), rt.cross_ws(r).data_ptr(), r, w, c)
         self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), AT.data_ptr(), tm, dAp, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)
+        self.b3x = (dh_tok.data_ptr(), None, x.data_ptr(), AT.data_ptr(), tm, None, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)    # dx only
+        self.b3w = (None, dh_kmj.data_ptr(), x.data_ptr(), None, tm, dAp, None, T, d_in, r, M, drop_p, seed, 0)              # dA only
 
 
 def build_workload(args, dev, lib, bucket_factory):
     from moka_amd import _lib
     from moka_amd.routing import MokaRouting
-    from oracle import cases as C
     B, S, r, M = args.batch, args.seq, args.rank, 3
     d, ff, L = LLAMA7B["d"], LLAMA7B["ff"], args.layers
     T = B * S
-    g = torch.Generator(device="cpu").manual_seed(42 + args.rank_id)
-    tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    tok, q = synthetic_layout(S)
     masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
     masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
     rt = MokaRouting.from_avt_masks(masks)
@@ -205,15 +223,42 @@ def run_forward(lib, wl, sp, rec=None):
         _call(lib, "moka_up_fwd", p.f3, sp, rec, p)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None):
+class SideStream:
+    """Experiment (--side-stream): second HIP stream for the weight-gradient kernels of the backward: dB runs
+    beside gy.Bw -> cross backward, dA beside dx, joined with the main stream at the end of every projection.
+    Measured on MI355X: 150.1 k vs 152.5 k tokens/s without -- every kernel already fills all CUs, so a
+    second queue only adds contention.  Kept for re-measurement, off by default."""
+
+    def __init__(self, dev, n_proj):
+        self.stream = torch.cuda.Stream(device=dev)
+        self.sp = c_void_p(self.stream.cuda_stream)
+        self.ev = [[torch.cuda.Event() for _ in range(3)] for _ in range(n_proj)]
+
+
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, side=None):
     """Reverse layer order; `on_layer_done(l)` fires after layer l's launches are enqueued."""
     projs = wl["projs"]
     per = len(PROJS)
+    main = torch.cuda.current_stream()
     for l in range(n_layers - 1, -1, -1):
-        for p in reversed(projs[l * per:(l + 1) * per]):
-            _call(lib, "moka_up_bwd", p.b1, sp, rec, p)
+        for k, p in enumerate(reversed(projs[l * per:(l + 1) * per])):
+            if side is None:
+                _call(lib, "moka_up_bwd", p.b1, sp, rec, p)
+                _call(lib, "moka_cross_bwd", p.b2, sp, rec, p)
+                _call(lib, "moka_down_bwd", p.b3, sp, rec, p)
+                continue
+            e_start, e_dh, e_done = side.ev[l * per + k]
+            e_start.record(main)                     # everything before this projection (zeroed grads, buffers free)
+            side.stream.wait_event(e_start)
+            _call(lib, "moka_up_bwd", p.b1w, side.sp, None, p)          # dB            (side)
+            _call(lib, "moka_up_bwd", p.b1g, sp, rec, p)                # gy.Bw         (main)
             _call(lib, "moka_cross_bwd", p.b2, sp, rec, p)
-            _call(lib, "moka_down_bwd", p.b3, sp, rec, p)
+            e_dh.record(main)
+            side.stream.wait_event(e_dh)
+            _call(lib, "moka_down_bwd", p.b3w, side.sp, None, p)        # dA            (side)
+            _call(lib, "moka_down_bwd", p.b3x, sp, rec, p)              # dx            (main)
+            e_done.record(side.stream)
+            main.wait_event(e_done)
         if on_layer_done is not None:
             on_layer_done(l)
 
@@ -303,6 +348,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="experiment: weight-gradient kernels on a second HIP stream (measured: no gain, the kernels fill the chip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -335,6 +382,7 @@ def main():
         opt = torch.optim.AdamW([mp], lr=1e-4, fused=True)
     L = args.layers
 
+    side = SideStream(dev, len(wl["projs"])) if args.side_stream else None
     records = Recorder(only=LIVE)
     records.reserve(2 * len(wl["projs"]) * args.steps + 16)
 
@@ -342,7 +390,7 @@ def main():
         sp = c_void_p(main_stream.cuda_stream)
         bucket.zero_()                               # same stream as the previous optimizer step
         run_forward(lib, wl, sp, rec)
-        run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
+        run_backward(lib, wl, sp, L, bucket.layer_done, rec, side)   # all-reduce of finished layer groups overlaps the rest
         bucket.finish(average=True)
         if opt is not None:
             opt.step()

@@ -132,7 +132,9 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
 
 /* g_part[s][t] = partial over d_out slice s of s_out[mod(t)] * gy[t] Bw   (needs BwT) and
  * dB_acc[o][k] += sum_t gy[t][o] * (s_out[mod(t)] hp[t][k])   (needs hp_kmj; fp32 accumulate,
- * the caller owns / zeroes dB_acc [d_out, r]; NULL skips it). */
+ * the caller owns / zeroes dB_acc [d_out, r]).  Either output may be NULL (skipped): the two halves are
+ * independent kernels, so a caller may enqueue them on different streams (as it may for the dA / dx
+ * halves of moka_down_bwd) -- each reads gy once. */
 int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8_t* tok_mod,
                 const float* s_out /*host, M floats*/, float* g_part, float* dB_acc,
                 int T, int r, int d_out, int M, int dtype, moka_stream_t stream);

@@ -1383,16 +1383,19 @@ int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8
                 float* g_part, float* dB_acc, int T, int r, int d_out, int M, int dtype, moka_stream_t stream) {
     int rc = check_common("moka_up_bwd", T, d_out, r, M, dtype);
     if (rc) return rc;
-    if (!gy || !BwT || !tok_mod || !s_out || !g_part) return fail(MOKA_EINVAL, "moka_up_bwd: null pointer");
+    if (!gy || !tok_mod || !s_out) return fail(MOKA_EINVAL, "moka_up_bwd: null pointer");
     const int RP = rank_pad(r);
-    // g = s_out[mod] * gy Bw: contraction over d_out with the transposed weight; one chain per tile
-    ReduceArgs ra;
-    memset(&ra, 0, sizeof(ra));
-    ra.in = (const unsigned char*)gy; ra.W[0] = (const unsigned char*)BwT; ra.tok_mod = tok_mod; ra.out = g_part;
-    for (int m = 0; m < M; ++m) ra.s_mod[m] = s_out[m];
-    ra.T = T; ra.C = d_out; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = reduce_ks(T, d_out);   // BwT has RP zero-padded rows
-    rc = launch_reduce(ra, RP, (hipStream_t)stream);
-    if (rc) return rc;
+    if (g_part) {
+        // g = s_out[mod] * gy Bw: contraction over d_out with the transposed weight; one chain per tile
+        if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
+        ReduceArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.in = (const unsigned char*)gy; ra.W[0] = (const unsigned char*)BwT; ra.tok_mod = tok_mod; ra.out = g_part;
+        for (int m = 0; m < M; ++m) ra.s_mod[m] = s_out[m];
+        ra.T = T; ra.C = d_out; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = reduce_ks(T, d_out);   // BwT has RP zero-padded rows
+        rc = launch_reduce(ra, RP, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     if (dB_acc) {
         if (!hp_kmj) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without hp_kmj");
         WgradArgs ga;

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from moka_amd import _lib  # noqa: E402
 from moka_amd.routing import MokaRouting  # noqa: E402
-from oracle import cases as C  # noqa: E402
+import bench  # noqa: E402
 
 
 DROP = 0.0
@@ -25,7 +25,7 @@ def main():
     global DROP
     DROP = float(os.environ.get("DROP", 0.0))
     T = B * S
-    tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    tok, q = bench.synthetic_layout(S)
     if os.environ.get("ALLTEXT"):
         tok = torch.zeros_like(tok)
     if os.environ.get("ALLIMG"):
