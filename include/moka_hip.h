@@ -57,8 +57,9 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      200            /* 0.2.0 */
+#define MOKA_VERSION      300            /* 0.3.0 */
 #define MOKA_MAX_MOD      3
+#define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
 #define MOKA_BF16         0
 
@@ -155,6 +156,41 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
                   void* dx_inout, int T, int d_in, int r, int M,
                   float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream);
+
+/* ---- grouped entry points (the decoder-layer shim) -------------------------------
+ * G (1..MOKA_MAX_GROUP) adapted projections that are fed by the SAME input x -- q/k/v of the attention
+ * block (AudioVisualText/models/modeling_llama.py:326-328, VisualText/modified_models/modeling_llama.py:251-253)
+ * and gate/up of the MLP (:222-224 / :152-159) -- and share the routing, r, M and the scalar
+ * hyper-parameters.  Semantics are exactly those of G calls of the single-projection entry points
+ * (which are implemented as G = 1 of these); what changes is the HBM traffic and the launch count:
+ *   moka_down_fwd_group   reads x once for all G down-projections,
+ *   moka_down_bwd_group   reads x once for all G dA and read-modify-writes dx once (dx += sum_g dh_g A_g),
+ *   the others            run the G independent problems in one launch (grid z).
+ * Pointer arguments become host arrays of G device pointers, in projection order; A / dA_acc hold G*M
+ * pointers (projection-major); d_out may differ per projection (GQA k/v); every projection of a group
+ * uses moka_ksplit(T, max_g d_out[g], r) slices for its g_part.  seeds: G dropout seeds (one mask per
+ * projection, as the reference draws one per adapter).  For r > 16 the shared-input kernels fall back to
+ * one launch per projection (same results). */
+int moka_down_fwd_group(const void* x, const void* const* A /*[G*M]*/, const uint8_t* tok_mod, float* const* part /*[G]*/,
+                        int T, int d_in, int r, int M, int G, float s_in, float dropout_p,
+                        const unsigned long long* seeds /*[G] or NULL when dropout_p == 0*/, int dtype, moka_stream_t stream);
+int moka_cross_fwd_group(const float* const* part, int ks, const moka_routing* rt, const float* s_out,
+                         const void* const* Bw, const int* d_out, const void* const* A /*[G*M]*/, int d_in,
+                         float* const* h, float* const* hp /*NULL or [G] (entries may be NULL)*/,
+                         void* const* hp_tok, void* const* hp_kmj, void* const* BwT, void* const* AT,
+                         int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+int moka_up_fwd_group(const void* const* hp_tok, const void* const* Bw, const uint8_t* tok_mod, void* const* y_inout,
+                      int T, int r, const int* d_out, int G, int dtype, moka_stream_t stream);
+int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const void* const* BwT, const uint8_t* tok_mod,
+                      const float* s_out, float* const* g_part, float* const* dB_acc,
+                      int T, int r, const int* d_out, int M, int G, int dtype, moka_stream_t stream);
+int moka_cross_bwd_group(const float* const* g_part, int ks, const float* const* h, const moka_routing* rt, float s_in,
+                         float* const* dh /*NULL or [G]*/, void* const* dh_tok, void* const* dh_kmj,
+                         void* const* ws /*G distinct workspaces*/, int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
+int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, const void* x, const void* const* AT,
+                        const uint8_t* tok_mod, float* const* dA_acc /*[G*M] or NULL*/, void* dx_inout /*or NULL*/,
+                        int T, int d_in, int r, int M, int G, float dropout_p, const unsigned long long* seeds,
+                        int dtype, moka_stream_t stream);
 
 /* The keep mask (1 byte per element of x, 1 = kept) the kernels derive from (dropout_p, seed): lets a
  * checker replay a dropout run exactly.  moka_dropout_scale returns 1/(1-p') (see moka_down_fwd). */

@@ -58,6 +58,29 @@ SYMBOLS = {
     # dh_tok, dh_kmj, x, AT, tok_mod, dA_acc[], dx, T, d_in, r, M, dropout_p, seed, dtype, stream
     "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p,
                               c_int, c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
+    # ---- grouped entry points (host arrays of G pointers)
+    # x, A[G*M], tok_mod, part[G], T, d_in, r, M, G, s_in, dropout_p, seeds[G], dtype, stream
+    "moka_down_fwd_group": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p),
+                                    c_int, c_int, c_int, c_int, c_int, c_float, c_float, POINTER(ctypes.c_ulonglong), c_int, c_void_p]),
+    # part[G], ks, rt, s_out[], Bw[G], d_out[G], A[G*M], d_in, h[G], hp[G], hp_tok[G], hp_kmj[G], BwT[G], AT[G], G, r, w, c, stream
+    "moka_cross_fwd_group": (c_int, [POINTER(c_void_p), c_int, POINTER(MokaRoutingStruct), POINTER(c_float),
+                                     POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_int,
+                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                     POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_float, c_float, c_void_p]),
+    # hp_tok[G], Bw[G], tok_mod, y[G], T, r, d_out[G], G, dtype, stream
+    "moka_up_fwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p),
+                                  c_int, c_int, POINTER(c_int), c_int, c_int, c_void_p]),
+    # gy[G], hp_kmj[G], BwT[G], tok_mod, s_out[], g_part[G], dB_acc[G], T, r, d_out[G], M, G, dtype, stream
+    "moka_up_bwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_float),
+                                  POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, POINTER(c_int), c_int, c_int, c_int, c_void_p]),
+    # g_part[G], ks, h[G], rt, s_in, dh[G], dh_tok[G], dh_kmj[G], ws[G], G, r, w, c, stream
+    "moka_cross_bwd_group": (c_int, [POINTER(c_void_p), c_int, POINTER(c_void_p), POINTER(MokaRoutingStruct), c_float,
+                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                     c_int, c_int, c_float, c_float, c_void_p]),
+    # dh_tok[G], dh_kmj[G], x, AT[G], tok_mod, dA_acc[G*M], dx, T, d_in, r, M, G, dropout_p, seeds[G], dtype, stream
+    "moka_down_bwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
+                                    POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    POINTER(ctypes.c_ulonglong), c_int, c_void_p]),
     # dropout_p, seed, T, d_in, keep_out, stream
     "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
     "moka_dropout_scale": (c_float, [c_float]),

@@ -148,14 +148,15 @@ static __device__ __forceinline__ float mod_scale(const float* s_mod, int m) {
 // R: reduce  in[T,C] -> part[KS,T,RP]      W_m is [r rows][C] row-major (A_m or BwT)
 // ------------------------------------------------------------------------------------------
 struct ReduceArgs {
-    const unsigned char* in;        // [T][C] bf16
-    const unsigned char* W[MOKA_MAX_MOD];
+    const unsigned char* in[MOKA_MAX_GROUP];                 // [z]  [T][C[z]] bf16   (shared-input group: in[0])
+    const unsigned char* W[MOKA_MAX_GROUP][MOKA_MAX_MOD];    // [g or z][m]
     const unsigned char* tok_mod;   // padded with MOKA_MOD_NONE
-    float* out;                     // [KS][T][RP]
+    float* out[MOKA_MAX_GROUP];     // [g or z]  [KS][T][RP]
     float s_mod[4];                 // scale per modality id
-    int T, C, r, M, ks;
-    int shared_w;                   // 1: W[0] serves every modality (gy.Bw); routing only picks the scale
-    DropArgs drop;                  // thr == 0: no dropout
+    int C[MOKA_MAX_GROUP];          // [z]
+    int T, r, M, ks;
+    int shared_w;                   // 1: W[.][0] serves every modality (gy.Bw); routing only picks the scale
+    DropArgs drop[MOKA_MAX_GROUP];  // [g]  thr == 0: no dropout
 };
 
 // One block per (32-token tile, K slice).  The NW waves of the block split the slice's K steps;
@@ -163,21 +164,27 @@ struct ReduceArgs {
 // batch i+1 (x and the weight fragments of the tile's first modality) is issued before batch i is
 // consumed, so the memory pipe never waits for the MFMA / weight round trip.  At the end the 16x16
 // partial tiles are summed through LDS.
-template <int RP, int NW, int U>
+//   G == 1: blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems (batched launch).
+//   G  > 1: G projections share the input (q/k/v, gate/up): every x fragment is loaded once and
+//           multiplied with the G weight sets (each with its own dropout mask).
+template <int RP, int NW, int U, int G>
 __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
+    const int z = (G == 1) ? blockIdx.z : 0;
+    const int C = a.C[z];
+    const unsigned char* in = a.in[z];
     const int t0 = blockIdx.x << 5;
-    const int nst = a.C >> 5;                             // K steps of 32 columns (C % 32 == 0)
+    const int nst = C >> 5;                               // K steps of 32 columns (C % 32 == 0)
     const int S0 = (int)(((long)blockIdx.y * nst) / a.ks), S1 = (int)(((long)(blockIdx.y + 1) * nst) / a.ks);
     const int s_begin = S0 + (int)(((long)wave * (S1 - S0)) / NW), s_end = S0 + (int)(((long)(wave + 1) * (S1 - S0)) / NW);
 
     const unsigned char* xrow[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
-        xrow[st] = a.in + ((size_t)min(t0 + 16 * st + i, a.T - 1) * a.C + 8 * g) * 2;
+        xrow[st] = in + ((size_t)min(t0 + 16 * st + i, a.T - 1) * C + 8 * g) * 2;
     unsigned pres[2] = {1u, 1u};                          // bit m: modality m present in sub-tile (block uniform)
     auto issue_x = [&](bf16x8 (&xb)[U][2], int s) {
 #pragma unroll
@@ -189,7 +196,8 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
             }
         }
     };
-    auto issue_w1 = [&](bf16x8 (&wb)[U][NT], int s, int m) {
+    auto issue_w1 = [&](bf16x8 (&wb)[U][NT], int s, int gi, int m) {
+        const unsigned char* W = a.W[G == 1 ? z : gi][m];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (s + u < s_end) {
@@ -197,23 +205,25 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
                 for (int nt = 0; nt < NT; ++nt) {
                     // rank rows >= r do not exist: clamp the row, its products are zeroed at the end
                     const int krow = min(nt * 16 + i, a.r - 1);
-                    wb[u][nt] = *(const bf16x8*)(a.W[m] + ((size_t)krow * a.C + 8 * g) * 2 + (size_t)(s + u) * 64);
+                    wb[u][nt] = *(const bf16x8*)(W + ((size_t)krow * C + 8 * g) * 2 + (size_t)(s + u) * 64);
                 }
             }
         }
     };
-
     // Weight fragments of the tile's first modality travel with the x batch; the other modalities of a
     // tile that straddles a span boundary are fetched on demand.  (Measured: prefetching a second set
     // unconditionally costs 7 % on single-modality tiles -- the weight fragments are 1 KB of L2 traffic
     // per 2 KB of x -- and conditionally issued loads make the vmcnt bookkeeping conservative, so the
     // ~3 % boundary tiles run ~14 % longer either way.)
     int mfirst = 0;
-    auto issue_w = [&](bf16x8 (&wb)[U][NT], int s) { issue_w1(wb, s, mfirst); };
+    auto issue_w = [&](bf16x8 (&wb)[G][U][NT], int s) {
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) issue_w1(wb[gi], s, gi, mfirst);
+    };
 
     // The x stream does not depend on the routing: issue the first batch right away, the tok_mod
     // bytes (which only select the weight rows / the skip) arrive underneath it.
-    bf16x8 xA[U][2], xB[U][2], wA[U][NT], wB[U][NT];
+    bf16x8 xA[U][2], xB[U][2], wA[G][U][NT], wB[G][U][NT];
     issue_x(xA, s_begin);
     int mrow2[2];
     unsigned mods4[2];                                    // modalities of my 4 result rows
@@ -235,41 +245,39 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
     mfirst = __builtin_ctz(pany);
     issue_w(wA, s_begin);
 
-    f32x4 acc[2][MOKA_MAX_MOD][NT];
+    f32x4 acc[G][2][MOKA_MAX_MOD][NT];
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[st][m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MOKA_MAX_MOD; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[gi][st][m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto consume = [&](bf16x8 (&xb)[U][2], bf16x8 (&wb)[U][NT], int s) {
-        if (a.drop.thr) {                                     // wave uniform
+    auto consume = [&](bf16x8 (&xb)[U][2], bf16x8 (&wb)[G][U][NT], int s) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (s + u < s_end) {
+        for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
-                        if (pres[st]) xb[u][st] = drop_apply(xb[u][st], drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((s + u) * 4 + g)));
-                    }
-                }
-            }
-        }
+            for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                if (!(pany & (1u << m))) continue;
+                bf16x8 wx[U][NT];
+                if (m != mfirst) issue_w1(wx, s, gi, m);          // span boundary inside the tile (rare)
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-            if (!(pany & (1u << m))) continue;
-            bf16x8 wx[U][NT];
-            if (m != mfirst) issue_w1(wx, s, m);               // span boundary inside the tile (rare)
+                for (int u = 0; u < U; ++u) {
+                    if (s + u < s_end) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (s + u < s_end) {
+                        for (int st = 0; st < 2; ++st) {
+                            if (pres[st] & (1u << m)) {
+                                bf16x8 xg = xb[u][st];
+                                if (a.drop[gi].thr) {             // wave uniform; every projection has its own mask
+                                    const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
+                                    xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(C >> 3) + (unsigned)((s + u) * 4 + g)));
+                                }
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        if (pres[st] & (1u << m)) {
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[st][m][nt] = MFMA16(xb[u][st], (m == mfirst) ? wb[u][nt] : wx[u][nt], acc[st][m][nt]);
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[gi][st][m][nt] = MFMA16(xg, (m == mfirst) ? wb[gi][u][nt] : wx[u][nt], acc[gi][st][m][nt]);
+                            }
                         }
                     }
                 }
@@ -288,35 +296,41 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
     }
 
     // select per row, scale, and reduce the NW partial tiles through LDS
-    float* red = (float*)smem;                            // [NW][2][NT][16 rows][16 cols]
+    constexpr int REDSZ = NW * 2 * NT * 256;
+    float* red = (float*)smem;                            // [G][NW][2][NT][16 rows][16 cols]
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int mr = (mods4[st] >> (8 * reg)) & 255;
-                float v = 0.f;
-                if (a.shared_w) {
-                    v = acc[st][0][nt][reg] * mod_scale(a.s_mod, mr);
-                } else {
-                    if (mr == 0) v = acc[st][0][nt][reg] * a.s_mod[0];
-                    else if (mr == 1) v = acc[st][1][nt][reg] * a.s_mod[1];
-                    else if (mr == 2) v = acc[st][2][nt][reg] * a.s_mod[2];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int mr = (mods4[st] >> (8 * reg)) & 255;
+                    float v = 0.f;
+                    if (a.shared_w) {
+                        v = acc[gi][st][0][nt][reg] * mod_scale(a.s_mod, mr);
+                    } else {
+                        if (mr == 0) v = acc[gi][st][0][nt][reg] * a.s_mod[0];
+                        else if (mr == 1) v = acc[gi][st][1][nt][reg] * a.s_mod[1];
+                        else if (mr == 2) v = acc[gi][st][2][nt][reg] * a.s_mod[2];
+                    }
+                    if (nt * 16 + i >= a.r) v = 0.f;      // padded rank columns
+                    red[gi * REDSZ + (((wave * 2 + st) * NT + nt) << 8) + ((4 * g + reg) << 4) + i] = v;
                 }
-                if (nt * 16 + i >= a.r) v = 0.f;          // padded rank columns
-                red[(((wave * 2 + st) * NT + nt) << 8) + ((4 * g + reg) << 4) + i] = v;
-            }
     __syncthreads();
-    float* outp = a.out + (size_t)blockIdx.y * a.T * RP;
-    for (int e = tid; e < 32 * RP; e += NW * 64) {
-        const int row = e / RP, k = e % RP;
-        const int st = row >> 4, r16 = row & 15, nt = k >> 4, kk = k & 15;
-        float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) sum += red[(((w * 2 + st) * NT + nt) << 8) + (r16 << 4) + kk];
-        const int t = t0 + row;
-        if (t < a.T) outp[(size_t)t * RP + k] = sum;
+    for (int gi = 0; gi < G; ++gi) {
+        float* outp = a.out[G == 1 ? z : gi] + (size_t)blockIdx.y * a.T * RP;
+        for (int e = tid; e < 32 * RP; e += NW * 64) {
+            const int row = e / RP, k = e % RP;
+            const int st = row >> 4, r16 = row & 15, nt = k >> 4, kk = k & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += red[gi * REDSZ + (((w * 2 + st) * NT + nt) << 8) + (r16 << 4) + kk];
+            const int t = t0 + row;
+            if (t < a.T) outp[(size_t)t * RP + k] = sum;
+        }
     }
 }
 
@@ -345,6 +359,8 @@ struct CrossArgs {
     int ks, B, S, T, Tp, Lk_max, Lkp, r, C, M, RB;
     float w, c;
 };
+// blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems on the same routing (batched launch)
+struct CrossBatch { CrossArgs z[MOKA_MAX_GROUP]; };
 
 template <int RP>
 static __device__ __forceinline__ void write_packs_fwd(const CrossArgs& a, int t, int k, float v_scaled) {
@@ -377,7 +393,8 @@ static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t
 // dependent batch (the key rows), then LDS-only work: one wave per query row, one lane per key.
 // Every block also transposes a slice of Bw into BwT (weights do not change until the backward).
 template <int RP, int KCH>
-__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cross_fwd_kernel(const CrossArgs a) {
+__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cross_fwd_kernel(const CrossBatch ab) {
+    const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = RP + 1;
     float* Hs = (float*)smem;                  // [32][KP]  h rows
@@ -529,7 +546,8 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
 // partial slot.  Rows that are themselves key rows are finished by part b (their dq, if any, joins
 // their dK slot).
 template <int RP, int KCH>
-__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cross_bwd_kernel(const CrossArgs a) {
+__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cross_bwd_kernel(const CrossBatch ab) {
+    const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = RP + 1;
     float* Gs = (float*)smem;                  // [32][KP]  g rows
@@ -684,7 +702,8 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
 // Backward, part b: the key rows  dh[key_j] = g[key_j] + sum over the sample's blocks of their dK partial.
 // Deterministic (fixed summation order), no atomics, no scratch that has to be zero on entry.
 template <int RP>
-__global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossArgs a, int nblk) {
+__global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossBatch ab, int nblk) {
+    const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* list = (int*)smem;                           // [nblk] indices of the blocks that wrote a partial
     __shared__ int s_n;
@@ -732,6 +751,9 @@ struct ExpandArgs {
     int T, C, r, M;
     DropArgs drop;                  // dx only: the adapter term passes through the dropout mask of x
 };
+// W_CK (y += hp.Bw^T): blockIdx.z selects one of the batched problems.
+// !W_CK (dx += sum_g dh_g.A_g): the G entries share tok_mod / out / T / C and differ in pack, W, drop.
+struct ExpandBatch { ExpandArgs z[MOKA_MAX_GROUP]; };
 
 // D^T orientation: MFMA rows = output columns, MFMA columns = tokens, so every lane ends up with 8
 // consecutive bf16 of one token row (16 B) and a wave touches 16 rows x 64 B per instruction (the
@@ -741,11 +763,14 @@ struct ExpandArgs {
 // ([C][r]: Bw itself, or the AT shadow of A_m written by moka_cross_fwd), so a fragment is one 16-byte
 // load: the fragments of weight set 0 (the only one for y; the text adapter for dx) stay in registers
 // for the whole block, other modalities' fragments are fetched from L2 for the (few) tiles that need them.
-template <int RP, int NQ, bool W_CK>
-__global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
+// G > 1 (dx only): G projections read the same x (q/k/v, gate/up), so their input gradients land in the
+// same dx: one read-modify-write pass adds all G terms (each through its own dropout mask).
+template <int RP, int NQ, bool W_CK, int G>
+__global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) {
     constexpr int KH = (RP + 31) / 32;                 // 32-wide rank blocks per hi (or lo) plane
     constexpr int WC = NQ * 32;                        // columns per wave
     constexpr int CW = 4 * WC;                         // columns per block
+    const ExpandArgs& a = ab.z[G == 1 ? blockIdx.z : 0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int c_wave = blockIdx.x * CW + wave * WC;
@@ -767,16 +792,19 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
         }
         return v;
     };
-    bf16x8 wf0[NQ][2][KH];
+    bf16x8 wf0[G][NQ][2][KH];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int kh = 0; kh < KH; ++kh) wf0[q][p][kh] = load_frag(a.W[0], q, p, kh);
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) wf0[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[0], q, p, kh);
 
     const int ntiles = (a.T + 15) >> 4;
     const size_t prow = (size_t)(2 * RP) * 2;                     // pack row bytes
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
         const int t = (tile << 4) + i;                            // operand / result lanes: token = lane & 15
         const bool valid = t < a.T;
@@ -785,16 +813,19 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
         const bool same = __all(mrow == m0);
         if (same && m0 == MOKA_MOD_NONE) continue;
         // B operand: my token's pack row.  RP == 16: K = 32 is [hi(16) | lo(16)] = elements 8g..8g+7 of the row.
-        bf16x8 bh[KH], bl[KH];
-        const unsigned char* prp = (const unsigned char*)a.pack + (size_t)min(t, a.T - 1) * prow;
+        bf16x8 bh[G][KH], bl[G][KH];
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh) {
-            if (RP == 16) {
-                bh[kh] = *(const bf16x8*)(prp + 16 * g);
-                bl[kh] = bh[kh];
-            } else {
-                bh[kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
-                bl[kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+        for (int gi = 0; gi < G; ++gi) {
+            const unsigned char* prp = (const unsigned char*)ab.z[G == 1 ? blockIdx.z : gi].pack + (size_t)min(t, a.T - 1) * prow;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                if (RP == 16) {
+                    bh[gi][kh] = *(const bf16x8*)(prp + 16 * g);
+                    bl[gi][kh] = bh[gi][kh];
+                } else {
+                    bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+                    bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+                }
             }
         }
         unsigned char* orow = a.out + ((size_t)min(t, a.T - 1) * a.C + c_wave + 8 * g) * 2;
@@ -803,57 +834,81 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandArgs a) {
         for (int q = 0; q < NQ; ++q)
             if (c_wave + 32 * q < a.C) o[q] = *(const bf16x8*)(orow + 64 * q);
 
-        f32x4 d[NQ][2];
+        float sum[NQ][8];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) d[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (W_CK || (same && m0 == 0)) {
-            // shared Bw (the modality scale is in the pack) / all-text tile: resident fragments
+            for (int e = 0; e < 8; ++e) sum[q][e] = 0.f;
+
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const ExpandArgs& ag = ab.z[G == 1 ? blockIdx.z : gi];
+            f32x4 d[NQ][2];
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < 2; ++p) d[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (W_CK || (same && m0 == 0)) {
+                // shared Bw (the modality scale is in the pack) / all-text tile: resident fragments
 #pragma unroll
-                    for (int kh = 0; kh < KH; ++kh) {
-                        d[q][p] = MFMA16(wf0[q][p][kh], bh[kh], d[q][p]);
-                        if (RP != 16) d[q][p] = MFMA16(wf0[q][p][kh], bl[kh], d[q][p]);
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int kh = 0; kh < KH; ++kh) {
+                            d[q][p] = MFMA16(wf0[gi][q][p][kh], bh[gi][kh], d[q][p]);
+                            if (RP != 16) d[q][p] = MFMA16(wf0[gi][q][p][kh], bl[gi][kh], d[q][p]);
+                        }
+            } else {
+                // a non-text or mixed tile of the dx pass: one chain per modality present, tokens of the other
+                // modalities masked out of the B operand; non-text fragments come from the L2-resident shadow
+#pragma unroll
+                for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                    if (m < a.M && __any(mrow == m)) {
+                        const bool mine = mrow == m;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int kh = 0; kh < KH; ++kh) {
+                                    const bf16x8 wv = (m == 0) ? wf0[gi][q][p][kh] : load_frag(ag.W[m], q, p, kh);
+                                    d[q][p] = MFMA16(wv, mine ? bh[gi][kh] : z8, d[q][p]);
+                                    if (RP != 16) d[q][p] = MFMA16(wv, mine ? bl[gi][kh] : z8, d[q][p]);
+                                }
                     }
-        } else {
-            // a non-text or mixed tile of the dx pass: one chain per modality present, tokens of the other
-            // modalities masked out of the B operand; non-text fragments come from the L2-resident shadow
+                }
+            }
 #pragma unroll
-            for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-                if (m < a.M && __any(mrow == m)) {
-                    const bool mine = mrow == m;
+            for (int q = 0; q < NQ; ++q) {
+                if (c_wave + 32 * q >= a.C) continue;
+                KeepMask keep = {{~0u, ~0u, ~0u, ~0u}};
+                float dsc = 1.f;
+                if (ag.drop.thr) {
+                    keep = drop_keep8(ag.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
+                    dsc = ag.drop.inv_keep;
+                }
+                if constexpr (G == 1) {
+                    bf16x8 res;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
+                    for (int e = 0; e < 8; ++e)
+                        res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (drop_kept(keep, e) ? d[q][e >> 2][e & 3] * dsc : 0.f));
+                    if (valid) *(bf16x8*)(orow + 64 * q) = res;
+                } else {
 #pragma unroll
-                        for (int p = 0; p < 2; ++p)
-#pragma unroll
-                            for (int kh = 0; kh < KH; ++kh) {
-                                const bf16x8 wv = (m == 0) ? wf0[q][p][kh] : load_frag(a.W[m], q, p, kh);
-                                d[q][p] = MFMA16(wv, mine ? bh[kh] : z8, d[q][p]);
-                                if (RP != 16) d[q][p] = MFMA16(wv, mine ? bl[kh] : z8, d[q][p]);
-                            }
+                    for (int e = 0; e < 8; ++e) sum[q][e] += drop_kept(keep, e) ? d[q][e >> 2][e & 3] * dsc : 0.f;
                 }
             }
         }
+        if constexpr (G > 1) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (c_wave + 32 * q >= a.C) continue;
-            KeepMask keep = {{~0u, ~0u, ~0u, ~0u}};
-            float dsc = 1.f;
-            if (a.drop.thr) {
-                keep = drop_keep8(a.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
-                dsc = a.drop.inv_keep;
+            for (int q = 0; q < NQ; ++q) {
+                if (c_wave + 32 * q >= a.C) continue;
+                bf16x8 res;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + sum[q][e]);
+                if (valid) *(bf16x8*)(orow + 64 * q) = res;
             }
-            bf16x8 res;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (drop_kept(keep, e) ? d[q][e >> 2][e & 3] * dsc : 0.f));
-            if (valid) *(bf16x8*)(orow + 64 * q) = res;
         }
     }
 }
@@ -870,6 +925,9 @@ struct WgradArgs {
     int per_mod;                    // 1: one pack plane per modality (dA); 0: single (dB)
     DropArgs drop;                  // dA only: x passes through its dropout mask
 };
+// OUT_CK (dB): blockIdx.z selects one of the batched problems.
+// !OUT_CK (dA) with G > 1: the G entries share `in` (= x) and the routing; wave set g of a block works on entry g.
+struct WgradBatch { WgradArgs z[MOKA_MAX_GROUP]; };
 
 // Block = NW waves owning NSB*64 columns for a long run of tokens.  Each wave walks over a contiguous
 // run of 32-token groups with a 2-deep software pipeline: tok_mod of group i+2 and the
@@ -880,8 +938,12 @@ struct WgradArgs {
 // One accumulator set per modality, so span boundaries cost nothing but an extra MFMA chain.
 // At the end the NW waves' tiles are summed through private LDS regions (plain stores), one
 // modality at a time, and leave the chip as one coalesced fp32 atomic per (column, rank).
-template <int RP, int NSB, int NW, bool OUT_CK>
-__global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) {
+// G > 1 (dA of projections that read the same x): the block has G sets of NW waves; set g runs the
+// same token runs against the packs / accumulators of projection g.  The G waves of a run request the
+// same x lines within a short time, so the copies are served by L1 / L2 (hit-on-miss) and HBM sees
+// each line once; per-wave registers and LDS stay those of the single-projection kernel.
+template <int RP, int NSB, int NW, bool OUT_CK, int G>
+__global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatch ab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
     constexpr int NM = OUT_CK ? 1 : MOKA_MAX_MOD;   // dB: one plane; dA: one plane per modality
@@ -889,12 +951,16 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
     constexpr int CCB = NSB * 64;                   // columns per block
     constexpr int PITCH = 64 * 2 + 32;              // bytes per LDS row; odd multiple of 32
     constexpr int REGION = 32 * PITCH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int gi = (G == 1) ? 0 : __builtin_amdgcn_readfirstlane(wave_all / NW);   // projection of this wave set
+    const int wave = (G == 1) ? wave_all : wave_all - gi * NW;                        // token-run index inside the block
+    const WgradArgs& a = ab.z[G == 1 ? blockIdx.z : gi];
     const int i = lane & 15, g = lane >> 4;
     const int c_begin = blockIdx.x * CCB;
-    unsigned char* my = smem + wave * REGION;
-    float* red = (float*)(smem + NW * REGION);      // [NW][CCB][RP]  per-wave partial sums
-    unsigned* touched = (unsigned*)(red + (size_t)NW * CCB * RP);
+    if (c_begin >= a.C) return;                     // batched problems of different width (block uniform)
+    unsigned char* my = smem + wave_all * REGION;
+    float* red = (float*)(smem + NW * G * REGION);  // [NW*G][CCB][RP]  per-wave partial sums
+    unsigned* touched = (unsigned*)(red + (size_t)NW * G * CCB * RP);
     const int ngroups = a.Tp >> 5;
     const int grp_begin = blockIdx.y * a.groups_per_block;
     const int grp_end = min(ngroups, grp_begin + a.groups_per_block);
@@ -1013,7 +1079,7 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
     if (lane == 0 && ever) atomicOr(touched, ever);
     __syncthreads();
     const unsigned any = *touched;
-    float* mine = red + (size_t)wave * CCB * RP;
+    float* mine = red + (size_t)wave_all * CCB * RP;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         if (!(any & (1u << m))) continue;                         // block uniform
@@ -1028,15 +1094,17 @@ __global__ void __launch_bounds__(NW * 64) moka_wgrad_kernel(const WgradArgs a) 
                     for (int reg = 0; reg < 4; ++reg)
                         mine[(sb * 64 + ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = acc[m][sb][ct][nt][reg];
         __syncthreads();
-        for (int e = tid; e < CCB * RP; e += NW * 64) {
+        for (int e2 = tid; e2 < G * CCB * RP; e2 += NW * G * 64) {
             // consecutive threads -> consecutive addresses of the destination ([C][r] for dB, [r][C] for dA)
+            const int ge = e2 / (CCB * RP), e = e2 - ge * (CCB * RP);
+            const WgradArgs& ag = ab.z[G == 1 ? blockIdx.z : ge];
             const int k = OUT_CK ? (e % RP) : (e / CCB), cl = OUT_CK ? (e / RP) : (e % CCB);
             const int c = c_begin + cl;
             if (c >= a.C || k >= a.r) continue;
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) sum += red[((size_t)w * CCB + cl) * RP + k];
-            atomicAdd(a.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), a.drop.thr ? sum * a.drop.inv_keep : sum);
+            for (int w = 0; w < NW; ++w) sum += red[((size_t)(ge * NW + w) * CCB + cl) * RP + k];
+            atomicAdd(ag.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), ag.drop.thr ? sum * ag.drop.inv_keep : sum);
         }
         __syncthreads();
     }
@@ -1147,113 +1215,138 @@ static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     return MOKA_OK;
 }
 
-template <int RP, int NW, int U>
-static void launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)NW * 2 * (RP / 16) * 256 * 4;
-    dim3 grid((a.T + 31) / 32, a.ks), block(NW * 64);
-    ensure_lds((const void*)moka_reduce_kernel<RP, NW, U>, lds);
-    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U>), grid, block, lds, st, a);
+template <int RP, int NW, int U, int G>
+static void launch_reduce_t(const ReduceArgs& a, int nz, hipStream_t st) {
+    const size_t lds = (size_t)G * NW * 2 * (RP / 16) * 256 * 4;
+    dim3 grid((a.T + 31) / 32, a.ks, nz), block(NW * 64);
+    ensure_lds((const void*)moka_reduce_kernel<RP, NW, U, G>, lds);
+    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U, G>), grid, block, lds, st, a);
 }
 
-static int launch_reduce(const ReduceArgs& a, int RP, hipStream_t st) {
+// G > 1: shared-input group (RP == 16 only, see can_group); G == 1: nz batched problems
+static int launch_reduce(const ReduceArgs& a, int RP, int G, int nz, hipStream_t st) {
     if (RP == 16) {
         const int nw = g_tune_reduce_nw == 8 ? 8 : 4, u = g_tune_reduce_u == 4 ? 4 : 2;
-        if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4>(a, st); else launch_reduce_t<16, 4, 2>(a, st); }
-        else { if (u == 4) launch_reduce_t<16, 8, 4>(a, st); else launch_reduce_t<16, 8, 2>(a, st); }
+        if (G == 3) launch_reduce_t<16, 4, 2, 3>(a, 1, st);
+        else if (G == 2) launch_reduce_t<16, 4, 2, 2>(a, 1, st);
+        else if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4, 1>(a, nz, st); else launch_reduce_t<16, 4, 2, 1>(a, nz, st); }
+        else { if (u == 4) launch_reduce_t<16, 8, 4, 1>(a, nz, st); else launch_reduce_t<16, 8, 2, 1>(a, nz, st); }
     }
-    else if (RP == 32) launch_reduce_t<32, 8, 2>(a, st);
-    else launch_reduce_t<64, 8, 1>(a, st);
+    else if (RP == 32) launch_reduce_t<32, 8, 2, 1>(a, nz, st);
+    else launch_reduce_t<64, 8, 1, 1>(a, nz, st);
     return check_launch("moka_reduce_kernel");
 }
 
 template <int RP, int KCH>
-static void launch_cross_t(bool bwd, const CrossArgs& a, hipStream_t st) {
-    dim3 grid(a.B, (a.S + a.RB - 1) / a.RB), block(512);
+static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
+    const CrossArgs& a = ab.z[0];
+    dim3 grid(a.B, (a.S + a.RB - 1) / a.RB, nz), block(512);
     if (!bwd) {
         const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
         ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH>, lds);
-        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH>), grid, block, lds, st, a);
+        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH>), grid, block, lds, st, ab);
     } else {
         const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
         ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH>, lds);
-        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH>), grid, block, lds, st, a);
-        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16), dim3(256), (size_t)grid.y * 4, st, a, (int)grid.y);
+        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH>), grid, block, lds, st, ab);
+        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16, nz), dim3(256), (size_t)grid.y * 4, st, ab, (int)grid.y);
     }
 }
 
-static int launch_cross(bool bwd, CrossArgs& a, const moka_routing* rt, int r, hipStream_t st) {
+// fills the routing fields of every problem and launches the batch
+static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt, int r, hipStream_t st) {
     const char* fn = bwd ? "moka_cross_bwd" : "moka_cross_fwd";
     const int RP = rank_pad(r);
     if (RP < 0) return fail(MOKA_EINVAL, "%s: rank %d not in 1..64", fn, r);
     if (!rt) return fail(MOKA_EINVAL, "%s: null routing", fn);
-    if (a.ks < 1 || rt->B < 1 || rt->S < 1) return fail(MOKA_EINVAL, "%s: ks=%d B=%d S=%d", fn, a.ks, rt->B, rt->S);
+    if (rt->B < 1 || rt->S < 1) return fail(MOKA_EINVAL, "%s: B=%d S=%d", fn, rt->B, rt->S);
     if (!rt->tok_mod || !rt->klen || !rt->ktok || !rt->kslot) return fail(MOKA_EINVAL, "%s: null routing pointer", fn);
     const int Lk = rt->Lk_max;
     if (Lk < 0 || Lk > 512) return fail(MOKA_EINVAL, "%s: Lk_max=%d not in 0..512", fn, Lk);
     const int kch = Lk <= 64 ? 1 : (Lk <= 128 ? 2 : (Lk <= 256 ? 4 : 8));
     if (kch * RP > 128) return fail(MOKA_EINVAL, "%s: Lk_max=%d with rank pad %d exceeds the register budget", fn, Lk, RP);
-    a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot;
-    a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
-    a.r = r; a.M = rt->M;
-    a.RB = cross_rows_per_block();
-    if ((size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 > 150 * 1024) return fail(MOKA_EINVAL, "%s: key block does not fit LDS", fn);
+    for (int z = 0; z < nz; ++z) {
+        CrossArgs& a = ab.z[z];
+        if (a.ks < 1) return fail(MOKA_EINVAL, "%s: ks=%d", fn, a.ks);
+        a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot;
+        a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
+        a.r = r; a.M = rt->M;
+        a.RB = cross_rows_per_block();
+    }
+    if ((size_t)(96 + 2 * ab.z[0].Lkp) * (RP + 1) * 4 > 150 * 1024) return fail(MOKA_EINVAL, "%s: key block does not fit LDS", fn);
     if (RP == 16) {
-        if (kch == 1) launch_cross_t<16, 1>(bwd, a, st); else if (kch == 2) launch_cross_t<16, 2>(bwd, a, st);
-        else if (kch == 4) launch_cross_t<16, 4>(bwd, a, st); else launch_cross_t<16, 8>(bwd, a, st);
+        if (kch == 1) launch_cross_t<16, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<16, 2>(bwd, ab, nz, st);
+        else if (kch == 4) launch_cross_t<16, 4>(bwd, ab, nz, st); else launch_cross_t<16, 8>(bwd, ab, nz, st);
     } else if (RP == 32) {
-        if (kch == 1) launch_cross_t<32, 1>(bwd, a, st); else if (kch == 2) launch_cross_t<32, 2>(bwd, a, st);
-        else launch_cross_t<32, 4>(bwd, a, st);
+        if (kch == 1) launch_cross_t<32, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<32, 2>(bwd, ab, nz, st);
+        else launch_cross_t<32, 4>(bwd, ab, nz, st);
     } else {
-        if (kch == 1) launch_cross_t<64, 1>(bwd, a, st); else launch_cross_t<64, 2>(bwd, a, st);
+        if (kch == 1) launch_cross_t<64, 1>(bwd, ab, nz, st); else launch_cross_t<64, 2>(bwd, ab, nz, st);
     }
     return check_launch(fn);
 }
 
-template <int RP, int NQ, bool W_CK>
-static void launch_expand_t(const ExpandArgs& a, hipStream_t st) {
+template <int RP, int NQ, bool W_CK, int G>
+static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     constexpr int CW = 4 * NQ * 32;
-    const int nc = (a.C + CW - 1) / CW;
-    const int ntiles = (a.T + 15) / 16;
-    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (a.C > 8192 ? 8 : 4);
-    int gy = (bpc * num_cu() + nc - 1) / nc;           // blocks per CU, each walking several token tiles
+    int Cmax = 0;
+    for (int z = 0; z < (G == 1 ? nz : 1); ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
+    const int nc = (Cmax + CW - 1) / CW;
+    const int ntiles = (ab.z[0].T + 15) / 16;
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (Cmax > 8192 ? 8 : 4);
+    int gy = (bpc * num_cu() + nc * nz - 1) / (nc * nz);   // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK>), dim3(nc, gy), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, ab);
 }
 
+// W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
 template <bool W_CK>
-static int launch_expand(const ExpandArgs& a, int RP, hipStream_t st) {
-    if (RP == 16) launch_expand_t<16, 4, W_CK>(a, st);
-    else if (RP == 32) launch_expand_t<32, 2, W_CK>(a, st);
-    else launch_expand_t<64, 1, W_CK>(a, st);
+static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) {
+    if (W_CK || nz == 1) {
+        if (RP == 16) launch_expand_t<16, 4, W_CK, 1>(ab, nz, st);
+        else if (RP == 32) launch_expand_t<32, 2, W_CK, 1>(ab, nz, st);
+        else launch_expand_t<64, 1, W_CK, 1>(ab, nz, st);
+    } else {                                             // can_group(): RP == 16
+        if (nz == 2) launch_expand_t<16, 2, false, 2>(ab, 1, st);
+        else launch_expand_t<16, 2, false, 3>(ab, 1, st);
+    }
     return check_launch("moka_expand_kernel");
 }
 
-template <int RP, int NSB, int NW, bool OUT_CK>
-static void launch_wgrad_t(WgradArgs& a, hipStream_t st) {
+template <int RP, int NSB, int NW, bool OUT_CK, int G>
+static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     constexpr int CCB = NSB * 64;
-    constexpr int NM = OUT_CK ? 1 : MOKA_MAX_MOD;
-    const int nc = (a.C + CCB - 1) / CCB;
-    const int ngroups = a.Tp / 32;
+    int Cmax = 0;
+    for (int z = 0; z < nz; ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
+    const int nc = (Cmax + CCB - 1) / CCB;
+    const int ngroups = ab.z[0].Tp / 32;
     const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : 1;
-    int nb = (bpc * num_cu() + nc - 1) / nc;
+    const int nzg = (G == 1) ? nz : 1;                  // grid z
+    int nb = (bpc * num_cu() + nc * nzg - 1) / (nc * nzg);
     if (nb > (ngroups + NW - 1) / NW) nb = (ngroups + NW - 1) / NW;
     if (nb < 1) nb = 1;
-    a.groups_per_block = (ngroups + nb - 1) / nb;
-    nb = (ngroups + a.groups_per_block - 1) / a.groups_per_block;
-    (void)sizeof(char[NM]);
-    const size_t lds = (size_t)NW * 32 * 160 + (size_t)NW * CCB * RP * 4 + NW * 4 + 16;
-    ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK>, lds);
-    hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK>), dim3(nc, nb), dim3(NW * 64), lds, st, a);
+    const int gpb = (ngroups + nb - 1) / nb;
+    for (int z = 0; z < nz; ++z) ab.z[z].groups_per_block = gpb;
+    nb = (ngroups + gpb - 1) / gpb;
+    const size_t lds = (size_t)NW * G * 32 * 160 + (size_t)NW * G * CCB * RP * 4 + 64;
+    ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>, lds);
+    hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
 }
 
+// OUT_CK: nz batched problems.  !OUT_CK: nz projections sharing x (one kernel when can_group()).
 template <bool OUT_CK>
-static int launch_wgrad(WgradArgs& a, int RP, hipStream_t st) {
-    if (RP == 16) {
-        if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK>(a, st);
-        else launch_wgrad_t<16, 1, 8, OUT_CK>(a, st);
-    } else if (RP == 32) launch_wgrad_t<32, 1, 8, OUT_CK>(a, st);
-    else launch_wgrad_t<64, 1, 4, OUT_CK>(a, st);
+static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
+    if (OUT_CK || nz == 1) {
+        if (RP == 16) {
+            if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK, 1>(ab, nz, st);
+            else launch_wgrad_t<16, 1, 8, OUT_CK, 1>(ab, nz, st);
+        } else if (RP == 32) launch_wgrad_t<32, 1, 8, OUT_CK, 1>(ab, nz, st);
+        else launch_wgrad_t<64, 1, 4, OUT_CK, 1>(ab, nz, st);
+    } else {                                             // can_group(): RP == 16
+        if (nz == 2) launch_wgrad_t<16, 1, 4, false, 2>(ab, nz, st);
+        else launch_wgrad_t<16, 1, 4, false, 3>(ab, nz, st);
+    }
     return check_launch("moka_wgrad_kernel");
 }
 
@@ -1293,53 +1386,106 @@ int moka_ksplit(int T, int C, int r) {
     return reduce_ks(T, C);
 }
 
+// shared-input groups run as ONE kernel for r <= 16; wider ranks fall back to one launch per projection
+static bool can_group(int r, int G) { return G > 1 && rank_pad(r) == 16; }
+
+int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_mod, float* const* part,
+                        int T, int d_in, int r, int M, int G, float s_in, float dropout_p, const unsigned long long* seeds,
+                        int dtype, moka_stream_t stream) {
+    int rc = check_common("moka_down_fwd", T, d_in, r, M, dtype);
+    if (rc) return rc;
+    if (G < 1 || G > MOKA_MAX_GROUP) return fail(MOKA_EINVAL, "moka_down_fwd: G=%d not in 1..%d", G, MOKA_MAX_GROUP);
+    if (!x || !A || !tok_mod || !part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
+    if (dropout_p != 0.f && !seeds) return fail(MOKA_EINVAL, "moka_down_fwd: dropout without seeds");
+    ReduceArgs a;
+    memset(&a, 0, sizeof(a));
+    float inv_keep = 1.f;
+    for (int g = 0; g < G; ++g) {
+        rc = make_drop("moka_down_fwd", dropout_p, seeds ? seeds[g] : 0ull, &a.drop[g]);
+        if (rc) return rc;
+        inv_keep = a.drop[g].inv_keep;
+        if (!part[g]) return fail(MOKA_EINVAL, "moka_down_fwd: part[%d] is null", g);
+        for (int m = 0; m < M; ++m)
+            if (!A[g * M + m]) return fail(MOKA_EINVAL, "moka_down_fwd: A[%d] is null", g * M + m);
+    }
+    if ((unsigned long long)T * (unsigned long long)(d_in >> 3) > 0xffffffffull && a.drop[0].thr)
+        return fail(MOKA_EINVAL, "moka_down_fwd: T * d_in too large for the dropout counter");
+    for (int m = 0; m < M; ++m) a.s_mod[m] = s_in * inv_keep;
+    a.tok_mod = tok_mod; a.T = T; a.r = r; a.M = M; a.ks = reduce_ks(T, d_in);
+    a.in[0] = (const unsigned char*)x; a.C[0] = d_in;
+    const int RP = rank_pad(r);
+    if (G == 1 || can_group(r, G)) {
+        for (int g = 0; g < G; ++g) {
+            a.out[g] = part[g];
+            for (int m = 0; m < M; ++m) a.W[g][m] = (const unsigned char*)A[g * M + m];
+        }
+        return launch_reduce(a, RP, G, 1, (hipStream_t)stream);
+    }
+    for (int g = 0; g < G; ++g) {                      // one launch per projection
+        ReduceArgs b = a;
+        b.out[0] = part[g]; b.drop[0] = a.drop[g];
+        for (int m = 0; m < M; ++m) b.W[0][m] = (const unsigned char*)A[g * M + m];
+        rc = launch_reduce(b, RP, 1, 1, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return MOKA_OK;
+}
+
 int moka_down_fwd(const void* x, const void* const* A, const uint8_t* tok_mod, float* part,
                   int T, int d_in, int r, int M, float s_in, float dropout_p, unsigned long long seed,
                   int dtype, moka_stream_t stream) {
-    int rc = check_common("moka_down_fwd", T, d_in, r, M, dtype);
-    if (rc) return rc;
-    DropArgs drop;
-    rc = make_drop("moka_down_fwd", dropout_p, seed, &drop);
-    if (rc) return rc;
-    if ((unsigned long long)T * (unsigned long long)(d_in >> 3) > 0xffffffffull && drop.thr)
-        return fail(MOKA_EINVAL, "moka_down_fwd: T * d_in too large for the dropout counter");
-    s_in *= drop.inv_keep;
-    if (!x || !A || !tok_mod || !part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
-    ReduceArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = (const unsigned char*)x;
-    for (int m = 0; m < M; ++m) {
-        if (!A[m]) return fail(MOKA_EINVAL, "moka_down_fwd: A[%d] is null", m);
-        a.W[m] = (const unsigned char*)A[m];
-        a.s_mod[m] = s_in;
+    if (!part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
+    float* parts[1] = {part};
+    return moka_down_fwd_group(x, A, tok_mod, parts, T, d_in, r, M, 1, s_in, dropout_p, &seed, dtype, stream);
+}
+
+#define GROUP_CHECK(fn) do { if (G < 1 || G > MOKA_MAX_GROUP) return fail(MOKA_EINVAL, fn ": G=%d not in 1..%d", G, MOKA_MAX_GROUP); } while (0)
+
+int moka_cross_fwd_group(const float* const* part, int ks, const moka_routing* rt, const float* s_out,
+                         const void* const* Bw, const int* d_out, const void* const* A, int d_in,
+                         float* const* h, float* const* hp, void* const* hp_tok, void* const* hp_kmj,
+                         void* const* BwT, void* const* AT, int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
+    GROUP_CHECK("moka_cross_fwd");
+    if (!part || !rt || !s_out || !h || !hp_tok || !hp_kmj) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer");
+    CrossBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    for (int g = 0; g < G; ++g) {
+        CrossArgs& a = ab.z[g];
+        if (!part[g] || !h[g] || !hp_tok[g] || !hp_kmj[g]) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer (projection %d)", g);
+        a.part = part[g]; a.ks = ks; a.out_f32 = h[g]; a.out_f32b = hp ? hp[g] : nullptr;
+        a.pack_tok = (unsigned short*)hp_tok[g]; a.pack_kmj = (unsigned short*)hp_kmj[g];
+        if (BwT && BwT[g]) {
+            if (!Bw || !Bw[g] || !d_out || d_out[g] < 32) return fail(MOKA_EINVAL, "moka_cross_fwd: BwT requested without Bw / d_out");
+            a.Bw = (const unsigned short*)Bw[g]; a.BwT = (unsigned short*)BwT[g]; a.C = d_out[g];
+        }
+        if (AT && AT[g]) {
+            if (!A || d_in < 32) return fail(MOKA_EINVAL, "moka_cross_fwd: AT requested without A / d_in");
+            a.AT = (unsigned short*)AT[g]; a.Cin = d_in;
+        }
+        for (int m = 0; m < rt->M && m < MOKA_MAX_MOD; ++m) {
+            a.s_mod[m] = s_out[m];
+            if (a.AT) {
+                if (!A[g * rt->M + m]) return fail(MOKA_EINVAL, "moka_cross_fwd: A[%d] is null", g * rt->M + m);
+                a.Aw[m] = (const unsigned short*)A[g * rt->M + m];
+            }
+        }
+        a.w = w; a.c = inv_sqrt_dk;
     }
-    a.tok_mod = tok_mod; a.out = part; a.T = T; a.C = d_in; a.r = r; a.M = M; a.ks = reduce_ks(T, d_in);
-    a.drop = drop;
-    return launch_reduce(a, rank_pad(r), (hipStream_t)stream);
+    return launch_cross(false, ab, G, rt, r, (hipStream_t)stream);
 }
 
 int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const float* s_out, const void* Bw, int d_out,
                    const void* const* A, int d_in,
                    float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT, void* AT,
                    int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
-    if (!part || !rt || !s_out || !h || !hp_tok || !hp_kmj) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer");
-    if (BwT && (!Bw || d_out < 32)) return fail(MOKA_EINVAL, "moka_cross_fwd: BwT requested without Bw / d_out");
-    if (AT && (!A || d_in < 32)) return fail(MOKA_EINVAL, "moka_cross_fwd: AT requested without A / d_in");
-    CrossArgs a;
-    memset(&a, 0, sizeof(a));
-    a.part = part; a.ks = ks; a.out_f32 = h; a.out_f32b = hp;
-    a.pack_tok = (unsigned short*)hp_tok; a.pack_kmj = (unsigned short*)hp_kmj;
-    a.Bw = (const unsigned short*)Bw; a.BwT = (unsigned short*)BwT; a.C = d_out;
-    a.AT = (unsigned short*)AT; a.Cin = d_in;
-    for (int m = 0; m < rt->M && m < MOKA_MAX_MOD; ++m) {
-        a.s_mod[m] = s_out[m];
-        if (AT) {
-            if (!A[m]) return fail(MOKA_EINVAL, "moka_cross_fwd: A[%d] is null", m);
-            a.Aw[m] = (const unsigned short*)A[m];
-        }
-    }
-    a.w = w; a.c = inv_sqrt_dk;
-    return launch_cross(false, a, rt, r, (hipStream_t)stream);
+    const void* Bw1[1] = {Bw};
+    void* BwT1[1] = {BwT};
+    void* AT1[1] = {AT};
+    float* h1[1] = {h};
+    float* hp1[1] = {hp};
+    void* tok1[1] = {hp_tok};
+    void* kmj1[1] = {hp_kmj};
+    return moka_cross_fwd_group(&part, ks, rt, s_out, Bw1, &d_out, A, d_in, h1, hp1, tok1, kmj1, BwT1, AT1, 1, r, w, inv_sqrt_dk, stream);
 }
 
 size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r) {
@@ -1350,59 +1496,174 @@ size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r) {
     return flags + (size_t)B * nblk * (Lk_max > 0 ? Lk_max : 1) * RP * 4;
 }
 
+int moka_cross_bwd_group(const float* const* g_part, int ks, const float* const* h, const moka_routing* rt, float s_in,
+                         float* const* dh, void* const* dh_tok, void* const* dh_kmj, void* const* ws,
+                         int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
+    GROUP_CHECK("moka_cross_bwd");
+    if (!g_part || !rt || !h || !dh_tok || !dh_kmj || !ws) return fail(MOKA_EINVAL, "moka_cross_bwd: null pointer");
+    CrossBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    for (int g = 0; g < G; ++g) {
+        CrossArgs& a = ab.z[g];
+        if (!g_part[g] || !h[g] || !dh_tok[g] || !dh_kmj[g] || !ws[g]) return fail(MOKA_EINVAL, "moka_cross_bwd: null pointer (projection %d)", g);
+        for (int g2 = 0; g2 < g; ++g2)
+            if (ws[g2] == ws[g]) return fail(MOKA_EINVAL, "moka_cross_bwd: projections %d and %d share one workspace", g2, g);
+        const size_t nblk8 = (size_t)(rt->S + 7) / 8;
+        a.dk_flag = (int*)ws[g];
+        a.dk_part = (float*)((unsigned char*)ws[g] + ((size_t)rt->B * nblk8 * 4 + 255) / 256 * 256);
+        a.part = g_part[g]; a.ks = ks; a.hfull = h[g]; a.out_f32 = dh ? dh[g] : nullptr;
+        a.pack_tok = (unsigned short*)dh_tok[g]; a.pack_kmj = (unsigned short*)dh_kmj[g];
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) a.s_mod[m] = s_in;
+        a.w = w; a.c = inv_sqrt_dk;
+    }
+    return launch_cross(true, ab, G, rt, r, (hipStream_t)stream);
+}
+
 int moka_cross_bwd(const float* g_part, int ks, const float* h, const moka_routing* rt, float s_in,
                    float* dh, void* dh_tok, void* dh_kmj, void* ws, int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
-    if (!g_part || !rt || !h || !dh_tok || !dh_kmj || !ws) return fail(MOKA_EINVAL, "moka_cross_bwd: null pointer");
-    CrossArgs a;
-    memset(&a, 0, sizeof(a));
-    {
-        const size_t nblk8 = (size_t)(rt->S + 7) / 8;
-        a.dk_flag = (int*)ws;
-        a.dk_part = (float*)((unsigned char*)ws + ((size_t)rt->B * nblk8 * 4 + 255) / 256 * 256);
+    float* dh1[1] = {dh};
+    void* tok1[1] = {dh_tok};
+    void* kmj1[1] = {dh_kmj};
+    void* ws1[1] = {ws};
+    return moka_cross_bwd_group(&g_part, ks, &h, rt, s_in, dh1, tok1, kmj1, ws1, 1, r, w, inv_sqrt_dk, stream);
+}
+
+int moka_up_fwd_group(const void* const* hp_tok, const void* const* Bw, const uint8_t* tok_mod, void* const* y_inout,
+                      int T, int r, const int* d_out, int G, int dtype, moka_stream_t stream) {
+    GROUP_CHECK("moka_up_fwd");
+    if (!hp_tok || !Bw || !tok_mod || !y_inout || !d_out) return fail(MOKA_EINVAL, "moka_up_fwd: null pointer");
+    ExpandBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    for (int g = 0; g < G; ++g) {
+        int rc = check_common("moka_up_fwd", T, d_out[g], r, 1, dtype);
+        if (rc) return rc;
+        if (!hp_tok[g] || !Bw[g] || !y_inout[g]) return fail(MOKA_EINVAL, "moka_up_fwd: null pointer (projection %d)", g);
+        ExpandArgs& a = ab.z[g];
+        a.pack = (const unsigned short*)hp_tok[g]; a.W[0] = (const unsigned char*)Bw[g]; a.tok_mod = tok_mod;
+        a.out = (unsigned char*)y_inout[g]; a.T = T; a.C = d_out[g]; a.r = r; a.M = 1;
     }
-    a.part = g_part; a.ks = ks; a.hfull = h; a.out_f32 = dh;
-    a.pack_tok = (unsigned short*)dh_tok; a.pack_kmj = (unsigned short*)dh_kmj;
-    for (int m = 0; m < MOKA_MAX_MOD; ++m) a.s_mod[m] = s_in;
-    a.w = w; a.c = inv_sqrt_dk;
-    return launch_cross(true, a, rt, r, (hipStream_t)stream);
+    return launch_expand<true>(ab, G, rank_pad(r), (hipStream_t)stream);
 }
 
 int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void* y_inout,
                 int T, int r, int d_out, int dtype, moka_stream_t stream) {
-    int rc = check_common("moka_up_fwd", T, d_out, r, 1, dtype);
-    if (rc) return rc;
-    if (!hp_tok || !Bw || !tok_mod || !y_inout) return fail(MOKA_EINVAL, "moka_up_fwd: null pointer");
-    ExpandArgs a;
-    memset(&a, 0, sizeof(a));
-    a.pack = (const unsigned short*)hp_tok; a.W[0] = (const unsigned char*)Bw; a.tok_mod = tok_mod;
-    a.out = (unsigned char*)y_inout; a.T = T; a.C = d_out; a.r = r; a.M = 1;
-    return launch_expand<true>(a, rank_pad(r), (hipStream_t)stream);
+    return moka_up_fwd_group(&hp_tok, &Bw, tok_mod, &y_inout, T, r, &d_out, 1, dtype, stream);
 }
 
-int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8_t* tok_mod, const float* s_out,
-                float* g_part, float* dB_acc, int T, int r, int d_out, int M, int dtype, moka_stream_t stream) {
-    int rc = check_common("moka_up_bwd", T, d_out, r, M, dtype);
-    if (rc) return rc;
-    if (!gy || !tok_mod || !s_out) return fail(MOKA_EINVAL, "moka_up_bwd: null pointer");
+int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const void* const* BwT, const uint8_t* tok_mod,
+                      const float* s_out, float* const* g_part, float* const* dB_acc,
+                      int T, int r, const int* d_out, int M, int G, int dtype, moka_stream_t stream) {
+    GROUP_CHECK("moka_up_bwd");
+    if (!gy || !tok_mod || !s_out || !d_out) return fail(MOKA_EINVAL, "moka_up_bwd: null pointer");
     const int RP = rank_pad(r);
-    if (g_part) {
+    int Cmax = 0;
+    for (int g = 0; g < G; ++g) {
+        int rc = check_common("moka_up_bwd", T, d_out[g], r, M, dtype);
+        if (rc) return rc;
+        if (!gy[g]) return fail(MOKA_EINVAL, "moka_up_bwd: gy[%d] is null", g);
+        if ((g_part && !g_part[g] != !g_part[0]) || (dB_acc && !dB_acc[g] != !dB_acc[0]))
+            return fail(MOKA_EINVAL, "moka_up_bwd: an output must be requested for every projection of the group or for none");
+        Cmax = d_out[g] > Cmax ? d_out[g] : Cmax;
+    }
+    int rc = MOKA_OK;
+    if (g_part && g_part[0]) {
         // g = s_out[mod] * gy Bw: contraction over d_out with the transposed weight; one chain per tile
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
         ReduceArgs ra;
         memset(&ra, 0, sizeof(ra));
-        ra.in = (const unsigned char*)gy; ra.W[0] = (const unsigned char*)BwT; ra.tok_mod = tok_mod; ra.out = g_part;
+        ra.tok_mod = tok_mod;
         for (int m = 0; m < M; ++m) ra.s_mod[m] = s_out[m];
-        ra.T = T; ra.C = d_out; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = reduce_ks(T, d_out);   // BwT has RP zero-padded rows
-        rc = launch_reduce(ra, RP, (hipStream_t)stream);
+        ra.T = T; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = reduce_ks(T, Cmax);     // BwT has RP zero-padded rows
+        for (int g = 0; g < G; ++g) {
+            if (!BwT[g]) return fail(MOKA_EINVAL, "moka_up_bwd: BwT[%d] is null", g);
+            ra.in[g] = (const unsigned char*)gy[g]; ra.W[g][0] = (const unsigned char*)BwT[g]; ra.out[g] = g_part[g]; ra.C[g] = d_out[g];
+        }
+        rc = launch_reduce(ra, RP, 1, G, (hipStream_t)stream);
         if (rc) return rc;
     }
-    if (dB_acc) {
+    if (dB_acc && dB_acc[0]) {
         if (!hp_kmj) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without hp_kmj");
-        WgradArgs ga;
-        memset(&ga, 0, sizeof(ga));
-        ga.in = (const unsigned char*)gy; ga.pack = (const unsigned short*)hp_kmj; ga.tok_mod = tok_mod; ga.acc[0] = dB_acc;
-        ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_out; ga.r = r; ga.M = M; ga.per_mod = 0;
-        rc = launch_wgrad<true>(ga, RP, (hipStream_t)stream);
+        WgradBatch gb;
+        memset(&gb, 0, sizeof(gb));
+        for (int g = 0; g < G; ++g) {
+            if (!hp_kmj[g]) return fail(MOKA_EINVAL, "moka_up_bwd: hp_kmj[%d] is null", g);
+            WgradArgs& ga = gb.z[g];
+            ga.in = (const unsigned char*)gy[g]; ga.pack = (const unsigned short*)hp_kmj[g]; ga.tok_mod = tok_mod; ga.acc[0] = dB_acc[g];
+            ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_out[g]; ga.r = r; ga.M = M; ga.per_mod = 0;
+        }
+        rc = launch_wgrad<true>(gb, G, RP, (hipStream_t)stream);
+    }
+    return rc;
+}
+
+int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8_t* tok_mod, const float* s_out,
+                float* g_part, float* dB_acc, int T, int r, int d_out, int M, int dtype, moka_stream_t stream) {
+    return moka_up_bwd_group(&gy, &hp_kmj, &BwT, tok_mod, s_out, &g_part, &dB_acc, T, r, &d_out, M, 1, dtype, stream);
+}
+
+int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, const void* x, const void* const* AT,
+                        const uint8_t* tok_mod, float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M, int G,
+                        float dropout_p, const unsigned long long* seeds, int dtype, moka_stream_t stream) {
+    GROUP_CHECK("moka_down_bwd");
+    int rc = check_common("moka_down_bwd", T, d_in, r, M, dtype);
+    if (rc) return rc;
+    if (!tok_mod) return fail(MOKA_EINVAL, "moka_down_bwd: null pointer");
+    if (dropout_p != 0.f && !seeds) return fail(MOKA_EINVAL, "moka_down_bwd: dropout without seeds");
+    DropArgs drop[MOKA_MAX_GROUP];
+    for (int g = 0; g < G; ++g) {
+        rc = make_drop("moka_down_bwd", dropout_p, seeds ? seeds[g] : 0ull, &drop[g]);
+        if (rc) return rc;
+    }
+    const int RP = rank_pad(r);
+    const bool fused = G == 1 || can_group(r, G);
+    if (dA_acc) {
+        if (!dh_kmj || !x) return fail(MOKA_EINVAL, "moka_down_bwd: dA requested without dh_kmj / x");
+        WgradBatch gb;
+        memset(&gb, 0, sizeof(gb));
+        for (int g = 0; g < G; ++g) {
+            if (!dh_kmj[g]) return fail(MOKA_EINVAL, "moka_down_bwd: dh_kmj[%d] is null", g);
+            WgradArgs& ga = gb.z[g];
+            ga.in = (const unsigned char*)x; ga.pack = (const unsigned short*)dh_kmj[g]; ga.tok_mod = tok_mod;
+            for (int m = 0; m < M; ++m) {
+                if (!dA_acc[g * M + m]) return fail(MOKA_EINVAL, "moka_down_bwd: dA_acc[%d] is null", g * M + m);
+                ga.acc[m] = dA_acc[g * M + m];
+            }
+            ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in; ga.r = r; ga.M = M; ga.per_mod = 1; ga.drop = drop[g];
+        }
+        if (fused) {
+            rc = launch_wgrad<false>(gb, G, RP, (hipStream_t)stream);
+            if (rc) return rc;
+        } else {
+            for (int g = 0; g < G; ++g) {
+                WgradBatch one;
+                memset(&one, 0, sizeof(one));
+                one.z[0] = gb.z[g];
+                rc = launch_wgrad<false>(one, 1, RP, (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (dx_inout) {
+        if (!dh_tok || !AT) return fail(MOKA_EINVAL, "moka_down_bwd: dx requested without dh_tok / AT");
+        ExpandBatch eb;
+        memset(&eb, 0, sizeof(eb));
+        for (int g = 0; g < G; ++g) {
+            if (!dh_tok[g] || !AT[g]) return fail(MOKA_EINVAL, "moka_down_bwd: dh_tok / AT of projection %d is null", g);
+            ExpandArgs& a = eb.z[g];
+            a.pack = (const unsigned short*)dh_tok[g]; a.tok_mod = tok_mod; a.out = (unsigned char*)dx_inout;
+            for (int m = 0; m < M; ++m) a.W[m] = (const unsigned char*)AT[g] + (size_t)m * d_in * RP * 2;
+            a.T = T; a.C = d_in; a.r = r; a.M = M; a.drop = drop[g];
+        }
+        if (fused) {
+            rc = launch_expand<false>(eb, G, RP, (hipStream_t)stream);
+        } else {
+            for (int g = 0; g < G && !rc; ++g) {
+                ExpandBatch one;
+                memset(&one, 0, sizeof(one));
+                one.z[0] = eb.z[g];
+                rc = launch_expand<false>(one, 1, RP, (hipStream_t)stream);
+            }
+        }
     }
     return rc;
 }
@@ -1410,36 +1671,8 @@ int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8
 int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* AT, const uint8_t* tok_mod,
                   float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M,
                   float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream) {
-    int rc = check_common("moka_down_bwd", T, d_in, r, M, dtype);
-    if (rc) return rc;
-    DropArgs drop;
-    rc = make_drop("moka_down_bwd", dropout_p, seed, &drop);
-    if (rc) return rc;
-    if (!tok_mod) return fail(MOKA_EINVAL, "moka_down_bwd: null pointer");
-    const int RP = rank_pad(r);
-    if (dA_acc) {
-        if (!dh_kmj || !x) return fail(MOKA_EINVAL, "moka_down_bwd: dA requested without dh_kmj / x");
-        WgradArgs ga;
-        memset(&ga, 0, sizeof(ga));
-        ga.in = (const unsigned char*)x; ga.pack = (const unsigned short*)dh_kmj; ga.tok_mod = tok_mod;
-        for (int m = 0; m < M; ++m) {
-            if (!dA_acc[m]) return fail(MOKA_EINVAL, "moka_down_bwd: dA_acc[%d] is null", m);
-            ga.acc[m] = dA_acc[m];
-        }
-        ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in; ga.r = r; ga.M = M; ga.per_mod = 1; ga.drop = drop;
-        rc = launch_wgrad<false>(ga, RP, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    if (dx_inout) {
-        if (!dh_tok || !AT) return fail(MOKA_EINVAL, "moka_down_bwd: dx requested without dh_tok / AT");
-        ExpandArgs a;
-        memset(&a, 0, sizeof(a));
-        a.pack = (const unsigned short*)dh_tok; a.tok_mod = tok_mod; a.out = (unsigned char*)dx_inout;
-        for (int m = 0; m < M; ++m) a.W[m] = (const unsigned char*)AT + (size_t)m * d_in * RP * 2;
-        a.T = T; a.C = d_in; a.r = r; a.M = M; a.drop = drop;
-        rc = launch_expand<false>(a, RP, (hipStream_t)stream);
-    }
-    return rc;
+    return moka_down_bwd_group(dh_tok ? &dh_tok : nullptr, dh_kmj ? &dh_kmj : nullptr, x, AT ? &AT : nullptr, tok_mod,
+                               dA_acc, dx_inout, T, d_in, r, M, 1, dropout_p, &seed, dtype, stream);
 }
 
 int moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in, uint8_t* keep_out, moka_stream_t stream) {

@@ -144,6 +144,125 @@ def down_bwd_(bst: BwdState, x2: torch.Tensor, AT: Optional[torch.Tensor], rt: M
                                  _stream_ptr(x2.device)), "moka_down_bwd")
 
 
+# --------------------------------------------------------------------------------------
+# grouped entry points: G projections fed by the same x (q/k/v, gate/up)
+# --------------------------------------------------------------------------------------
+def _ints(vals: Sequence[int]):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _u64s(vals: Sequence[int]):
+    return (ctypes.c_ulonglong * len(vals))(*[int(v) for v in vals])
+
+
+def _optptrs(tensors: Sequence[Optional[torch.Tensor]]):
+    return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def down_fwd_group(x2: torch.Tensor, A: Sequence[Sequence[torch.Tensor]], rt: MokaRouting, r: int, s_in: float,
+                   dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+    """One read of x2 [T,d_in] for the G down-projections A[g][m]; returns the G split-K partial buffers."""
+    lib = _lib.load()
+    T, d_in = x2.shape
+    G, M = len(A), len(A[0])
+    RP = _lib.rank_pad(r)
+    ks = _lib.ksplit(T, d_in, r)
+    parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device) for _ in range(G)]
+    flat = [a for Ag in A for a in Ag]
+    _lib.check(lib.moka_down_fwd_group(x2.data_ptr(), _ptrs(flat), rt.tok_mod.data_ptr(), _ptrs(parts),
+                                       T, d_in, r, M, G, float(s_in), float(dropout_p),
+                                       _u64s(seeds if seeds is not None else [0] * G), _lib.MOKA_BF16,
+                                       _stream_ptr(x2.device)), "moka_down_fwd_group")
+    return parts
+
+
+def cross_fwd_group(parts: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
+                    Bw: Sequence[torch.Tensor], A: Optional[Sequence[Sequence[torch.Tensor]]] = None) -> List[FwdState]:
+    lib = _lib.load()
+    G = len(parts)
+    ks, T, RP = parts[0].shape
+    dev = parts[0].device
+    Tp = _lib.tok_pad(T)
+    sts = []
+    for g in range(G):
+        st = FwdState()
+        st.h = torch.empty((T, RP), dtype=torch.float32, device=dev)
+        st.hp = None
+        st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
+        st.hp_kmj = torch.empty((2, RP, Tp), dtype=torch.bfloat16, device=dev)
+        st.BwT = torch.empty((RP, Bw[g].shape[0]), dtype=torch.bfloat16, device=dev)
+        st.AT = torch.empty((len(A[g]), A[g][0].shape[1], RP), dtype=torch.bfloat16, device=dev) if A is not None else None
+        sts.append(st)
+    flatA = None if A is None else _ptrs([a for Ag in A for a in Ag])
+    _lib.check(lib.moka_cross_fwd_group(_ptrs(parts), ks, byref(rt.struct), _floats(s_out),
+                                        _ptrs(Bw), _ints([b.shape[0] for b in Bw]), flatA, 0 if A is None else A[0][0].shape[1],
+                                        _ptrs([st.h for st in sts]), None, _ptrs([st.hp_tok for st in sts]),
+                                        _ptrs([st.hp_kmj for st in sts]), _ptrs([st.BwT for st in sts]),
+                                        None if A is None else _ptrs([st.AT for st in sts]),
+                                        G, r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_fwd_group")
+    return sts
+
+
+def up_fwd_group_(ys: Sequence[torch.Tensor], hp_toks: Sequence[torch.Tensor], Bw: Sequence[torch.Tensor], rt: MokaRouting, r: int):
+    lib = _lib.load()
+    T = ys[0].shape[0]
+    _lib.check(lib.moka_up_fwd_group(_ptrs(hp_toks), _ptrs(Bw), rt.tok_mod.data_ptr(), _ptrs(ys), T, r,
+                                     _ints([y.shape[1] for y in ys]), len(ys), _lib.MOKA_BF16, _stream_ptr(ys[0].device)),
+               "moka_up_fwd_group")
+
+
+def up_bwd_group(gys: Sequence[torch.Tensor], hp_kmjs: Sequence[torch.Tensor], BwTs: Sequence[torch.Tensor], rt: MokaRouting, r: int,
+                 s_out: Sequence[float], dB_accs: Optional[Sequence[torch.Tensor]]) -> List[torch.Tensor]:
+    lib = _lib.load()
+    G = len(gys)
+    T = gys[0].shape[0]
+    RP = _lib.rank_pad(r)
+    d_outs = [g_.shape[1] for g_ in gys]
+    ks = _lib.ksplit(T, max(d_outs), r)
+    g_parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=gys[0].device) for _ in range(G)]
+    _lib.check(lib.moka_up_bwd_group(_ptrs(gys), _ptrs(hp_kmjs), _ptrs(BwTs), rt.tok_mod.data_ptr(), _floats(s_out),
+                                     _ptrs(g_parts), None if dB_accs is None else _ptrs(dB_accs),
+                                     T, r, _ints(d_outs), len(s_out), G, _lib.MOKA_BF16, _stream_ptr(gys[0].device)),
+               "moka_up_bwd_group")
+    return g_parts
+
+
+def cross_bwd_group(g_parts: Sequence[torch.Tensor], hs: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float,
+                    w: float, inv_sqrt_dk: float) -> List[BwdState]:
+    lib = _lib.load()
+    G = len(g_parts)
+    ks, T, RP = g_parts[0].shape
+    dev = g_parts[0].device
+    Tp = _lib.tok_pad(T)
+    sts = []
+    for g in range(G):
+        st = BwdState()
+        st.dh = None
+        st.dh_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
+        st.dh_kmj = torch.empty((rt.M, 2, RP, Tp), dtype=torch.bfloat16, device=dev)
+        sts.append(st)
+    _lib.check(lib.moka_cross_bwd_group(_ptrs(g_parts), ks, _ptrs(hs), byref(rt.struct), float(s_in), None,
+                                        _ptrs([st.dh_tok for st in sts]), _ptrs([st.dh_kmj for st in sts]),
+                                        _ptrs([rt.cross_ws(r, g) for g in range(G)]), G, r, float(w), float(inv_sqrt_dk),
+                                        _stream_ptr(dev)), "moka_cross_bwd_group")
+    return sts
+
+
+def down_bwd_group_(bsts: Sequence[BwdState], x2: torch.Tensor, ATs: Optional[Sequence[torch.Tensor]], rt: MokaRouting, r: int,
+                    dA_accs: Optional[Sequence[Sequence[torch.Tensor]]], dx2: Optional[torch.Tensor],
+                    dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None):
+    """dA_accs[g][m] += (one read of x2 for all G); dx2 += sum_g dh_g A_g (one read-modify-write)."""
+    lib = _lib.load()
+    T, d_in = x2.shape
+    G = len(bsts)
+    _lib.check(lib.moka_down_bwd_group(_ptrs([b.dh_tok for b in bsts]), _ptrs([b.dh_kmj for b in bsts]), x2.data_ptr(),
+                                       None if ATs is None else _ptrs(ATs), rt.tok_mod.data_ptr(),
+                                       None if dA_accs is None else _ptrs([a for Ag in dA_accs for a in Ag]),
+                                       None if dx2 is None else dx2.data_ptr(), T, d_in, r, rt.M, G, float(dropout_p),
+                                       _u64s(seeds if seeds is not None else [0] * G), _lib.MOKA_BF16, _stream_ptr(x2.device)),
+               "moka_down_bwd_group")
+
+
 def dropout_mask(dropout_p: float, seed: int, T: int, d_in: int, device) -> torch.Tensor:
     """The keep mask (uint8 [T,d_in]) the kernels derive from (dropout_p, seed) -- for checkers."""
     lib = _lib.load()
@@ -239,3 +358,121 @@ class MokaLinearFn(torch.autograd.Function):
 
 def moka_linear(x, W, bias, Bw, A: Sequence[torch.Tensor], rt: MokaRouting, spec: AdapterSpec):
     return MokaLinearFn.apply(x, W, bias, Bw, rt, spec, *A)
+
+
+# --------------------------------------------------------------------------------------
+# autograd node of a GROUP of adapted projections fed by the same x
+# --------------------------------------------------------------------------------------
+class MokaLinearGroupFn(torch.autograd.Function):
+    """(y_0 .. y_{G-1}) = (x W_g^T (+ b_g) + adapter_g(x)) for the G projections that read the same x:
+    q/k/v of the attention block, gate/up of the MLP.  Same arithmetic as G MokaLinearFn nodes; x is
+    read once by the G down-projections and once by the G dA kernels, and the G input gradients are
+    added to dx in one read-modify-write pass.
+
+    Inputs: x, rt, specs (list of G AdapterSpec: r / s_in / s_out / w / d_k / dropout_p must agree, seeds
+    differ), G, M, then per projection W_g, bias_g|None, Bw_g, A_g0..A_g{M-1}.
+    """
+
+    @staticmethod
+    def forward(ctx, x, rt: MokaRouting, specs, G: int, M: int, *flat):
+        per = 3 + M
+        Ws = [flat[g * per] for g in range(G)]
+        biases = [flat[g * per + 1] for g in range(G)]
+        Bws = [flat[g * per + 2] for g in range(G)]
+        As = [list(flat[g * per + 3:g * per + 3 + M]) for g in range(G)]
+        _require_device(x, "x")
+        _require_bf16(x, "x")
+        for g in range(G):
+            _require_bf16(Ws[g], "base weight")
+            _require_bf16(Bws[g], "lora_B")
+            for a in As[g]:
+                _require_bf16(a, "lora_A")
+        sp = specs[0]
+        for o in specs[1:]:
+            if (o.r, o.s_in, o.s_out, o.w, o.inv_sqrt_dk, o.dropout_p) != (sp.r, sp.s_in, sp.s_out, sp.w, sp.inv_sqrt_dk, sp.dropout_p):
+                raise ValueError("moka_amd: the projections of one group must share r, scaling, blc/attn weight and dropout")
+        if len(sp.s_out) != rt.M or M != rt.M:
+            raise ValueError(f"routing describes {rt.M} modalities but {M} adapters / {len(sp.s_out)} scales were given")
+        d_in = x.shape[-1]
+        x2 = x.reshape(-1, d_in)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        if x2.shape[0] != rt.T:
+            raise ValueError(f"x has {x2.shape[0]} tokens but the masks describe {rt.T}")
+        ys = [torch.nn.functional.linear(x2, Ws[g], biases[g]) for g in range(G)]      # frozen base, stock PyTorch-ROCm
+        As = [[a if a.is_contiguous() else a.contiguous() for a in Ag] for Ag in As]
+        Bws = [b if b.is_contiguous() else b.contiguous() for b in Bws]
+        seeds = [s_.seed for s_ in specs]
+        parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
+        need_x = ctx.needs_input_grad[0]
+        sts = cross_fwd_group(parts, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, Bws, As if need_x else None)
+        up_fwd_group_(ys, [st.hp_tok for st in sts], Bws, rt, sp.r)
+        saved = [x2]
+        for g in range(G):
+            saved += [Ws[g], Bws[g], sts[g].h, sts[g].hp_kmj, sts[g].BwT, sts[g].AT if need_x else None, *As[g]]
+        ctx.save_for_backward(*saved)
+        ctx.rt, ctx.specs, ctx.G, ctx.M, ctx.x_shape = rt, specs, G, M, x.shape
+        ctx.has_bias = [b is not None for b in biases]
+        return tuple(y.reshape(*x.shape[:-1], y.shape[-1]) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        G, M, rt, specs = ctx.G, ctx.M, ctx.rt, ctx.specs
+        sp = specs[0]
+        r = sp.r
+        saved = ctx.saved_tensors
+        x2 = saved[0]
+        per_s = 6 + M
+        Ws = [saved[1 + g * per_s] for g in range(G)]
+        Bws = [saved[2 + g * per_s] for g in range(G)]
+        hs = [saved[3 + g * per_s] for g in range(G)]
+        hp_kmjs = [saved[4 + g * per_s] for g in range(G)]
+        BwTs = [saved[5 + g * per_s] for g in range(G)]
+        ATs = [saved[6 + g * per_s] for g in range(G)]
+        As = [list(saved[7 + g * per_s:7 + g * per_s + M]) for g in range(G)]
+        per = 3 + M
+        nig = ctx.needs_input_grad
+        base = 5                                                     # x, rt, specs, G, M
+        if any(nig[base + g * per] for g in range(G)):
+            raise _lib.MokaError("moka_amd: the base weight is frozen in MokA; requires_grad on it is not supported")
+        dev = x2.device
+        gy2 = []
+        for g in range(G):
+            t_ = gys[g]
+            if t_ is None:                                           # an output that did not reach the loss
+                t_ = torch.zeros((x2.shape[0], Ws[g].shape[0]), dtype=x2.dtype, device=dev)
+            t_ = t_.reshape(-1, t_.shape[-1])
+            gy2.append(t_ if t_.is_contiguous() else t_.contiguous())
+        need_x = nig[0]
+        need_B = any(nig[base + g * per + 2] for g in range(G))
+        need_A = any(nig[base + g * per + 3 + m] for g in range(G) for m in range(M))
+        dB_accs = [torch.zeros((Bws[g].shape[0], r), dtype=torch.float32, device=dev) for g in range(G)] if need_B else None
+        g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs)
+        dx2 = None
+        if need_x:
+            dx2 = torch.matmul(gy2[0], Ws[0])                        # frozen base: dx only, never dW
+            for g in range(1, G):
+                dx2.addmm_(gy2[g], Ws[g])
+        dA_accs = None
+        if need_A or need_x:
+            bsts = cross_bwd_group(g_parts, hs, rt, r, sp.s_in, sp.w, sp.inv_sqrt_dk)
+            if need_A:
+                dA_accs = [[torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=dev) for _ in range(M)] for _ in range(G)]
+            down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, [s_.seed for s_ in specs])
+        grads = []
+        for g in range(G):
+            gbias = gy2[g].sum(0) if (ctx.has_bias[g] and nig[base + g * per + 1]) else None
+            gB = dB_accs[g].to(Bws[g].dtype) if (need_B and nig[base + g * per + 2]) else None
+            gA = [dA_accs[g][m].to(As[g][m].dtype) if (need_A and nig[base + g * per + 3 + m]) else None for m in range(M)]
+            grads += [None, gbias, gB, *gA]
+        return (None if dx2 is None else dx2.reshape(ctx.x_shape), None, None, None, None, *grads)
+
+
+def moka_linear_group(x, projections, rt: MokaRouting, specs: Sequence[AdapterSpec]):
+    """projections: list of (W, bias|None, Bw, [A_0..A_{M-1}]) fed by the same x.  Returns the list of outputs."""
+    G = len(projections)
+    M = len(projections[0][3])
+    flat = []
+    for W, b, Bw, A in projections:
+        flat += [W, b, Bw, *A]
+    return list(MokaLinearGroupFn.apply(x, rt, list(specs), G, M, *flat))

@@ -47,15 +47,15 @@ class MokaRouting:
         self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.ktok.data_ptr(), self.klen.data_ptr(),
                                              self.kslot.data_ptr(), B, S, Lk_max, M)
 
-    def cross_ws(self, r: int) -> torch.Tensor:
-        """Scratch of moka_cross_bwd for rank r (no initialisation needed; one per routing and rank pad,
-        consumed inside the call, so consecutive layers share it)."""
+    def cross_ws(self, r: int, slot: int = 0) -> torch.Tensor:
+        """Scratch of moka_cross_bwd for rank r (no initialisation needed; one per routing, rank pad and
+        group slot, consumed inside the call, so consecutive layers share it)."""
         rp = _lib.rank_pad(r)
-        ws = self._ws.get(rp)
+        ws = self._ws.get((rp, slot))
         if ws is None:
             n = int(_lib.load().moka_cross_ws_bytes(self.B, self.S, self.Lk_max, int(r)))
             ws = torch.empty(max(n, 256), dtype=torch.uint8, device=self.tok_mod.device)
-            self._ws[rp] = ws
+            self._ws[(rp, slot)] = ws
         return ws
 
     @property

@@ -351,3 +351,117 @@ def test_dropout_layer_train_vs_eval():
     torch.manual_seed(5); y2 = lin(x, masks)
     torch.manual_seed(6); y3 = lin(x, masks)
     assert torch.equal(y1, y2) and not torch.equal(y1, y3) and not torch.equal(y1, y_eval)
+
+
+# ------------------------------------------------------------------------------------------
+# grouped entry points: q/k/v and gate/up read the same x
+# ------------------------------------------------------------------------------------------
+def _group_data(variant, B, S, d_in, d_outs, r, seed, layouts=None):
+    cds = []
+    for g, d_out in enumerate(d_outs):
+        name = f"group_{variant}_{d_in}_{d_out}_{r}_{g}"
+        lay = layouts if layouts is not None else [C.synthetic_sequence_layout(S)] * B
+        if variant == "vt":
+            lay = [[(k if k != "a" else "v", n) for k, n in l_] for l_ in lay]
+        C._CASES[name] = dict(variant=variant, B=B, S=S, d_in=d_in, d_out=d_out, r=r, alpha=16.0,
+                              w=1.0 if variant == "avt" else 0.05, layouts=lay, seed=seed + 17 * g, big=True)
+        cd = C.make_case_data(name)
+        if g:
+            cd.x = cds[0].x                                          # the group shares its input
+        cds.append(cd)
+    return cds
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(variant="avt", B=2, S=2048, d_in=4096, d_outs=(4096, 4096, 4096), r=16, p=0.0),     # q/k/v, Llama-2-7B
+    dict(variant="avt", B=2, S=2048, d_in=4096, d_outs=(4096, 1024, 1024), r=16, p=0.05),    # GQA-shaped, dropout
+    dict(variant="avt", B=1, S=2048, d_in=4096, d_outs=(11008, 11008), r=16, p=0.05),        # gate/up
+    dict(variant="vt", B=2, S=2048, d_in=4096, d_outs=(4096, 4096, 4096), r=16, p=0.05),
+    dict(variant="avt", B=3, S=80, d_in=256, d_outs=(256, 128, 384), r=8, p=0.1, tiny=True),
+    dict(variant="avt", B=1, S=1024, d_in=1024, d_outs=(1024, 512), r=64, p=0.1),            # r > 16: per-projection fallback
+])
+def test_group_matches_single_projection_nodes(cfg):
+    """The grouped autograd node against G single-projection nodes on the same inputs and seeds:
+    y bit-identical (same kernels, same accumulation order); dA/dB equal up to the order of the fp32
+    atomics; dx equal up to bf16 rounding (the group rounds once, the singles after every projection)."""
+    from moka_amd.functional import AdapterSpec, moka_linear, moka_linear_group
+    dev = _dev()
+    bf = torch.bfloat16
+    lay = None
+    if cfg.get("tiny"):
+        lay = [[("p", 3), ("t", 9), ("v", 21), ("t", 2), ("a", 14), ("q", 9), ("t", 22)],
+               [("t", 5), ("v", 30), ("a", 10), ("q", 12), ("t", 23)],
+               [("v", 17), ("t", 3), ("a", 18), ("t", 7), ("q", 5), ("t", 30)]]
+    cds = _group_data(cfg["variant"], cfg["B"], cfg["S"], cfg["d_in"], cfg["d_outs"], cfg["r"], 4242, lay)
+    G = len(cds)
+    spec0, rt, _ = _spec_and_routing(cds[0], dev)
+    specs = [AdapterSpec(spec0.r, spec0.s_in, spec0.s_out, spec0.w, spec0.inv_sqrt_dk, cfg["p"], seed=991 + 7 * g) for g in range(G)]
+    x = cds[0].x.to(dev, bf)
+
+    def params():
+        out = []
+        for cd in cds:
+            out.append((cd.W.to(dev, bf), None, cd.Bw.to(dev, bf).requires_grad_(True), [a.to(dev, bf).requires_grad_(True) for a in cd.A]))
+        return out
+
+    # grouped
+    xg = x.clone().requires_grad_(True)
+    pg = params()
+    ys = moka_linear_group(xg, pg, rt, specs)
+    torch.autograd.backward(ys, [cd.gy.to(dev, bf) for cd in cds])
+    # singles
+    xs = x.clone().requires_grad_(True)
+    ps = params()
+    y1 = [moka_linear(xs, W, b, Bw, A, rt, specs[g]) for g, (W, b, Bw, A) in enumerate(ps)]
+    torch.autograd.backward(y1, [cd.gy.to(dev, bf) for cd in cds])
+    for g in range(G):
+        assert torch.equal(ys[g], y1[g]), f"y[{g}]"
+        assert rel(pg[g][2].grad, ps[g][2].grad) < 2e-3, f"dB[{g}]"          # both are bf16 casts of fp32 sums
+        for m in range(len(pg[g][3])):
+            ga, gb = pg[g][3][m].grad, ps[g][3][m].grad
+            if gb.float().norm().item() > 0:
+                assert rel(ga, gb) < 2e-3, f"dA[{g}][{m}]"
+    # singles: G bf16 dx tensors (each rounded after its base GEMM and again after the adapter add) summed
+    # by autograd in bf16; group: bf16 addmm_ chain of the base terms + ONE rounding of the adapter sum
+    # -> ~sqrt(3 G) roundings of 2^-9 apart
+    assert rel(xg.grad, xs.grad) < 8e-3, "dx"
+    assert (xg.grad.float() - xs.grad.float()).abs().max().item() <= 2.0 ** -5 * xs.grad.float().abs().max().item(), "dx max"
+
+
+def test_group_dx_against_fp64_oracle():
+    """dx of a q/k/v group with a zero base weight (so only the adapter terms remain) against the fp64
+    oracle's sum over the three projections: one bf16 rounding of the sum."""
+    from moka_amd import functional as F
+    dev = _dev()
+    bf = torch.bfloat16
+    cds = _group_data("avt", 2, 512, 1024, (1024, 512, 1024), 16, 555)
+    G = len(cds)
+    spec, rt, ort = _spec_and_routing(cds[0], dev)
+    c = cds[0].case
+    T = c.B * c.S
+    x2 = cds[0].x.reshape(T, c.d_in).to(dev, bf).contiguous()
+    As = [[a.to(dev, bf).contiguous() for a in cd.A] for cd in cds]
+    Bws = [cd.Bw.to(dev, bf).contiguous() for cd in cds]
+    parts = F.down_fwd_group(x2, As, rt, c.r, spec.s_in)
+    sts = F.cross_fwd_group(parts, rt, c.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bws, As)
+    gys = [cd.gy.reshape(T, -1).to(dev, bf).contiguous() for cd in cds]
+    dB = [torch.zeros(b.shape[0], c.r, dtype=torch.float32, device=dev) for b in Bws]
+    g_parts = F.up_bwd_group(gys, [s.hp_kmj for s in sts], [s.BwT for s in sts], rt, c.r, spec.s_out, dB)
+    bsts = F.cross_bwd_group(g_parts, [s.h for s in sts], rt, c.r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+    dA = [[torch.zeros(c.r, c.d_in, dtype=torch.float32, device=dev) for _ in range(rt.M)] for _ in range(G)]
+    dx2 = torch.zeros(T, c.d_in, dtype=bf, device=dev)
+    F.down_bwd_group_(bsts, x2, [s.AT for s in sts], rt, c.r, dA, dx2)
+    dxo = torch.zeros(c.B, c.S, c.d_in, dtype=torch.float64)
+    dmag = torch.zeros_like(dxo)                                   # resolution under cancellation between the G terms
+    for g, cd in enumerate(cds):
+        y0 = torch.zeros(c.B, c.S, cd.case.d_out, dtype=torch.float64)
+        _, ctx = O.adapter_forward(cd.x.double(), y0, [a.double() for a in cd.A], cd.Bw.double(), ort, spec.s_in, spec.s_out,
+                                   spec.w, c.r, dtype=torch.float64)
+        dx_g, dA_g, dB_g, _ = O.adapter_backward(cd.gy.double(), ctx)
+        dxo += dx_g
+        dmag += dx_g.abs()
+        assert rel(dB[g], dB_g) < TOL_F32, f"dB[{g}]"
+        for m in range(rt.M):
+            assert rel(dA[g][m], dA_g[m]) < TOL_F32, f"dA[{g}][{m}]"
+    assert rel(dx2, dxo.reshape(T, -1).to(bf)) < TOL_BF16          # the oracle's sum, rounded to bf16 once
+    assert ulp_bf16_diff(dx2, dxo.reshape(T, -1).to(bf), operand=dmag.reshape(T, -1)) <= 1.0
