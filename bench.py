@@ -71,35 +71,54 @@ def synthetic_layout(S):
     return tok, q
 
 
-class Proj:
-    """One adapted projection: device buffers + pre-built ctypes arguments for the six launches."""
+class Unit:
+    """The projections of one decoder layer that are fed by the same input (q/k/v; o; gate/up; down) with the
+    ctypes argument lists of the six (grouped) entry points pre-built.  G = 1 is the per-projection path."""
 
-    def __init__(self, lib, name, d_in, d_out, r, M, T, bufs, params, grads, ws, rt, s_in, s_out, w, c, drop_p=0.0, seed=0):
+    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds):
         from moka_amd import _lib
-        self.name, self.d_in, self.d_out = name, d_in, d_out
-        self.ks_in = _lib.ksplit(T, d_in, r)
-        self.ks_out = _lib.ksplit(T, d_out, r)
-        x, y, dx = bufs
-        A, Bw = params
-        dA, dB = grads
-        part, h, hp_tok, hp_kmj, BwT, AT, dh_tok, dh_kmj = ws
-        self.keep = (x, y, dx, A, Bw, dA, dB, ws)
-        Ap = (c_void_p * M)(*[a.data_ptr() for a in A])
-        dAp = (c_void_p * M)(*[a.data_ptr() for a in dA])
+        G = len(members)
+        self.label, self.G, self.T = label, G, T
+        self.d_in = members[0]["d_in"]
+        self.d_outs = [m["d_out"] for m in members]
+        ks_in = _lib.ksplit(T, self.d_in, r)
+        ks_out = _lib.ksplit(T, max(self.d_outs), r)
+        P = lambda ts: (c_void_p * len(ts))(*[t.data_ptr() for t in ts])          # noqa: E731
+        I = lambda vs: (ctypes.c_int * len(vs))(*vs)                              # noqa: E731
+        A = P([a for m in members for a in m["A"]])
+        dA = P([a for m in members for a in m["dA"]])
+        Bw, dB = P([m["Bw"] for m in members]), P([m["dB"] for m in members])
+        y = P([m["y"] for m in members])
+        h, hp_kmj = P([m["h"] for m in members]), P([m["hp_kmj"] for m in members])
+        BwT, AT = P([m["BwT"] for m in members]), P([m["AT"] for m in members])
+        part = P([scratch[g]["part"] for g in range(G)])
+        hp_tok = P([scratch[g]["hp_tok"] for g in range(G)])
+        dh_tok = P([scratch[g]["dh_tok"] for g in range(G)])
+        dh_kmj = P([scratch[g]["dh_kmj"] for g in range(G)])
+        ws = P([rt.cross_ws(r, g) for g in range(G)])
         so = (c_float * M)(*s_out)
-        self._c = (Ap, dAp, so)
+        sd = (ctypes.c_ulonglong * G)(*seeds)
+        do = I(self.d_outs)
         tm = rt.tok_mod.data_ptr()
-        self.f1 = (x.data_ptr(), Ap, tm, part.data_ptr(), T, d_in, r, M, s_in, drop_p, seed, 0)
-        self.f2 = (part.data_ptr(), self.ks_in, byref(rt.struct), so, Bw.data_ptr(), d_out, Ap, d_in, h.data_ptr(), None,
-                   hp_tok.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), AT.data_ptr(), r, w, c)
-        self.f3 = (hp_tok.data_ptr(), Bw.data_ptr(), tm, y.data_ptr(), T, r, d_out, 0)
-        self.b1 = (y.data_ptr(), hp_kmj.data_ptr(), BwT.data_ptr(), tm, so, part.data_ptr(), dB.data_ptr(), T, r, d_out, M, 0)
-        self.b1g = (y.data_ptr(), None, BwT.data_ptr(), tm, so, part.data_ptr(), None, T, r, d_out, M, 0)          # gy.Bw only
-        self.b1w = (y.data_ptr(), hp_kmj.data_ptr(), None, tm, so, None, dB.data_ptr(), T, r, d_out, M, 0)         # dB only
-        self.b2 = (part.data_ptr(), self.ks_out, h.data_ptr(), byref(rt.struct), s_in, None, dh_tok.data_ptr(), dh_kmj.data_ptr(), rt.cross_ws(r).data_ptr(), r, w, c)
-        self.b3 = (dh_tok.data_ptr(), dh_kmj.data_ptr(), x.data_ptr(), AT.data_ptr(), tm, dAp, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)
-        self.b3x = (dh_tok.data_ptr(), None, x.data_ptr(), AT.data_ptr(), tm, None, dx.data_ptr(), T, d_in, r, M, drop_p, seed, 0)    # dx only
-        self.b3w = (None, dh_kmj.data_ptr(), x.data_ptr(), None, tm, dAp, None, T, d_in, r, M, drop_p, seed, 0)              # dA only
+        self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sd, do, x, dx)
+        self.calls = {
+            "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sd, 0)),
+            "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
+                                                        BwT, AT, G, r, w, c)),
+            "moka_up_fwd": ("moka_up_fwd_group", (hp_tok, Bw, tm, y, T, r, do, G, 0)),
+            "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0)),
+            "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
+            "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
+                                                      drop_p, sd, 0)),
+        }
+        # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
+        # per-projection definition: a group that reads x once is still credited G reads -- the roofline
+        # fraction is defined on the reference's per-projection traffic):
+        #   down_fwd: read x  E*T*d_in      up_fwd: read+write y  2*E*T*d_out
+        #   up_bwd  : read gy E*T*d_out     down_bwd: read x, r+w dx  3*E*T*d_in
+        sdo = sum(self.d_outs)
+        self.algo = {"moka_down_fwd": E * T * self.d_in * G, "moka_up_fwd": 2 * E * T * sdo, "moka_up_bwd": E * T * sdo,
+                     "moka_down_bwd": 3 * E * T * self.d_in * G, "moka_cross_fwd": 3 * 4 * T * r * G, "moka_cross_bwd": 3 * 4 * T * r * G}
 
 
 def build_workload(args, dev, lib, bucket_factory):
@@ -113,50 +132,51 @@ def build_workload(args, dev, lib, bucket_factory):
     masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
     rt = MokaRouting.from_avt_masks(masks)
     RP = _lib.rank_pad(r)
-    bf = torch.bfloat16
+    bf, f32 = torch.bfloat16, torch.float32
+    width = lambda k: d if k == "d" else ff          # noqa: E731
 
-    # flat parameter / gradient buckets (fp32 master, bf16 working copy, fp32 grads x2 for overlap)
-    per_layer = sum(M * r * (d if di == "d" else ff) + r * (d if do == "d" else ff) for _, di, do, _ in PROJS)
+    # flat parameter / gradient buckets (fp32 master, bf16 working copy, fp32 grads)
+    per_layer = sum(M * r * width(di) + r * width(do) for _, di, do, _ in PROJS)
     n_params = per_layer * L
     bucket = bucket_factory(n_params, [per_layer * (l + 1) for l in range(L)])
     gbuf = bucket.flat
-    master = torch.empty(n_params, dtype=torch.float32, device=dev)
+    master = torch.empty(n_params, dtype=f32, device=dev)
     work = torch.empty(n_params, dtype=bf, device=dev)
 
-    # activation buffers: `args.distinct` layer sets cycled (each set >> 256 MiB Infinity Cache)
+    # activation buffers: `args.distinct` layer sets cycled (each set >> 256 MiB Infinity Cache).  Projections fed
+    # by the same tensor (q/k/v <- hid, gate/up <- hid2) share ONE input and ONE input-gradient buffer, as in the
+    # decoder (autograd sums their dx).
     nset = max(1, min(L, args.distinct))
     sets = []
     for _ in range(nset):
-        acts = {"hid": torch.randn(T, d, device=dev, dtype=bf), "attn": torch.randn(T, d, device=dev, dtype=bf),
-                "hid2": torch.randn(T, d, device=dev, dtype=bf), "act": torch.randn(T, ff, device=dev, dtype=bf)}
-        ys = [torch.randn(T, d if do == "d" else ff, device=dev, dtype=bf) for _, _, do, _ in PROJS]
-        dxs = [torch.randn(T, d if di == "d" else ff, device=dev, dtype=bf) for _, di, _, _ in PROJS]
-        sets.append((acts, ys, dxs))
+        acts = {k: torch.randn(T, width(wk), device=dev, dtype=bf) for k, wk in (("hid", "d"), ("attn", "d"), ("hid2", "d"), ("act", "ff"))}
+        dacts = {k: torch.randn(T, width(wk), device=dev, dtype=bf) for k, wk in (("hid", "d"), ("attn", "d"), ("hid2", "d"), ("act", "ff"))}
+        ys = [torch.randn(T, width(do), device=dev, dtype=bf) for _, _, do, _ in PROJS]
+        sets.append((acts, dacts, ys))
     Tp = _lib.tok_pad(T)
     max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r))
-    f32 = torch.float32
-    # scratch shared by all projections (consumed before the next projection overwrites it)
-    part = torch.empty(max_ks, T, RP, dtype=f32, device=dev)
-    hp_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
-    dh_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
-    dh_kmj = torch.empty(M, 2, RP, Tp, dtype=bf, device=dev)
-    # saved forward -> backward, one set per projection: h (fp32), the rank-major hp pack, BwT
-    saved = [[(torch.empty(T, RP, dtype=f32, device=dev), torch.empty(2, RP, Tp, dtype=bf, device=dev),
-               torch.empty(RP, d if do == "d" else ff, dtype=bf, device=dev),
-               torch.empty(M, d if di == "d" else ff, RP, dtype=bf, device=dev)) for _, di, do, _ in PROJS] for _ in range(L)]
-    ws = None
-    hh = saved
+    # scratch shared by all units (consumed before the next unit overwrites it), one slot per group member
+    scratch = [dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
+                    dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
+               for _ in range(3)]
+
+    # units = maximal runs of projections with the same input (--no-group: every projection alone)
+    unit_defs = []
+    for pi, (name, di, do, src) in enumerate(PROJS):
+        if unit_defs and not args.no_group and unit_defs[-1][0] == src and len(unit_defs[-1][1]) < 3:
+            unit_defs[-1][1].append(pi)
+        else:
+            unit_defs.append((src, [pi]))
 
     s = 16.0 / r
-    projs = []
-    layer_end = []
+    units, layer_end, keep = [], [], []
     off = 0
     bound = lambda n: 1.0 / math.sqrt(n)  # noqa: E731  kaiming_uniform(a=sqrt(5))
     for l in range(L):
-        acts, ys, dxs = sets[l % nset]
+        acts, dacts, ys = sets[l % nset]
+        members = []
         for pi, (name, di, do, src) in enumerate(PROJS):
-            d_in = d if di == "d" else ff
-            d_out = d if do == "d" else ff
+            d_in, d_out = width(di), width(do)
             A, dA = [], []
             for m in range(M):
                 n = r * d_in
@@ -169,16 +189,20 @@ def build_workload(args, dev, lib, bucket_factory):
             Bw = work[off:off + n].view(d_out, r)
             dB = gbuf[off:off + n].view(d_out, r)
             off += n
-            h, hp_kmj, BwT, AT = saved[l][pi]
-            wsl = (part, h, hp_tok, hp_kmj, BwT, AT, dh_tok, dh_kmj)
-            projs.append(Proj(lib, name, d_in, d_out, r, M, T, (acts[src], ys[pi], dxs[pi]), (A, Bw), (dA, dB), wsl, rt,
-                              s, [1.0] * M, 1.0, 1.0 / math.sqrt(r), drop_p=args.dropout, seed=1000003 * l + pi))
+            # saved forward -> backward, per projection: h (fp32), the rank-major hp pack, the weight shadows
+            members.append(dict(name=name, d_in=d_in, d_out=d_out, A=A, dA=dA, Bw=Bw, dB=dB, y=ys[pi],
+                                h=torch.empty(T, RP, dtype=f32, device=dev), hp_kmj=torch.empty(2, RP, Tp, dtype=bf, device=dev),
+                                BwT=torch.empty(RP, d_out, dtype=bf, device=dev), AT=torch.empty(M, d_in, RP, dtype=bf, device=dev)))
+        for src, pis in unit_defs:
+            mem = [members[pi] for pi in pis]
+            units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch,
+                              s, [1.0] * M, 1.0, 1.0 / math.sqrt(r), args.dropout, [1000003 * l + pi for pi in pis]))
         layer_end.append(off)
     assert off == n_params
     work.copy_(master)
     assert layer_end == bucket.layer_end
-    return dict(projs=projs, rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end,
-                keep=(sets, saved, masks, part, hp_tok, dh_tok, dh_kmj))
+    return dict(units=units, units_per_layer=len(unit_defs), rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T,
+                n_params=n_params, layer_end=layer_end, keep=(sets, masks, scratch))
 
 
 ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
@@ -189,8 +213,7 @@ LIVE = ("moka_up_fwd",)     # the dominant single-kernel entry point, bracketed 
 
 class Recorder:
     """HIP-event brackets around launches on the launch stream.  `only` limits which entry points are
-    bracketed (bracketing all 1344 launches of a step makes the host the bottleneck and distorts the
-    headline; the two single-kernel entry points cost ~450 event records per step)."""
+    bracketed (bracketing every launch of a step makes the host the bottleneck and distorts the headline)."""
 
     def __init__(self, only=None):
         self.only, self.items, self.pool = only, [], []
@@ -202,63 +225,36 @@ class Recorder:
         self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(n))
 
 
-def _call(lib, name, args, sp, rec, p):
-    """Launch one entry point; bracket it with HIP events when the recorder asks for it."""
+def _call(lib, name, u, sp, rec):
+    """Launch one entry point of unit `u`; bracket it with HIP events when the recorder asks for it."""
+    sym, args = u.calls[name]
     if rec is None or (rec.only is not None and name not in rec.only):
-        rc = getattr(lib, name)(*args, sp)
+        rc = getattr(lib, sym)(*args, sp)
     else:
         e0, e1 = rec.event(), rec.event()
         e0.record()
-        rc = getattr(lib, name)(*args, sp)
+        rc = getattr(lib, sym)(*args, sp)
         e1.record()
-        rec.items.append((name, p.d_in, p.d_out, e0, e1))
+        rec.items.append((name, u, e0, e1))
     if rc:
         raise RuntimeError(lib.moka_last_error().decode())
 
 
 def run_forward(lib, wl, sp, rec=None):
-    for p in wl["projs"]:
-        _call(lib, "moka_down_fwd", p.f1, sp, rec, p)
-        _call(lib, "moka_cross_fwd", p.f2, sp, rec, p)
-        _call(lib, "moka_up_fwd", p.f3, sp, rec, p)
+    for u in wl["units"]:
+        _call(lib, "moka_down_fwd", u, sp, rec)
+        _call(lib, "moka_cross_fwd", u, sp, rec)
+        _call(lib, "moka_up_fwd", u, sp, rec)
 
 
-class SideStream:
-    """Experiment (--side-stream): second HIP stream for the weight-gradient kernels of the backward: dB runs
-    beside gy.Bw -> cross backward, dA beside dx, joined with the main stream at the end of every projection.
-    Measured on MI355X: 150.1 k vs 152.5 k tokens/s without -- every kernel already fills all CUs, so a
-    second queue only adds contention.  Kept for re-measurement, off by default."""
-
-    def __init__(self, dev, n_proj):
-        self.stream = torch.cuda.Stream(device=dev)
-        self.sp = c_void_p(self.stream.cuda_stream)
-        self.ev = [[torch.cuda.Event() for _ in range(3)] for _ in range(n_proj)]
-
-
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, side=None):
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None):
     """Reverse layer order; `on_layer_done(l)` fires after layer l's launches are enqueued."""
-    projs = wl["projs"]
-    per = len(PROJS)
-    main = torch.cuda.current_stream()
+    units, per = wl["units"], wl["units_per_layer"]
     for l in range(n_layers - 1, -1, -1):
-        for k, p in enumerate(reversed(projs[l * per:(l + 1) * per])):
-            if side is None:
-                _call(lib, "moka_up_bwd", p.b1, sp, rec, p)
-                _call(lib, "moka_cross_bwd", p.b2, sp, rec, p)
-                _call(lib, "moka_down_bwd", p.b3, sp, rec, p)
-                continue
-            e_start, e_dh, e_done = side.ev[l * per + k]
-            e_start.record(main)                     # everything before this projection (zeroed grads, buffers free)
-            side.stream.wait_event(e_start)
-            _call(lib, "moka_up_bwd", p.b1w, side.sp, None, p)          # dB            (side)
-            _call(lib, "moka_up_bwd", p.b1g, sp, rec, p)                # gy.Bw         (main)
-            _call(lib, "moka_cross_bwd", p.b2, sp, rec, p)
-            e_dh.record(main)
-            side.stream.wait_event(e_dh)
-            _call(lib, "moka_down_bwd", p.b3w, side.sp, None, p)        # dA            (side)
-            _call(lib, "moka_down_bwd", p.b3x, sp, rec, p)              # dx            (main)
-            e_done.record(side.stream)
-            main.wait_event(e_done)
+        for u in reversed(units[l * per:(l + 1) * per]):
+            _call(lib, "moka_up_bwd", u, sp, rec)
+            _call(lib, "moka_cross_bwd", u, sp, rec)
+            _call(lib, "moka_down_bwd", u, sp, rec)
         if on_layer_done is not None:
             on_layer_done(l)
 
@@ -348,8 +344,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
-    ap.add_argument("--side-stream", action="store_true",
-                    help="experiment: weight-gradient kernels on a second HIP stream (measured: no gain, the kernels fill the chip)")
+    ap.add_argument("--no-group", action="store_true",
+                    help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -382,15 +378,14 @@ def main():
         opt = torch.optim.AdamW([mp], lr=1e-4, fused=True)
     L = args.layers
 
-    side = SideStream(dev, len(wl["projs"])) if args.side_stream else None
     records = Recorder(only=LIVE)
-    records.reserve(2 * len(wl["projs"]) * args.steps + 16)
+    records.reserve(2 * len(wl["units"]) * args.steps + 16)
 
     def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
         bucket.zero_()                               # same stream as the previous optimizer step
         run_forward(lib, wl, sp, rec)
-        run_backward(lib, wl, sp, L, bucket.layer_done, rec, side)   # all-reduce of finished layer groups overlaps the rest
+        run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
         bucket.finish(average=True)
         if opt is not None:
             opt.step()
@@ -422,55 +417,57 @@ def main():
         fwd_b, bwd_b = algorithmic_bytes_per_token(LLAMA7B["d"], LLAMA7B["ff"], args.rank, args.layers)
         algo_gbs = (fwd_b + bwd_b) * T / (ms_per_step * 1e-3) / 1e9
         # per-launch durations from the HIP events recorded on the launch stream inside the timed region
-        d_, ff_, r_ = LLAMA7B["d"], LLAMA7B["ff"], args.rank
         def collect(items):
             tot = {n: 0.0 for n in ENTRY}
             cnt = {n: 0 for n in ENTRY}
+            byt = {n: 0 for n in ENTRY}
             per_shape = {}
-            for n, di, do, e0, e1 in items:
+            for n, u, e0, e1 in items:
                 ms = e0.elapsed_time(e1)
                 tot[n] += ms
                 cnt[n] += 1
-                a_, b_ = per_shape.get((n, di, do), (0.0, 0))
-                per_shape[(n, di, do)] = (a_ + ms, b_ + 1)
-            return tot, cnt, per_shape
-        tot, cnt, per_shape = collect(records.items)              # live: the timed steps (LIVE entry points)
+                byt[n] += u.algo[n]
+                key = (n, u.label, u.d_in, tuple(u.d_outs))
+                a_, b_, _ = per_shape.get(key, (0.0, 0, 0))
+                per_shape[key] = (a_ + ms, b_ + 1, u.algo[n])
+            return tot, cnt, byt, per_shape
+        tot, cnt, byt, per_shape = collect(records.items)         # live: the timed steps (LIVE entry points)
         # every entry point, in one extra untimed pass (full bracketing would perturb the timed region)
         extra = Recorder()
         sp_ = c_void_p(torch.cuda.current_stream().cuda_stream)
         run_forward(lib, wl, sp_, extra)
         run_backward(lib, wl, sp_, L, None, extra)
         torch.cuda.synchronize()
-        tot_x, cnt_x, per_shape_x = collect(extra.items)
-        # algorithmic bytes per launch of each entry point (SURVEY 8(d) split by kernel):
-        #   down_fwd: read x                 E*T*d_in      up_fwd : read+write y      2*E*T*d_out
-        #   up_bwd  : read gy                E*T*d_out     down_bwd: read x, r+w dx   3*E*T*d_in
-        def algo(n, di, do):
-            return {"moka_down_fwd": E * T * di, "moka_up_fwd": 2 * E * T * do, "moka_up_bwd": E * T * do,
-                    "moka_down_bwd": 3 * E * T * di, "moka_cross_fwd": 3 * 4 * T * r_, "moka_cross_bwd": 3 * 4 * T * r_}[n]
+        tot_x, cnt_x, _, per_shape_x = collect(extra.items)
         table = {}
-        for (n, di, do), (ms, c_) in sorted(per_shape_x.items()):
+        for (n, label, di, dos), (ms, c_, nb) in sorted(per_shape_x.items()):
             avg = ms / c_
-            table[f"{n}[{di}->{do}]"] = {"avg_ms": round(avg, 4), "algo_GBps": round(algo(n, di, do) / (avg * 1e-3) / 1e9, 1)}
-        # the dominant kernel: largest total time among the entry points that are ONE kernel launch
-        # (moka_down_fwd -> moka_reduce_kernel, moka_up_fwd -> moka_expand_kernel<.., true>)
+            table[f"{n}[{label}: {di}->{'/'.join(str(v) for v in dos)}]"] = {"avg_ms": round(avg, 4), "algo_GBps": round(nb / (avg * 1e-3) / 1e9, 1)}
+        # the dominant kernel: the largest entry point of a pass that is ONE kernel launch
+        # (moka_up_fwd -> moka_expand_kernel<.., true>; grouped units run their members in one launch, grid z)
         single = {"moka_up_fwd": "moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
-        dom = "moka_up_fwd"       # largest single-kernel entry point of a pass (see entry_point_ms_per_pass)
-        dom_bytes = sum(algo(n, di, do) * c_ for (n, di, do), (ms, c_) in per_shape.items() if n == dom)
+        dom = "moka_up_fwd"
+        dom_bytes = byt[dom]
         dom_avg_ms = tot[dom] / cnt[dom]
         achieved = dom_bytes / cnt[dom] / (dom_avg_ms * 1e-3) / 1e9
         traffic = None
-        tr = [(pmc_traffic_bytes(n, do if n == "moka_up_fwd" else di, T), c_) for (n, di, do), (ms, c_) in per_shape.items() if n == dom]
-        if tr and all(t_ is not None for t_, _ in tr) and args.seq == 2048:
-            traffic = round(sum(t_ * c_ for t_, c_ in tr) / sum(c_ for _, c_ in tr))
+        if args.seq == 2048:
+            tr = 0.0
+            for n, u, e0, e1 in records.items:
+                if n == dom:
+                    tr += sum(pmc_traffic_bytes(n, do, T) or float("nan") for do in u.d_outs)
+            if tr == tr:
+                traffic = round(tr / cnt[dom])
         out = {
             "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline",
             "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Llama-2-7B dims, MokA r=16 M=3 (AVT semantics), adapter fwd+bwd of 7x%d projections, "
-                                   "seq=2048 (256 image + 128 audio + 64 question + text), lora_dropout %g, batch %d seq/GPU, "
-                                   "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params" % (args.layers, args.dropout, args.batch),
+                                   "seq=2048 (256 image + 128 audio + 64 question + text), lora_dropout %g, batch %d seq/GPU, %s, "
+                                   "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params"
+                                   % (args.layers, args.dropout, args.batch,
+                                      "one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points"),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),

@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "moka_hip.h"
 
@@ -167,7 +168,9 @@ struct ReduceArgs {
 //   G == 1: blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems (batched launch).
 //   G  > 1: G projections share the input (q/k/v, gate/up): every x fragment is loaded once and
 //           multiplied with the G weight sets (each with its own dropout mask).
-template <int RP, int NW, int U, int G>
+//   MIX == false: shared weights (gy.Bw) -- a tile never needs more than one weight set, so the
+//           two-modality paths (and their registers) are compiled out.
+template <int RP, int NW, int U, int G, bool MIX>
 __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
@@ -196,34 +199,9 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
             }
         }
     };
-    auto issue_w1 = [&](bf16x8 (&wb)[U][NT], int s, int gi, int m) {
-        const unsigned char* W = a.W[G == 1 ? z : gi][m];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (s + u < s_end) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    // rank rows >= r do not exist: clamp the row, its products are zeroed at the end
-                    const int krow = min(nt * 16 + i, a.r - 1);
-                    wb[u][nt] = *(const bf16x8*)(W + ((size_t)krow * C + 8 * g) * 2 + (size_t)(s + u) * 64);
-                }
-            }
-        }
-    };
-    // Weight fragments of the tile's first modality travel with the x batch; the other modalities of a
-    // tile that straddles a span boundary are fetched on demand.  (Measured: prefetching a second set
-    // unconditionally costs 7 % on single-modality tiles -- the weight fragments are 1 KB of L2 traffic
-    // per 2 KB of x -- and conditionally issued loads make the vmcnt bookkeeping conservative, so the
-    // ~3 % boundary tiles run ~14 % longer either way.)
-    int mfirst = 0;
-    auto issue_w = [&](bf16x8 (&wb)[G][U][NT], int s) {
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) issue_w1(wb[gi], s, gi, mfirst);
-    };
-
     // The x stream does not depend on the routing: issue the first batch right away, the tok_mod
     // bytes (which only select the weight rows / the skip) arrive underneath it.
-    bf16x8 xA[U][2], xB[U][2], wA[G][U][NT], wB[G][U][NT];
+    bf16x8 xA[U][2], xB[U][2];
     issue_x(xA, s_begin);
     int mrow2[2];
     unsigned mods4[2];                                    // modalities of my 4 result rows
@@ -242,57 +220,124 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
     }
     const unsigned pany = pres[0] | pres[1];
     if (pany == 0) return;                                // padding tile (its speculative first batch is the only waste)
-    mfirst = __builtin_ctz(pany);
-    issue_w(wA, s_begin);
 
-    f32x4 acc[G][2][MOKA_MAX_MOD][NT];
+    // ONE accumulator per sub-tile: MFMA rows are tokens, so in a sub-tile that straddles a span
+    // boundary the chain of modality m runs with the rows of the other modalities zeroed in the x
+    // operand and every result row only ever receives its own modality's product.
+    f32x4 acc[G][2][NT];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int m = 0; m < MOKA_MAX_MOD; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[gi][st][m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) acc[gi][st][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto consume = [&](bf16x8 (&xb)[U][2], bf16x8 (&wb)[G][U][NT], int s) {
+    auto mfma_step = [&](int gi, int st, int s1, bf16x8 xg, const bf16x8 (&w)[NT], int m, bool mask_rows) {
+        if (a.drop[gi].thr) {                                     // wave uniform; every projection has its own mask
+            const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
+            xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(C >> 3) + (unsigned)(s1 * 4 + g)));
+        }
+        if (mask_rows) {                                          // mixed sub-tile: my row (token i) only counts in its own chain
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            xg = (mrow2[st] == m) ? xg : z8;
+        }
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
+        for (int nt = 0; nt < NT; ++nt) acc[gi][st][nt] = MFMA16(xg, w[nt], acc[gi][st][nt]);
+    };
+
+    // The software-pipelined stream over this wave's K steps for a tile with NS (1 or 2) modalities.
+    // Two batches in flight: x (HBM latency) and, travelling with it, the weight fragments of all NS
+    // modalities (L2; measured: issuing them only one batch ahead exposes the loaded L2 latency and costs
+    // 15-40 %).  Every load of the loop is unconditional: a conditionally issued load
+    // makes the compiler's vmcnt bookkeeping conservative and serialises the batches -- and the kernel
+    // ends with its slowest block, i.e. with the tiles that straddle a span boundary.  One code path per
+    // NS keeps the common single-modality loop small (instruction cache).
+    auto stream = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        int mods[NS];
+        mods[0] = __builtin_ctz(pany);
+        if (NS > 1) mods[NS - 1] = __builtin_ctz(pany & (pany - 1));
+        const unsigned char* wp[NS][G][NT];                       // per-lane fragment addresses
+        bf16x8 wA[NS][G][U][NT], wB[NS][G][U][NT];
 #pragma unroll
-            for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-                if (!(pany & (1u << m))) continue;
-                bf16x8 wx[U][NT];
-                if (m != mfirst) issue_w1(wx, s, gi, m);          // span boundary inside the tile (rare)
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)   // rank rows >= r do not exist: clamp the row, its products are zeroed at the end
+                    wp[k][gi][nt] = a.W[G == 1 ? z : gi][mods[k]] + ((size_t)min(nt * 16 + i, a.r - 1) * C + 8 * g) * 2;
+        auto issue_w = [&](bf16x8 (&w)[NS][G][U][NT], int s) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (s + u < s_end) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) w[k][gi][u][nt] = *(const bf16x8*)(wp[k][gi][nt] + (size_t)(s + u) * 64);
+                        }
+                    }
+        };
+        auto consume = [&](bf16x8 (&xb)[U][2], bf16x8 (&w)[NS][G][U][NT], int s) {
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (s + u < s_end) {
 #pragma unroll
-                        for (int st = 0; st < 2; ++st) {
-                            if (pres[st] & (1u << m)) {
-                                bf16x8 xg = xb[u][st];
-                                if (a.drop[gi].thr) {             // wave uniform; every projection has its own mask
-                                    const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
-                                    xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(C >> 3) + (unsigned)((s + u) * 4 + g)));
-                                }
+                        for (int st = 0; st < 2; ++st)
 #pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[gi][st][m][nt] = MFMA16(xg, (m == mfirst) ? wb[gi][u][nt] : wx[u][nt], acc[gi][st][m][nt]);
+                            for (int k = 0; k < NS; ++k) {
+                                const unsigned bit = 1u << mods[k];
+                                if (pres[st] & bit) mfma_step(gi, st, s + u, xb[u][st], w[k][gi][u], mods[k], NS > 1 && pres[st] != bit);
                             }
-                        }
                     }
                 }
-            }
+        };
+        issue_w(wA, s_begin);
+        for (int s = s_begin; s < s_end;) {
+            if (s + U < s_end) { issue_x(xB, s + U); issue_w(wB, s + U); }
+            consume(xA, wA, s);
+            s += U;
+            if (s >= s_end) break;
+            if (s + U < s_end) { issue_x(xA, s + U); issue_w(wA, s + U); }
+            consume(xB, wB, s);
+            s += U;
         }
     };
 
-    for (int s = s_begin; s < s_end;) {
-        if (s + U < s_end) { issue_x(xB, s + U); issue_w(wB, s + U); }
-        consume(xA, wA, s);
-        s += U;
-        if (s >= s_end) break;
-        if (s + U < s_end) { issue_x(xA, s + U); issue_w(wA, s + U); }
-        consume(xB, wB, s);
-        s += U;
+    const int nmods = __builtin_popcount(pany);
+    if (!MIX || nmods == 1) {
+        stream(std::integral_constant<int, 1>{});
+    } else if (nmods == 2) {
+        stream(std::integral_constant<int, 2>{});
+    } else {
+        // three modalities inside one 32-token tile (needs two spans shorter than 32 tokens): plain loop
+#pragma unroll 1
+        for (int s = s_begin; s < s_end; ++s) {
+            bf16x8 x2[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) x2[st] = (s == s_begin) ? xA[0][st] : *(const bf16x8*)(xrow[st] + (size_t)s * 64);
+#pragma unroll 1
+            for (int gi = 0; gi < G; ++gi) {
+#pragma unroll 1
+                for (int m = 0; m < a.M; ++m) {
+                    bf16x8 w[NT];
+                    const unsigned char* W = a.W[G == 1 ? z : gi][m];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        w[nt] = *(const bf16x8*)(W + ((size_t)min(nt * 16 + i, a.r - 1) * C + 8 * g) * 2 + (size_t)s * 64);
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+                        if (pres[st] & (1u << m)) {
+#pragma unroll
+                            for (int gj = 0; gj < G; ++gj)        // gi is a run-time index here
+                                if (gj == gi) mfma_step(gj, st, s, x2[st], w, m, pres[st] != (1u << m));
+                        }
+                }
+            }
+        }
     }
 
     // select per row, scale, and reduce the NW partial tiles through LDS
@@ -307,15 +352,8 @@ __global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int mr = (mods4[st] >> (8 * reg)) & 255;
-                    float v = 0.f;
-                    if (a.shared_w) {
-                        v = acc[gi][st][0][nt][reg] * mod_scale(a.s_mod, mr);
-                    } else {
-                        if (mr == 0) v = acc[gi][st][0][nt][reg] * a.s_mod[0];
-                        else if (mr == 1) v = acc[gi][st][1][nt][reg] * a.s_mod[1];
-                        else if (mr == 2) v = acc[gi][st][2][nt][reg] * a.s_mod[2];
-                    }
-                    if (nt * 16 + i >= a.r) v = 0.f;      // padded rank columns
+                    float v = acc[gi][st][nt][reg] * mod_scale(a.s_mod, mr);        // 0 for rows of no modality
+                    if (mr >= a.M || nt * 16 + i >= a.r) v = 0.f;                   // padding rows, padded rank columns
                     red[gi * REDSZ + (((wave * 2 + st) * NT + nt) << 8) + ((4 * g + reg) << 4) + i] = v;
                 }
     __syncthreads();
@@ -1215,25 +1253,29 @@ static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     return MOKA_OK;
 }
 
-template <int RP, int NW, int U, int G>
+template <int RP, int NW, int U, int G, bool MIX>
 static void launch_reduce_t(const ReduceArgs& a, int nz, hipStream_t st) {
     const size_t lds = (size_t)G * NW * 2 * (RP / 16) * 256 * 4;
     dim3 grid((a.T + 31) / 32, a.ks, nz), block(NW * 64);
-    ensure_lds((const void*)moka_reduce_kernel<RP, NW, U, G>, lds);
-    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U, G>), grid, block, lds, st, a);
+    ensure_lds((const void*)moka_reduce_kernel<RP, NW, U, G, MIX>, lds);
+    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U, G, MIX>), grid, block, lds, st, a);
 }
 
 // G > 1: shared-input group (RP == 16 only, see can_group); G == 1: nz batched problems
 static int launch_reduce(const ReduceArgs& a, int RP, int G, int nz, hipStream_t st) {
     if (RP == 16) {
         const int nw = g_tune_reduce_nw == 8 ? 8 : 4, u = g_tune_reduce_u == 4 ? 4 : 2;
-        if (G == 3) launch_reduce_t<16, 4, 2, 3>(a, 1, st);
-        else if (G == 2) launch_reduce_t<16, 4, 2, 2>(a, 1, st);
-        else if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4, 1>(a, nz, st); else launch_reduce_t<16, 4, 2, 1>(a, nz, st); }
-        else { if (u == 4) launch_reduce_t<16, 8, 4, 1>(a, nz, st); else launch_reduce_t<16, 8, 2, 1>(a, nz, st); }
+        if (G == 3) launch_reduce_t<16, 4, 2, 3, true>(a, 1, st);
+        else if (G == 2) launch_reduce_t<16, 4, 2, 2, true>(a, 1, st);
+        else if (a.shared_w) {
+            if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4, 1, false>(a, nz, st); else launch_reduce_t<16, 4, 2, 1, false>(a, nz, st); }
+            else { if (u == 4) launch_reduce_t<16, 8, 4, 1, false>(a, nz, st); else launch_reduce_t<16, 8, 2, 1, false>(a, nz, st); }
+        } else {
+            if (nw == 4) launch_reduce_t<16, 4, 2, 1, true>(a, nz, st); else launch_reduce_t<16, 8, 2, 1, true>(a, nz, st);
+        }
     }
-    else if (RP == 32) launch_reduce_t<32, 8, 2, 1>(a, nz, st);
-    else launch_reduce_t<64, 8, 1, 1>(a, nz, st);
+    else if (RP == 32) { if (a.shared_w) launch_reduce_t<32, 8, 2, 1, false>(a, nz, st); else launch_reduce_t<32, 8, 2, 1, true>(a, nz, st); }
+    else { if (a.shared_w) launch_reduce_t<64, 8, 1, 1, false>(a, nz, st); else launch_reduce_t<64, 8, 1, 1, true>(a, nz, st); }
     return check_launch("moka_reduce_kernel");
 }
 
@@ -1293,7 +1335,7 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     for (int z = 0; z < (G == 1 ? nz : 1); ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
     const int nc = (Cmax + CW - 1) / CW;
     const int ntiles = (ab.z[0].T + 15) / 16;
-    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (Cmax > 8192 ? 8 : 4);
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : ((Cmax > 8192 || nz > 1) ? 8 : 4);
     int gy = (bpc * num_cu() + nc * nz - 1) / (nc * nz);   // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
