@@ -45,11 +45,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                                   // RNE
-    return (unsigned short)(u >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+static __device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {       // two results packed in one dword
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2));
 }
 static __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
@@ -920,21 +924,33 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (c_wave + 32 * q >= a.C) continue;
-                KeepMask keep = {{~0u, ~0u, ~0u, ~0u}};
+                // element e of my 16-byte chunk = d[q][e >> 2][e & 3]; dropout keeps it iff its 16-bit mask field is set:
+                // the field is sign-extended to a dword mask and ANDed onto the fp32 product (3 VALU ops per element)
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = d[q][e >> 2][e & 3];
                 float dsc = 1.f;
                 if (ag.drop.thr) {
-                    keep = drop_keep8(ag.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
+                    const KeepMask keep = drop_keep8(ag.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
                     dsc = ag.drop.inv_keep;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
+                        v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
+                        v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
+                    }
                 }
                 if constexpr (G == 1) {
-                    bf16x8 res;
+                    union { bf16x8 b; unsigned u[4]; } ou, res;
+                    ou.b = o[q];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + (drop_kept(keep, e) ? d[q][e >> 2][e & 3] * dsc : 0.f));
-                    if (valid) *(bf16x8*)(orow + 64 * q) = res;
+                    for (int w2 = 0; w2 < 4; ++w2)
+                        res.u[w2] = f2bf_pk(fmaf(v[2 * w2], dsc, __uint_as_float(ou.u[w2] << 16)),
+                                            fmaf(v[2 * w2 + 1], dsc, __uint_as_float(ou.u[w2] & 0xffff0000u)));
+                    if (valid) *(bf16x8*)(orow + 64 * q) = res.b;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sum[q][e] += drop_kept(keep, e) ? d[q][e >> 2][e & 3] * dsc : 0.f;
+                    for (int e = 0; e < 8; ++e) sum[q][e] = fmaf(v[e], dsc, sum[q][e]);
                 }
             }
         }
@@ -942,10 +958,12 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (c_wave + 32 * q >= a.C) continue;
-                bf16x8 res;
+                union { bf16x8 b; unsigned u[4]; } ou, res;
+                ou.b = o[q];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) res[e] = (short)f2bf(bf2f((unsigned short)o[q][e]) + sum[q][e]);
-                if (valid) *(bf16x8*)(orow + 64 * q) = res;
+                for (int w2 = 0; w2 < 4; ++w2)
+                    res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[q][2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[q][2 * w2 + 1]);
+                if (valid) *(bf16x8*)(orow + 64 * q) = res.b;
             }
         }
     }
@@ -997,8 +1015,14 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     const int c_begin = blockIdx.x * CCB;
     if (c_begin >= a.C) return;                     // batched problems of different width (block uniform)
     unsigned char* my = smem + wave_all * REGION;
-    float* red = (float*)(smem + NW * G * REGION);  // [NW*G][CCB][RP]  per-wave partial sums
-    unsigned* touched = (unsigned*)(red + (size_t)NW * G * CCB * RP);
+    // per-wave partial sums for the final block reduction, stored in the order of the destination so that
+    // both the strided MFMA-result writes and the linear reads stay (nearly) free of LDS bank conflicts:
+    // dB [column][rank]; dA [rank][column] with a padded pitch (a 16-way conflict on the reads of the
+    // unpadded [column][rank] layout cost 7 us of a 29 us launch)
+    constexpr int RPITCH = OUT_CK ? RP : CCB + 1;
+    constexpr int RSZ = OUT_CK ? CCB * RP : RP * (CCB + 1);           // floats per wave
+    float* red = (float*)(smem + NW * G * REGION);  // [NW*G][RSZ]
+    unsigned* touched = (unsigned*)(red + (size_t)NW * G * RSZ);
     const int ngroups = a.Tp >> 5;
     const int grp_begin = blockIdx.y * a.groups_per_block;
     const int grp_end = min(ngroups, grp_begin + a.groups_per_block);
@@ -1113,14 +1137,22 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
     }
 
-    // ---- block reduction, one modality at a time through the private regions
+    // ---- block reduction, one modality at a time.  The per-wave partial tiles go through LDS; the barrier
+    // between "all partials written" and "sum them" only has to order LDS traffic (s_waitcnt lgkmcnt(0) +
+    // s_barrier): __syncthreads() would also wait for the fire-and-forget global atomics of the previous
+    // round, a full L2 round trip per modality (measured: 8.5 us of a 29 us dA launch).  Consecutive
+    // rounds alternate between two buffers (the wave's own, now idle, tile region and `red`), so one
+    // barrier per round is enough: round k+2 rewrites a buffer only after everybody passed barrier k+1.
     if (lane == 0 && ever) atomicOr(touched, ever);
     __syncthreads();
     const unsigned any = *touched;
-    float* mine = red + (size_t)wave_all * CCB * RP;
+    constexpr bool ALIAS = (size_t)RSZ * 4 <= (size_t)REGION;
+    int round = 0;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         if (!(any & (1u << m))) continue;                         // block uniform
+        const bool own = ALIAS && !(round & 1);
+        float* mine = own ? (float*)my : red + (size_t)wave_all * RSZ;
         // D[row = column c (4g+reg)][col = rank k (i)]
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb)
@@ -1130,8 +1162,9 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
-                        mine[(sb * 64 + ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = acc[m][sb][ct][nt][reg];
-        __syncthreads();
+                        mine[OUT_CK ? (sb * 64 + ct * 16 + 4 * g + reg) * RPITCH + nt * 16 + i
+                                    : (nt * 16 + i) * RPITCH + sb * 64 + ct * 16 + 4 * g + reg] = acc[m][sb][ct][nt][reg];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int e2 = tid; e2 < G * CCB * RP; e2 += NW * G * 64) {
             // consecutive threads -> consecutive addresses of the destination ([C][r] for dB, [r][C] for dA)
             const int ge = e2 / (CCB * RP), e = e2 - ge * (CCB * RP);
@@ -1141,10 +1174,14 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
             if (c >= a.C || k >= a.r) continue;
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) sum += red[((size_t)(ge * NW + w) * CCB + cl) * RP + k];
+            for (int w = 0; w < NW; ++w) {
+                const float* src = own ? (const float*)(smem + (size_t)(ge * NW + w) * REGION) : red + (size_t)(ge * NW + w) * RSZ;
+                sum += src[OUT_CK ? cl * RPITCH + k : k * RPITCH + cl];
+            }
             atomicAdd(ag.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), ag.drop.thr ? sum * ag.drop.inv_keep : sum);
         }
-        __syncthreads();
+        if (!ALIAS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // single buffer: reads done before the next round writes
+        ++round;
     }
 }
 
@@ -1195,7 +1232,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1371,7 +1408,7 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     const int gpb = (ngroups + nb - 1) / nb;
     for (int z = 0; z < nz; ++z) ab.z[z].groups_per_block = gpb;
     nb = (ngroups + gpb - 1) / gpb;
-    const size_t lds = (size_t)NW * G * 32 * 160 + (size_t)NW * G * CCB * RP * 4 + 64;
+    const size_t lds = (size_t)NW * G * 32 * 160 + (size_t)NW * G * (OUT_CK ? CCB * RP : RP * (CCB + 1)) * 4 + 64;
     ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>, lds);
     hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
 }
@@ -1382,6 +1419,7 @@ static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
     if (OUT_CK || nz == 1) {
         if (RP == 16) {
             if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK, 1>(ab, nz, st);
+            else if (g_tune_wgrad_nw == 4) launch_wgrad_t<16, 1, 4, OUT_CK, 1>(ab, nz, st);
             else launch_wgrad_t<16, 1, 8, OUT_CK, 1>(ab, nz, st);
         } else if (RP == 32) launch_wgrad_t<32, 1, 8, OUT_CK, 1>(ab, nz, st);
         else launch_wgrad_t<64, 1, 4, OUT_CK, 1>(ab, nz, st);
@@ -1411,6 +1449,7 @@ int moka_tune(const char* key, int value) {
     if (!key) return fail(MOKA_EINVAL, "moka_tune: null key");
     if (!strcmp(key, "reduce_nw")) g_tune_reduce_nw = value;
     else if (!strcmp(key, "reduce_u")) g_tune_reduce_u = value;
+    else if (!strcmp(key, "wgrad_nw")) g_tune_wgrad_nw = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
