@@ -847,80 +847,121 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     const int ntiles = (a.T + 15) >> 4;
     const size_t prow = (size_t)(2 * RP) * 2;                     // pack row bytes
     const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
-        const int t = (tile << 4) + i;                            // operand / result lanes: token = lane & 15
-        const bool valid = t < a.T;
-        const int mrow = a.tok_mod[t];
-        const int m0 = __builtin_amdgcn_readfirstlane(mrow);
-        const bool same = __all(mrow == m0);
-        if (same && m0 == MOKA_MOD_NONE) continue;
-        // B operand: my token's pack row.  RP == 16: K = 32 is [hi(16) | lo(16)] = elements 8g..8g+7 of the row.
+
+    // Two token tiles in flight per wave: while tile k is multiplied and stored, the routing byte, the
+    // pack rows and the in/out rows of tile k+1 are already on their way (HBM latency).  Every load of
+    // the prefetch is unconditional (the tile index is clamped), see the note on vmcnt in the reduce kernel.
+    struct Tile {
+        int mrow;
         bf16x8 bh[G][KH], bl[G][KH];
+        bf16x8 o[NQ];
+    };
+    auto issue = [&](Tile& R, int tile) {
+        const int tt = min(tile, ntiles - 1);
+        const int t = min((tt << 4) + i, a.T - 1);                // operand / result lanes: token = lane & 15
+        R.mrow = a.tok_mod[(tt << 4) + i];
+        // B operand: my token's pack row.  RP == 16: K = 32 is [hi(16) | lo(16)] = elements 8g..8g+7 of the row.
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const unsigned char* prp = (const unsigned char*)ab.z[G == 1 ? blockIdx.z : gi].pack + (size_t)min(t, a.T - 1) * prow;
+            const unsigned char* prp = (const unsigned char*)ab.z[G == 1 ? blockIdx.z : gi].pack + (size_t)t * prow;
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) {
                 if (RP == 16) {
-                    bh[gi][kh] = *(const bf16x8*)(prp + 16 * g);
-                    bl[gi][kh] = bh[gi][kh];
+                    R.bh[gi][kh] = *(const bf16x8*)(prp + 16 * g);
                 } else {
-                    bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
-                    bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+                    R.bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+                    R.bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
                 }
             }
         }
-        unsigned char* orow = a.out + ((size_t)min(t, a.T - 1) * a.C + c_wave + 8 * g) * 2;
-        bf16x8 o[NQ];
+        const unsigned char* orow = a.out + ((size_t)t * a.C + c_wave + 8 * g) * 2;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (c_wave + 32 * q < a.C) o[q] = *(const bf16x8*)(orow + 64 * q);
+            if (c_wave + 32 * q < a.C) R.o[q] = *(const bf16x8*)(orow + 64 * q);   // block-uniform condition
+    };
+
+    auto process = [&](Tile& R, int tile, Tile& N, int next_tile) {
+        const int t = (tile << 4) + i;
+        const bool valid = t < a.T;
+        const int mrow = R.mrow;
+        const int m0 = __builtin_amdgcn_readfirstlane(mrow);
+        const bool same = __all(mrow == m0);
+        if (same && m0 == MOKA_MOD_NONE) { issue(N, next_tile); return; }      // padding tile: nothing to add
+        unsigned char* orow = a.out + ((size_t)min(t, a.T - 1) * a.C + c_wave + 8 * g) * 2;
 
         float sum[NQ][8];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum[q][e] = 0.f;
-
+        f32x4 d[G][NQ][2];
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-            const ExpandArgs& ag = ab.z[G == 1 ? blockIdx.z : gi];
-            f32x4 d[NQ][2];
+        for (int gi = 0; gi < G; ++gi)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) d[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (W_CK || (same && m0 == 0)) {
-                // shared Bw (the modality scale is in the pack) / all-text tile: resident fragments
+                for (int p = 0; p < 2; ++p) d[gi][q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        auto chain = [&](int gi, const bf16x8 (&wf)[NQ][2][KH], bool mine) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int kh = 0; kh < KH; ++kh) {
+                        d[gi][q][p] = MFMA16(wf[q][p][kh], mine ? R.bh[gi][kh] : z8, d[gi][q][p]);
+                        if (RP != 16) d[gi][q][p] = MFMA16(wf[q][p][kh], mine ? R.bl[gi][kh] : z8, d[gi][q][p]);
+                    }
+        };
+        if (W_CK || (same && m0 == 0)) {
+            // shared Bw (the modality scale is in the pack) / all-text tile: resident fragments
+            issue(N, next_tile);
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) chain(gi, wf0[gi], true);
+        } else {
+            // a non-text or mixed tile of the dx pass: one chain per modality present, tokens of the other
+            // modalities masked out of the B operand.  The fragments of the first non-text modality are
+            // requested from the L2-resident shadow BEFORE the prefetch of the next tile goes out, so that
+            // waiting for them does not wait for HBM; a second non-text modality in one tile is rare.
+            unsigned pm = 0;
+#pragma unroll
+            for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+            const unsigned nontext = pm & ~1u;
+            const int mA = nontext ? __builtin_ctz(nontext) : 0;
+            bf16x8 wfx[G][NQ][2][KH];
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
-                        for (int kh = 0; kh < KH; ++kh) {
-                            d[q][p] = MFMA16(wf0[gi][q][p][kh], bh[gi][kh], d[q][p]);
-                            if (RP != 16) d[q][p] = MFMA16(wf0[gi][q][p][kh], bl[gi][kh], d[q][p]);
-                        }
-            } else {
-                // a non-text or mixed tile of the dx pass: one chain per modality present, tokens of the other
-                // modalities masked out of the B operand; non-text fragments come from the L2-resident shadow
+                        for (int kh = 0; kh < KH; ++kh) wfx[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[mA], q, p, kh);
+            issue(N, next_tile);
 #pragma unroll
-                for (int m = 0; m < MOKA_MAX_MOD; ++m) {
-                    if (m < a.M && __any(mrow == m)) {
-                        const bool mine = mrow == m;
+            for (int gi = 0; gi < G; ++gi) {
+                if (pm & 1u) chain(gi, wf0[gi], mrow == 0);
+                if (nontext) chain(gi, wfx[gi], mrow == mA);
+            }
+            const unsigned rest = nontext & (nontext - 1);
+            if (rest) {                                           // image AND audio tokens inside one 16-token tile
+                const int mB = __builtin_ctz(rest);
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q)
+                for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
-                            for (int p = 0; p < 2; ++p)
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                                for (int kh = 0; kh < KH; ++kh) {
-                                    const bf16x8 wv = (m == 0) ? wf0[gi][q][p][kh] : load_frag(ag.W[m], q, p, kh);
-                                    d[q][p] = MFMA16(wv, mine ? bh[gi][kh] : z8, d[q][p]);
-                                    if (RP != 16) d[q][p] = MFMA16(wv, mine ? bl[gi][kh] : z8, d[q][p]);
-                                }
-                    }
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int kh = 0; kh < KH; ++kh) wfx[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[mB], q, p, kh);
+                    chain(gi, wfx[gi], mrow == mB);
                 }
             }
+        }
+
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const ExpandArgs& ag = ab.z[G == 1 ? blockIdx.z : gi];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (c_wave + 32 * q >= a.C) continue;
@@ -928,7 +969,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
                 // the field is sign-extended to a dword mask and ANDed onto the fp32 product (3 VALU ops per element)
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = d[q][e >> 2][e & 3];
+                for (int e = 0; e < 8; ++e) v[e] = d[gi][q][e >> 2][e & 3];
                 float dsc = 1.f;
                 if (ag.drop.thr) {
                     const KeepMask keep = drop_keep8(ag.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
@@ -942,7 +983,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
                 }
                 if constexpr (G == 1) {
                     union { bf16x8 b; unsigned u[4]; } ou, res;
-                    ou.b = o[q];
+                    ou.b = R.o[q];
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2)
                         res.u[w2] = f2bf_pk(fmaf(v[2 * w2], dsc, __uint_as_float(ou.u[w2] << 16)),
@@ -959,13 +1000,22 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
             for (int q = 0; q < NQ; ++q) {
                 if (c_wave + 32 * q >= a.C) continue;
                 union { bf16x8 b; unsigned u[4]; } ou, res;
-                ou.b = o[q];
+                ou.b = R.o[q];
 #pragma unroll
                 for (int w2 = 0; w2 < 4; ++w2)
                     res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[q][2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[q][2 * w2 + 1]);
                 if (valid) *(bf16x8*)(orow + 64 * q) = res.b;
             }
         }
+    };
+
+    Tile TA, TB;
+    const int step = gridDim.y;
+    issue(TA, blockIdx.y);
+    for (int tile = blockIdx.y; tile < ntiles; tile += 2 * step) {
+        process(TA, tile, TB, tile + step);
+        if (tile + step >= ntiles) break;
+        process(TB, tile + step, TA, tile + 2 * step);
     }
 }
 
@@ -1372,7 +1422,7 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     for (int z = 0; z < (G == 1 ? nz : 1); ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
     const int nc = (Cmax + CW - 1) / CW;
     const int ntiles = (ab.z[0].T + 15) / 16;
-    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : ((Cmax > 8192 || nz > 1) ? 8 : 4);
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : ((Cmax > 8192 || (W_CK && nz > 1)) ? 8 : 2);
     int gy = (bpc * num_cu() + nc * nz - 1) / (nc * nz);   // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;

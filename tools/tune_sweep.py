@@ -109,7 +109,7 @@ def main():
             "down_fwd": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_fwd": [("expand_bpc", v) for v in (2, 4, 6, 8)],
-            "down_bwd(dx only)": [("expand_bpc", v) for v in (2, 3, 4)],
+            "down_bwd(dx only)": [("expand_bpc", v) for v in (2, 4, 8)],
             "up_bwd(g+dB)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2, 4)],
             "down_bwd(dA only)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2)],
             "cross_fwd": [("cross_rows", v) for v in (32, 16, 8)],
