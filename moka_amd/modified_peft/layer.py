@@ -195,6 +195,14 @@ class Linear(nn.Module, LoraLayer):
             raise NotImplementedError("moka_amd: per-sample `adapter_names` (mixed-batch LoRA) is outside the MokA path")
         if self.merged:
             return self.base_layer(x, *args, **kwargs)
+        W, bias, Bw, A, rt, spec = self._plan(x, my_text_mask, my_image_mask, question_mask)
+        return moka_linear(x, W, bias, Bw, A, rt, spec)
+
+    def _plan(self, x, my_text_mask, my_image_mask, question_mask, *args, **kwargs):
+        """(W, bias, Bw, [A_m], routing, spec) of the adapter path of this call (``layer.py:589-678``), or None when
+        the call takes one of the base-layer fallbacks.  Shared with the grouped decoder shim (``moka_amd/decoder.py``)."""
+        if self.disable_adapters or self.merged or kwargs.get("adapter_names") is not None:
+            return None
         base = self.get_base_layer()
         W = base.weight.T if self.fan_in_fan_out else base.weight
         A_t, A_i, B_t = self.lora_A["text"].weight, None, self.lora_B["text"].weight
@@ -210,12 +218,12 @@ class Linear(nn.Module, LoraLayer):
             A_i = self.lora_A["image"].weight
             rt = GLOBAL_ROUTING_CACHE.get("vt", [my_text_mask, my_image_mask, question_mask])
             spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r), dropout_p=p)
-            return moka_linear(x, W, base.bias, B_t, [A_t, A_i], rt, spec)
+            return (W, base.bias, B_t, [A_t, A_i], rt, spec)
         # masks None (cached decode steps): plain LoRA with the text adapter (layer.py:672-678)
         B_, S_ = (x.shape[0], x.shape[1]) if x.dim() == 3 else (1, x.shape[0])
         rt = GLOBAL_ROUTING_CACHE.plain(B_, S_, x.device, 1)
         spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r), dropout_p=p)
-        return moka_linear(x, W, base.bias, B_t, [A_t], rt, spec)
+        return (W, base.bias, B_t, [A_t], rt, spec)
 
     def __repr__(self) -> str:
         return "lora." + super().__repr__()

@@ -84,7 +84,9 @@ class Linear(nn.Linear, LoraLayer):
         Bw = self.lora_B0.weight
         return A, (Bw if Bw.dtype == dtype else Bw.to(dtype))
 
-    def forward(self, x: torch.Tensor, modality_mask: Optional[List[torch.Tensor]] = None):
+    def _plan(self, x: torch.Tensor, modality_mask: Optional[List[torch.Tensor]] = None):
+        """(W, bias, Bw, [A_m], routing, spec) of this call, or None when the layer produces no output
+        (``lora.py:532``).  Shared by ``forward`` and by the grouped decoder shim (``moka_amd/decoder.py``)."""
         method = self.loramethod or ""
         W = self.weight.T if self.fan_in_fan_out else self.weight
         A, Bw = self._adapter_weights(x.dtype)
@@ -92,13 +94,20 @@ class Linear(nn.Linear, LoraLayer):
         if "test" in method and x.size(1) == 1:
             # decode step: only the text adapter, no masks (lora.py:373-381)
             rt = GLOBAL_ROUTING_CACHE.plain(x.shape[0], x.shape[1], x.device, 1)
-            return moka_linear(x, W, self.bias, Bw, A[:1], rt,
-                               AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed))
+            return (W, self.bias, Bw, A[:1], rt,
+                    AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed))
         if "test" in method or "train" in method:
             # prefill / train: token-routed adapters + cross-modal interaction (lora.py:385-532)
             rt = GLOBAL_ROUTING_CACHE.get("avt", list(modality_mask[:4]))
-            return moka_linear(x, W, self.bias, Bw, A, rt, spec)
+            return (W, self.bias, Bw, A, rt, spec)
         return None                      # the reference falls off the end of forward (lora.py:532)
+
+    def forward(self, x: torch.Tensor, modality_mask: Optional[List[torch.Tensor]] = None):
+        plan = self._plan(x, modality_mask)
+        if plan is None:
+            return None
+        W, bias, Bw, A, rt, spec = plan
+        return moka_linear(x, W, bias, Bw, A, rt, spec)
 
 
 def mark_only_lora_as_trainable(model: nn.Module, bias: str = "none") -> None:

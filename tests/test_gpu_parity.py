@@ -465,3 +465,74 @@ def test_group_dx_against_fp64_oracle():
             assert rel(dA[g][m], dA_g[m]) < TOL_F32, f"dA[{g}][{m}]"
     assert rel(dx2, dxo.reshape(T, -1).to(bf)) < TOL_BF16          # the oracle's sum, rounded to bf16 once
     assert ulp_bf16_diff(dx2, dxo.reshape(T, -1).to(bf), operand=dmag.reshape(T, -1)) <= 1.0
+
+
+def _avt_block(dev, d, ff, seed):
+    """A Llama-shaped attention/MLP pair of adapted projections (AVT mirror), random non-zero lora_B."""
+    from moka_amd.peft_hyper import Linear
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(d_in, d_out):
+        m = Linear(d_in, d_out, r=(16, 16, 16), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.1,
+                   loramethod="train", bias=False)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(d_out, d_in, generator=g) * 0.02)
+            m.lora_B0.weight.copy_(torch.randn(d_out, 16, generator=g) * 0.02)
+        return m.to(dev, torch.bfloat16)
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = lin(d, d), lin(d, d // 2), lin(d, d // 2)
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = lin(d, ff), lin(d, ff), lin(ff, d)
+            self.act_fn = torch.nn.SiLU()
+
+    return Attn().to(dev), MLP().to(dev)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_decoder_shim_matches_per_projection_calls(train):
+    """moka_amd/decoder.py: q/k/v and gate/up through the grouped entry points against the reference's call pattern
+    (one module call per projection, AVT modeling_llama.py:222-224,326-328).  eval(): outputs bit-identical, all
+    parameter gradients equal up to fp32 summation order; train(): same under a fixed torch seed (the per-call dropout
+    seeds are drawn in the same order)."""
+    from moka_amd.decoder import MokaLlamaMLP, qkv_forward
+    dev = _dev()
+    cd = C.make_case_data("avt_r16_q")
+    c = cd.case
+    attn, mlp = _avt_block(dev, c.d_in, 3 * c.d_in // 2 // 32 * 32, 31)
+    shim = MokaLlamaMLP(mlp)
+    masks = [m.to(dev) for m in cd.masks]
+    x0 = cd.x.to(dev, torch.bfloat16)
+    for mod in (attn, mlp):
+        mod.train(train)
+
+    def run(grouped):
+        torch.manual_seed(77)
+        for p in list(attn.parameters()) + list(mlp.parameters()):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if grouped:
+            q, k, v = qkv_forward(attn, x, masks)
+            y = shim(x, masks)
+        else:
+            q, k, v = attn.q_proj(x, masks), attn.k_proj(x, masks), attn.v_proj(x, masks)
+            y = mlp.down_proj(mlp.act_fn(mlp.gate_proj(x, masks)) * mlp.up_proj(x, masks), masks)
+        loss = q.float().square().mean() + k.float().mean() + v.float().square().mean() + y.float().square().mean()
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in list(attn.named_parameters()) + list(mlp.named_parameters()) if p.grad is not None}
+        return (q, k, v, y), x.grad, grads
+
+    o1, dx1, g1 = run(False)
+    o2, dx2, g2 = run(True)
+    for a_, b_ in zip(o1, o2):
+        assert torch.equal(a_, b_)
+    assert set(g1) == set(g2) and len(g1) == 6 * 4
+    for n in g1:
+        if g1[n].float().norm().item() > 0:
+            assert rel(g2[n], g1[n]) < 4e-3, n                    # bf16 casts of fp32 sums in a different order
+    assert rel(dx2, dx1) < 1e-2
