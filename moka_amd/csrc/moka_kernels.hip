@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     constexpr int CT = 4;                           // 16-column tiles per 64-column sub-tile
     constexpr int CCB = NSB * 64;                   // columns per block
     constexpr int PITCH = 64 * 2 + 32;              // bytes per LDS row; odd multiple of 32
-    constexpr int REGION = 32 * PITCH;
+    constexpr int REGION = NSB * 32 * PITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
     const int gi = (G == 1) ? 0 : __builtin_amdgcn_readfirstlane(wave_all / NW);   // projection of this wave set
     const int wave = (G == 1) ? wave_all : wave_all - gi * NW;                        // token-run index inside the block
@@ -1105,30 +1105,32 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
             bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
         }
     };
-    // tile loads + the pack fragments of the group's first modality (the only one, except on span boundaries)
-    auto issue = [&](uint4 (&ld)[NSB][4], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp, unsigned pm) {
+    // tile loads + the pack fragments of the group's first modality (the only one, except on span boundaries).
+    // Always issued (group index clamped): a conditionally issued load makes the vmcnt bookkeeping
+    // conservative and the next wait would drain the prefetch as well.
+    const int grp_last = ngroups - 1;
+    auto issue = [&](uint4 (&ld)[NSB][4], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp_, unsigned pm) {
+        const int grp = min(grp_, grp_last);
         const int t0 = grp << 5;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const size_t rowoff = (size_t)min(t0 + 8 * u + lrow, a.T - 1) * a.C;
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
-                const int c = c_begin + sb * 64 + lcol * 8;
-                ld[sb][u] = make_uint4(0, 0, 0, 0);
-                if (c < a.C) ld[sb][u] = *(const uint4*)(a.in + (rowoff + c) * 2);
+                const int c = min(c_begin + sb * 64 + lcol * 8, a.C - 8);           // C % 32 == 0; columns >= C never reach the output
+                ld[sb][u] = *(const uint4*)(a.in + (rowoff + c) * 2);
             }
         }
-        load_pack(bh, bl, grp, __builtin_ctz(pm));
+        load_pack(bh, bl, grp, pm ? __builtin_ctz(pm) : 0);
     };
-    auto compute = [&](uint4 (&ld)[NSB][4], bf16x8 (&bh0)[NT], bf16x8 (&bl0)[NT], int grp, unsigned pm) {
+    // bhx / blx: pack fragments of the SECOND modality of a group that straddles a span boundary.  They are
+    // requested (conditionally) BEFORE the unconditional prefetch of the next group goes out: the compiler's
+    // conservative vmcnt for "maybe issued" loads is then still exact for everything older than the prefetch.
+    auto compute = [&](uint4 (&ld)[NSB][4], bf16x8 (&bh0)[NT], bf16x8 (&bl0)[NT], bf16x8 (&bhx)[NT], bf16x8 (&blx)[NT], int grp, unsigned pm) {
         const int mfirst = __builtin_ctz(pm);
+        const unsigned rest = pm & (pm - 1);
+        const int msecond = rest ? __builtin_ctz(rest) : -1;
         ever |= pm;
-        // span boundary inside the group (rare): fetch the other planes before touching LDS
-        bf16x8 bhx[NM][NT], blx[NM][NT];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            if ((pm & (1u << m)) && m != mfirst) load_pack(bhx[m], blx[m], grp, m);
-        }
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
@@ -1140,50 +1142,71 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
                     bf16x8 t8 = drop_apply(*(bf16x8*)&v, keep);
                     v = *(uint4*)&t8;
                 }
-                *(uint4*)(my + (8 * u + lrow) * PITCH + lcol * 16) = v;
+                *(uint4*)(my + (sb * 32 + 8 * u + lrow) * PITCH + lcol * 16) = v;
+            }
+        }
+        // one pass over the transposed tile per modality present (exactly one, except on span boundaries)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (!(pm & (1u << m))) continue;
+            bf16x8 bh[NT], bl[NT];
+            if (m == mfirst) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bh[nt] = bh0[nt]; bl[nt] = bl0[nt]; }
+            } else if (m == msecond) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bh[nt] = bhx[nt]; bl[nt] = blx[nt]; }
+            } else {
+                load_pack(bh, bl, grp, m);                        // three modalities inside 32 tokens
             }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
-                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
-                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
-                const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    if (!(pm & (1u << m))) continue;
+                for (int ct = 0; ct < CT; ++ct) {
+                    const unsigned char* base = my + (sb * 32 + 4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
+                    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
+                    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
+                    const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const bf16x8 bh = (m == mfirst) ? bh0[nt] : bhx[m][nt];
-                        const bf16x8 bl = (m == mfirst) ? bl0[nt] : blx[m][nt];
-                        acc[m][sb][ct][nt] = MFMA16(av, bh, acc[m][sb][ct][nt]);
-                        acc[m][sb][ct][nt] = MFMA16(av, bl, acc[m][sb][ct][nt]);
+                        acc[m][sb][ct][nt] = MFMA16(av, bh[nt], acc[m][sb][ct][nt]);
+                        acc[m][sb][ct][nt] = MFMA16(av, bl[nt], acc[m][sb][ct][nt]);
                     }
                 }
-            }
         }
     };
 
-    // ---- 2-deep pipeline over this wave's CONTIGUOUS run of groups
+    // ---- 2-deep pipeline over this wave's CONTIGUOUS run of groups (routing bytes two groups ahead)
     uint4 ldA[NSB][4], ldB[NSB][4];
-    bf16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
+    bf16x8 bhA[NT], blA[NT], bhB[NT], blB[NT], bhx[NT], blx[NT];
     const int per_wave = (grp_end - grp_begin + NW - 1) / NW;
     int grp = grp_begin + wave * per_wave;
     const int wend = min(grp_end, grp + per_wave);
-    int mym_cur = (grp < wend) ? a.tok_mod[(grp << 5) + (lane & 31)] : MOKA_MOD_NONE;
-    int mym_nxt = (grp + 1 < wend) ? a.tok_mod[((grp + 1) << 5) + (lane & 31)] : MOKA_MOD_NONE;
+    auto routing_of = [&](int gq) -> int {                       // tok_mod is padded past T: the load itself is unconditional
+        const int v = a.tok_mod[(min(gq, grp_last + 1) << 5) + (lane & 31)];
+        return (gq < wend) ? v : MOKA_MOD_NONE;
+    };
+    auto second_pack = [&](int gq, unsigned pm) {                // conditional, always ahead of the next prefetch
+        const unsigned rest = pm & (pm - 1);
+        if (rest) load_pack(bhx, blx, gq, __builtin_ctz(rest));
+    };
+    int mym_cur = routing_of(grp);
+    int mym_nxt = routing_of(grp + 1);
     unsigned pres_cur = present_of(mym_cur);
-    if (pres_cur) issue(ldA, bhA, blA, grp, pres_cur);
+    issue(ldA, bhA, blA, grp, pres_cur);
     while (grp < wend) {
-        int mym_nn = (grp + 2 < wend) ? a.tok_mod[((grp + 2) << 5) + (lane & 31)] : MOKA_MOD_NONE;
+        int mym_nn = routing_of(grp + 2);
         unsigned pres_nxt = present_of(mym_nxt);
-        if (pres_nxt) issue(ldB, bhB, blB, grp + 1, pres_nxt);
-        if (pres_cur) compute(ldA, bhA, blA, grp, pres_cur);
+        second_pack(grp, pres_cur);
+        issue(ldB, bhB, blB, grp + 1, pres_nxt);
+        if (pres_cur) compute(ldA, bhA, blA, bhx, blx, grp, pres_cur);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
         if (grp >= wend) break;
-        mym_nn = (grp + 2 < wend) ? a.tok_mod[((grp + 2) << 5) + (lane & 31)] : MOKA_MOD_NONE;
+        mym_nn = routing_of(grp + 2);
         pres_nxt = present_of(mym_nxt);
-        if (pres_nxt) issue(ldA, bhA, blA, grp + 1, pres_nxt);
-        if (pres_cur) compute(ldB, bhB, blB, grp, pres_cur);
+        second_pack(grp, pres_cur);
+        issue(ldA, bhA, blA, grp + 1, pres_nxt);
+        if (pres_cur) compute(ldB, bhB, blB, bhx, blx, grp, pres_cur);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
     }
 
@@ -1458,7 +1481,7 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     const int gpb = (ngroups + nb - 1) / nb;
     for (int z = 0; z < nz; ++z) ab.z[z].groups_per_block = gpb;
     nb = (ngroups + gpb - 1) / gpb;
-    const size_t lds = (size_t)NW * G * 32 * 160 + (size_t)NW * G * (OUT_CK ? CCB * RP : RP * (CCB + 1)) * 4 + 64;
+    const size_t lds = (size_t)NW * G * NSB * 32 * 160 + (size_t)NW * G * (OUT_CK ? CCB * RP : RP * (CCB + 1)) * 4 + 64;
     ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>, lds);
     hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
 }
