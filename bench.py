@@ -82,7 +82,7 @@ class Unit:
         self.d_in = members[0]["d_in"]
         self.d_outs = [m["d_out"] for m in members]
         ks_in = _lib.ksplit(T, self.d_in, r)
-        ks_out = _lib.ksplit(T, max(self.d_outs), r)
+        ks_out = _lib.ksplit_bwd(T, max(self.d_outs), r)
         P = lambda ts: (c_void_p * len(ts))(*[t.data_ptr() for t in ts])          # noqa: E731
         I = lambda vs: (ctypes.c_int * len(vs))(*vs)                              # noqa: E731
         A = P([a for m in members for a in m["A"]])
@@ -154,7 +154,7 @@ def build_workload(args, dev, lib, bucket_factory):
         ys = [torch.randn(T, width(do), device=dev, dtype=bf) for _, _, do, _ in PROJS]
         sets.append((acts, dacts, ys))
     Tp = _lib.tok_pad(T)
-    max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r))
+    max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r), _lib.ksplit_bwd(T, ff, r))
     # scratch shared by all units (consumed before the next unit overwrites it), one slot per group member
     scratch = [dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
                     dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))

@@ -88,7 +88,7 @@ const char* moka_last_error(void);
 int         moka_device_check(void);
 
 /* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_u", "reduce_ks", "expand_bpc", "wgrad_ct",
- * "wgrad_bpc", "cross_rows"; value 0 restores the default).  Results never depend on it. */
+ * "wgrad_bpc", "cross_rows", "no_fused_gy", "gy_ng"; value 0 restores the default).  Results never depend on it. */
 int moka_tune(const char* key, int value);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
@@ -96,8 +96,11 @@ int moka_rank_pad(int r);
 /* Token count rounded up to the pack granularity (32). */
 int moka_tok_pad(int T);
 /* Number of split-K partial slices the reduce kernel writes for T tokens of width C
- * (moka_down_fwd: C = d_in; moka_up_bwd: C = d_out).  `part` holds ks * T * RP floats. */
+ * (moka_down_fwd: C = d_in).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
+/* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
+ * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  r <= 16: one slice per 512-column block of gy. */
+int moka_ksplit_bwd(int T, int C, int r);
 
 /* ---- forward ----------------------------------------------------------------------- */
 
@@ -131,7 +134,7 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
 
 /* ---- backward ---------------------------------------------------------------------- */
 
-/* g_part[s][t] = partial over d_out slice s of s_out[mod(t)] * gy[t] Bw   (needs BwT) and
+/* g_part[s][t] = partial over d_out slice s (s < moka_ksplit_bwd()) of s_out[mod(t)] * gy[t] Bw   (needs BwT) and
  * dB_acc[o][k] += sum_t gy[t][o] * (s_out[mod(t)] hp[t][k])   (needs hp_kmj; fp32 accumulate,
  * the caller owns / zeroes dB_acc [d_out, r]).  Either output may be NULL (skipped): the two halves are
  * independent kernels, so a caller may enqueue them on different streams (as it may for the dA / dx
@@ -168,7 +171,7 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
  *   the others            run the G independent problems in one launch (grid z).
  * Pointer arguments become host arrays of G device pointers, in projection order; A / dA_acc hold G*M
  * pointers (projection-major); d_out may differ per projection (GQA k/v); every projection of a group
- * uses moka_ksplit(T, max_g d_out[g], r) slices for its g_part.  seeds: G dropout seeds (one mask per
+ * uses moka_ksplit_bwd(T, max_g d_out[g], r) slices for its g_part.  seeds: G dropout seeds (one mask per
  * projection, as the reference draws one per adapter).  For r > 16 the shared-input kernels fall back to
  * one launch per projection (same results). */
 int moka_down_fwd_group(const void* x, const void* const* A /*[G*M]*/, const uint8_t* tok_mod, float* const* part /*[G]*/,

@@ -39,6 +39,7 @@ SYMBOLS = {
     "moka_rank_pad": (c_int, [c_int]),
     "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),
+    "moka_ksplit_bwd": (c_int, [c_int, c_int, c_int]),
     # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, stream
     "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
@@ -120,6 +121,13 @@ def rank_pad(r: int) -> int:
 
 def ksplit(T: int, C: int, r: int) -> int:
     ks = load().moka_ksplit(int(T), int(C), int(r))
+    if ks < 0:
+        raise ValueError(f"unsupported shape for the HIP path: T={T} width={C} r={r} (width must be a multiple of 32)")
+    return ks
+
+
+def ksplit_bwd(T: int, C: int, r: int) -> int:
+    ks = load().moka_ksplit_bwd(int(T), int(C), int(r))
     if ks < 0:
         raise ValueError(f"unsupported shape for the HIP path: T={T} width={C} r={r} (width must be a multiple of 32)")
     return ks

@@ -138,6 +138,21 @@ static __device__ __forceinline__ bf16x8 drop_apply(bf16x8 v, const KeepMask& km
 }
 static __device__ __forceinline__ bool drop_kept(const KeepMask& km, int e) { return (km.w[e >> 1] >> (16 * (e & 1))) & 1u; }
 
+// Sum of the split-K slices part[s][t][k], s = s0, s0 + step, ... < ks, with eight independent loads in
+// flight (indices clamped, so no load is conditional): the backward sums up to 22 slices per element.
+static __device__ __forceinline__ float sum_slices(const float* p, size_t stride, int ks, int s0, int step) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < ks; s += 8 * step) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sj = s + j * step;
+            const float x = p[(size_t)min(sj, ks - 1) * stride];
+            v[j] += (sj < ks) ? x : 0.f;
+        }
+    }
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
 // position of token (t & 31) inside its group of 32 in the rank-major packs
 static __device__ __forceinline__ int kmj_pos(int tl) {
     return (tl < 16) ? (8 * (tl >> 2) + (tl & 3)) : (8 * ((tl - 16) >> 2) + 4 + (tl & 3));
@@ -608,20 +623,45 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
     int my_mod = MOKA_MOD_NONE, my_slot = -1;
     if (tid < nrow) { my_mod = a.tok_mod[b * a.S + r0 + tid]; my_slot = a.kslot[b * a.S + r0 + tid]; }
     for (int j = tid; j < a.Lkp; j += 512) Kt[j] = a.ktok[b * a.Lkp + j];
+    // g rows = sum of the split-K slices (up to 22 for a 11008-wide gy): all 512 threads take part, the slices of
+    // one element are dealt round-robin to 512 / (RB * RP) thread groups, partial sums meet in LDS (Dh as scratch)
+    const int NE = a.RB * RP;                              // elements of the block
+    const bool split = (NE <= 256);
+    if (split) {
+        const int nsg = 512 / NE, sg = tid / NE, el = tid - sg * NE;
+        if (sg < nsg) {
+            const int row = el / RP, k = el % RP;
+            float v = 0.f;
+            if (row < nrow) v = sum_slices(a.part + ((size_t)(b * a.S + r0 + row)) * RP + k, (size_t)a.T * RP, a.ks, sg, nsg);
+            Dh[sg * NE + el] = v;                          // NE * nsg <= 512 <= 32 * KP floats
+        }
+    }
     for (int e = tid; e < 32 * RP; e += 512) {
         const int row = e / RP, k = e % RP;
         float v = 0.f, hv = 0.f;
         if (row < nrow) {
             const int t = b * a.S + r0 + row;
-            for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
+            if (!split) v = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
             hv = a.hfull[(size_t)t * RP + k];
         }
-        Gs[row * KP + k] = v;
+        if (!split) Gs[row * KP + k] = v;
         Hs[row * KP + k] = hv;
     }
     if (tid < 32) { s_mod[tid] = my_mod; s_slot[tid] = my_slot; }
     const int Lk = min(klen_b, a.Lk_max);
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
+    if (split) {
+        const int nsg = 512 / NE;
+        for (int e = tid; e < 32 * RP; e += 512) {
+            const int row = e / RP, k = e % RP;
+            float v = 0.f;
+            if (row < a.RB) {
+                for (int q = 0; q < nsg; ++q) v += Dh[q * NE + row * RP + k];
+            }
+            Gs[row * KP + k] = v;
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < 32 * RP; e += 512) {
         const int row = e / RP, k = e % RP;
         float v = Gs[row * KP + k];
@@ -777,7 +817,7 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossBat
     const int j = e / RP, k = e % RP;
     const int t = a.ktok[b * a.Lkp + j];
     if (t < 0 || a.kslot[t] != j) return;           // zero key row / not the owner of that token
-    for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
+    v += sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
     if (a.out_f32) a.out_f32[(size_t)t * RP + k] = v;
     write_packs_bwd<RP>(a, t, k, a.tok_mod[t], v * a.s_mod[0]);
 }
@@ -1258,6 +1298,187 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Y: one pass over gy for BOTH halves of moka_up_bwd (r <= 16):
+//      g_part[cb][t][k] = s_out[mod(t)] * sum_{c in column block cb} gy[t][c] BwT[k][c]
+//      dB[c][k]        += sum_t gy[t][c] * hp_pack[k][t]
+// ------------------------------------------------------------------------------------------
+struct GyArgs {
+    const unsigned char* gy;        // [T][C] bf16
+    const unsigned short* pack;     // hp_kmj [2][RP][Tp] (may be null when dB is)
+    const unsigned char* BwT;       // [RP][C] bf16, zero padded rows
+    const unsigned char* tok_mod;
+    float* g_part;                  // [ncb][T][RP]  one slice per 512-column block (ncb = grid x)
+    float* dB;                      // [C][r] fp32 accumulate, or null
+    float s_mod[4];
+    int T, Tp, C, r, M;
+};
+struct GyBatch { GyArgs z[MOKA_MAX_GROUP]; };
+
+// Block = 8 waves on a [NG*32 tokens x 512 columns] tile of gy; wave w owns columns 64w..64w+63 for the
+// block's NG 32-token groups (NG: long runs keep the number of dB atomics down -- they cost ~3 us per
+// million -- short runs give more blocks; the launcher picks).  A group is loaded ONCE, in MFMA-A-fragment shape (16 rows x 64 B per
+// instruction), two groups in flight per wave, and feeds
+//   * the g contraction directly from the registers (K = this wave's 64 columns, weight fragments
+//     resident); the [32 x 16] partial goes to a wave-private LDS slot and every PH groups the eight
+//     waves' slots are summed and written as one split-K slice (two LDS-only barriers per PH groups);
+//   * the dB contraction through the wave-private LDS tile + ds_read_b64_tr_b16 (tokens = K), exactly as
+//     in the wgrad kernel, reduced over the block at the end.
+// Replaces moka_reduce_kernel + moka_wgrad_kernel<OUT_CK> on gy, which each read gy once (measured: 36 us
+// for a 67 MB gy where one pass costs ~20 us).
+template <int RP, bool WITH_DB, int NG>
+__global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = RP / 16;
+    constexpr int NW = 8, PH = 2, CT = 4;              // NG = 32-token groups per block
+    constexpr int PITCH = 64 * 2 + 32, REGION = 32 * PITCH;
+    constexpr int RSLOT = 32 * RP;                       // floats per (wave, group) partial
+    const GyArgs& a = ab.z[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ngroups = a.Tp >> 5;
+    const int grp0 = blockIdx.y * NG;
+    if (grp0 >= ngroups) return;
+    const int cb0 = blockIdx.x * 512;
+    float* slice = a.g_part + (size_t)blockIdx.x * a.T * RP;
+    if (cb0 >= a.C) {                                    // batched projections of different width: empty slice
+        for (int e = tid; e < NG * 32 * RP; e += 512) {
+            const int t = grp0 * 32 + e / RP;
+            if (t < a.T) slice[(size_t)t * RP + (e % RP)] = 0.f;
+        }
+        return;
+    }
+    const int c0 = cb0 + 64 * wave;
+    const bool wactive = c0 < a.C;                       // wave uniform (C % 32 == 0: a wave may own 32 valid columns)
+    unsigned char* my = smem + wave * REGION;
+    float* rbuf = (float*)(smem + NW * REGION);          // [NW][PH][32][RP]
+    float* myr = rbuf + (size_t)wave * PH * RSLOT;
+
+    // weight fragments of my 64 columns (two K steps), resident: lane (n = rank i, k chunk g)
+    bf16x8 bwt[2][NT];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = c0 + 32 * kk + 8 * g;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < a.C) v = *(const bf16x8*)(a.BwT + ((size_t)(nt * 16 + i) * a.C + c) * 2);
+            bwt[kk][nt] = v;
+        }
+
+    const int grp_last = ngroups - 1;
+    // F[st][kk]: rows 16st + i of the group, columns c0 + 32kk + 8g .. +7   (unconditional, clamped)
+    auto issue = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp_) {
+        const int grp = min(grp_, grp_last);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const size_t rowoff = (size_t)min((grp << 5) + 16 * st + i, a.T - 1) * a.C;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = min(c0 + 32 * kk + 8 * g, a.C - 8);
+                F[st][kk] = *(const bf16x8*)(a.gy + (rowoff + c) * 2);
+            }
+        }
+        if (WITH_DB) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned short* ph = a.pack + ((size_t)(nt * 16 + i)) * a.Tp + (grp << 5) + 8 * g;
+                bh[nt] = *(const bf16x8*)ph;
+                bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
+            }
+        }
+    };
+    f32x4 accW[CT][NT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accW[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int gi) {
+        const int grp = grp0 + gi;
+        const bool live = wactive && grp < ngroups;      // wave uniform
+        // ---- g: [32 tokens x RP] partial over my columns -> my LDS slot of this phase
+        float* slot = myr + (size_t)(gi % PH) * RSLOT;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 accR = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    accR = MFMA16(F[st][0], bwt[0][nt], accR);
+                    if (c0 + 32 < a.C) accR = MFMA16(F[st][1], bwt[1][nt], accR);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = accR[reg];
+            }
+        // ---- dB: transposed tile through the wave-private LDS region
+        if (WITH_DB && live) {
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    *(bf16x8*)(my + (16 * st + i) * PITCH + (32 * kk + 8 * g) * 2) = (c0 + 32 * kk < a.C) ? F[st][kk] : z8;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const unsigned char* base = my + (4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
+                const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    accW[ct][nt] = MFMA16(av, bh[nt], accW[ct][nt]);
+                    accW[ct][nt] = MFMA16(av, bl[nt], accW[ct][nt]);
+                }
+            }
+        }
+    };
+    // sum the eight waves' slots of one phase (PH groups) and write the split-K slice rows
+    auto reduce_phase = [&](int phase) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int e = tid; e < PH * RSLOT; e += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += rbuf[(size_t)w * PH * RSLOT + e];
+            const int t = (grp0 + phase * PH) * 32 + e / RP;
+            if (t < a.T) {
+                const int mr = a.tok_mod[t];
+                slice[(size_t)t * RP + (e % RP)] = (mr < a.M) ? sum * mod_scale(a.s_mod, mr) : 0.f;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    bf16x8 FA[2][2], FB[2][2], bhA[NT], blA[NT], bhB[NT], blB[NT];
+    issue(FA, bhA, blA, grp0);
+#pragma unroll
+    for (int gi = 0; gi < NG; gi += 2) {
+        issue(FB, bhB, blB, grp0 + gi + 1);
+        compute(FA, bhA, blA, gi);
+        issue(FA, bhA, blA, grp0 + gi + 2);
+        compute(FB, bhB, blB, gi + 1);
+        if ((gi + 2) % PH == 0) reduce_phase((gi + 1) / PH);
+    }
+
+    if (WITH_DB) {
+        // block reduction of dB (layout [column][rank]), own tile regions as buffers, LDS-only barrier
+        float* mine = (float*)my;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) mine[(ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = accW[ct][nt][reg];
+        // wave w's tile holds columns cb0 + 64w ..: the destination rows are disjoint, no cross-wave sum needed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int e = lane; e < 64 * RP; e += 64) {
+            const int cl = e / RP, k = e % RP;
+            const int c = c0 + cl;
+            if (c < a.C && k < a.r) atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
+        }
+    }
+}
+
 // Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
 __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
     const size_t nchunk = (size_t)T * (C >> 3);
@@ -1305,7 +1526,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1503,6 +1724,35 @@ static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
     return check_launch("moka_wgrad_kernel");
 }
 
+template <bool WITH_DB, int NG>
+static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
+    const int ntb = ((gb.z[0].Tp >> 5) + NG - 1) / NG;
+    const size_t lds = (size_t)8 * (32 * 160) + (size_t)8 * 2 * 32 * 16 * 4;
+    ensure_lds((const void*)moka_gy_kernel<16, WITH_DB, NG>, lds);
+    hipLaunchKernelGGL((moka_gy_kernel<16, WITH_DB, NG>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+}
+
+template <bool WITH_DB>
+static int launch_gy(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
+    const int ncb = (Cmax + 511) / 512;
+    const int ngroups = gb.z[0].Tp >> 5;
+    // groups per block: without dB short runs (more blocks); with dB the longest run that still gives every CU a block
+    // (measured at T = 8192: 4096 wide -> 8, 11008 wide -> 8, 3 x 4096 -> 8/16, 2 x 11008 -> 16; g only -> 4)
+    int ng = 4;
+    if (WITH_DB) {
+        auto blocks = [&](int n) { return (long)ncb * nz * ((ngroups + n - 1) / n); };
+        ng = blocks(16) >= 2L * num_cu() ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
+    }
+    if (g_tune_gy_ng == 4 || g_tune_gy_ng == 8 || g_tune_gy_ng == 16) ng = g_tune_gy_ng;
+    if (ng == 16) launch_gy_t<WITH_DB, 16>(gb, nz, ncb, st);
+    else if (ng == 8) launch_gy_t<WITH_DB, 8>(gb, nz, ncb, st);
+    else launch_gy_t<WITH_DB, 4>(gb, nz, ncb, st);
+    return check_launch("moka_gy_kernel");
+}
+
+// number of g_part slices moka_up_bwd writes for output width C
+static int bwd_ks(int T, int C, int r) { return rank_pad(r) == 16 ? (C + 511) / 512 : reduce_ks(T, C); }
+
 extern "C" {
 
 int moka_version(void) { return MOKA_VERSION; }
@@ -1523,6 +1773,8 @@ int moka_tune(const char* key, int value) {
     if (!strcmp(key, "reduce_nw")) g_tune_reduce_nw = value;
     else if (!strcmp(key, "reduce_u")) g_tune_reduce_u = value;
     else if (!strcmp(key, "wgrad_nw")) g_tune_wgrad_nw = value;
+    else if (!strcmp(key, "no_fused_gy")) g_tune_no_fused_gy = value;
+    else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
@@ -1534,6 +1786,11 @@ int moka_tune(const char* key, int value) {
 
 int moka_rank_pad(int r) { return rank_pad(r); }
 int moka_tok_pad(int T) { return T < 0 ? MOKA_EINVAL : (T + 31) / 32 * 32; }
+
+int moka_ksplit_bwd(int T, int C, int r) {
+    if (T < 1 || C < 32 || (C % 32) != 0 || rank_pad(r) < 0) return MOKA_EINVAL;
+    return bwd_ks(T, C, r);
+}
 
 int moka_ksplit(int T, int C, int r) {
     if (rank_pad(r) < 0 || C < 32 || (C % 32) != 0 || T < 1) return MOKA_EINVAL;
@@ -1720,6 +1977,23 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         Cmax = d_out[g] > Cmax ? d_out[g] : Cmax;
     }
     int rc = MOKA_OK;
+    if (g_part && g_part[0] && RP == 16 && !g_tune_no_fused_gy) {
+        // r <= 16: ONE pass over gy produces the g slices (one per 512-column block) and, if requested, dB
+        if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
+        const bool with_db = dB_acc && dB_acc[0];
+        if (with_db && !hp_kmj) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without hp_kmj");
+        GyBatch gb;
+        memset(&gb, 0, sizeof(gb));
+        for (int g = 0; g < G; ++g) {
+            if (!BwT[g] || (with_db && !hp_kmj[g])) return fail(MOKA_EINVAL, "moka_up_bwd: BwT / hp_kmj of projection %d is null", g);
+            GyArgs& a = gb.z[g];
+            a.gy = (const unsigned char*)gy[g]; a.pack = with_db ? (const unsigned short*)hp_kmj[g] : nullptr;
+            a.BwT = (const unsigned char*)BwT[g]; a.tok_mod = tok_mod; a.g_part = g_part[g]; a.dB = with_db ? dB_acc[g] : nullptr;
+            for (int m = 0; m < M; ++m) a.s_mod[m] = s_out[m];
+            a.T = T; a.Tp = (T + 31) / 32 * 32; a.C = d_out[g]; a.r = r; a.M = M;
+        }
+        return with_db ? launch_gy<true>(gb, G, Cmax, (hipStream_t)stream) : launch_gy<false>(gb, G, Cmax, (hipStream_t)stream);
+    }
     if (g_part && g_part[0]) {
         // g = s_out[mod] * gy Bw: contraction over d_out with the transposed weight; one chain per tile
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
@@ -1727,7 +2001,7 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         memset(&ra, 0, sizeof(ra));
         ra.tok_mod = tok_mod;
         for (int m = 0; m < M; ++m) ra.s_mod[m] = s_out[m];
-        ra.T = T; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = reduce_ks(T, Cmax);     // BwT has RP zero-padded rows
+        ra.T = T; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = g_tune_no_fused_gy && RP == 16 ? (Cmax + 511) / 512 : reduce_ks(T, Cmax);     // BwT has RP zero-padded rows
         for (int g = 0; g < G; ++g) {
             if (!BwT[g]) return fail(MOKA_EINVAL, "moka_up_bwd: BwT[%d] is null", g);
             ra.in[g] = (const unsigned char*)gy[g]; ra.W[g][0] = (const unsigned char*)BwT[g]; ra.out[g] = g_part[g]; ra.C[g] = d_out[g];

@@ -102,7 +102,7 @@ def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: torch.Tensor,
     lib = _lib.load()
     T, d_out = gy2.shape
     RP = _lib.rank_pad(r)
-    ks = _lib.ksplit(T, d_out, r)
+    ks = _lib.ksplit_bwd(T, d_out, r)
     g_part = torch.empty((ks, T, RP), dtype=torch.float32, device=gy2.device)
     _lib.check(lib.moka_up_bwd(gy2.data_ptr(), None if hp_kmj is None else hp_kmj.data_ptr(), BwT.data_ptr(),
                                rt.tok_mod.data_ptr(), _floats(s_out), g_part.data_ptr(),
@@ -218,7 +218,7 @@ def up_bwd_group(gys: Sequence[torch.Tensor], hp_kmjs: Sequence[torch.Tensor], B
     T = gys[0].shape[0]
     RP = _lib.rank_pad(r)
     d_outs = [g_.shape[1] for g_ in gys]
-    ks = _lib.ksplit(T, max(d_outs), r)
+    ks = _lib.ksplit_bwd(T, max(d_outs), r)
     g_parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=gys[0].device) for _ in range(G)]
     _lib.check(lib.moka_up_bwd_group(_ptrs(gys), _ptrs(hp_kmjs), _ptrs(BwTs), rt.tok_mod.data_ptr(), _floats(s_out),
                                      _ptrs(g_parts), None if dB_accs is None else _ptrs(dB_accs),

@@ -39,7 +39,7 @@ def main():
     rt = MokaRouting.from_avt_masks(masks)
     bf, f32 = torch.bfloat16, torch.float32
     RP, Tp = 16, _lib.tok_pad(T)
-    NBUF = 6      # rotate over distinct buffers so nothing stays in the 256 MiB Infinity Cache
+    NBUF = int(os.environ.get("NBUF", 6))      # rotate over distinct buffers so nothing stays in the 256 MiB Infinity Cache
 
     def shapes(d_in, d_out):
         xs = [torch.randn(T, d_in, device=dev, dtype=bf) for _ in range(NBUF)]
@@ -47,7 +47,7 @@ def main():
         dxs = [torch.randn(T, d_in, device=dev, dtype=bf) for _ in range(NBUF)]
         A = [torch.randn(r, d_in, device=dev, dtype=bf) * 0.01 for _ in range(M)]
         Bw = torch.randn(d_out, r, device=dev, dtype=bf) * 0.02
-        part = torch.empty(8, T, RP, dtype=f32, device=dev)
+        part = torch.empty(24, T, RP, dtype=f32, device=dev)
         h = torch.empty(T, RP, dtype=f32, device=dev)
         hp_tok = torch.empty(Tp, 2 * RP, dtype=bf, device=dev)
         hp_kmj = torch.empty(2, RP, Tp, dtype=bf, device=dev)
@@ -75,8 +75,9 @@ def main():
                                                       w["h"].data_ptr(), None, w["hp_tok"].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), w["AT"].data_ptr(), r, 1.0, c, sp()),
             "up_fwd": lambda i: lib.moka_up_fwd(w["hp_tok"].data_ptr(), w["Bw"].data_ptr(), tm, w["ys"][i % NBUF].data_ptr(), T, r, d_out, 0, sp()),
             "up_bwd(g only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), None, T, r, d_out, M, 0, sp()),
+            "up_bwd(dB only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), None, tm, so, None, w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
             "up_bwd(g+dB)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
-            "cross_bwd": lambda i: lib.moka_cross_bwd(w["part"].data_ptr(), _lib.ksplit(T, d_out, r), w["h"].data_ptr(), byref(rt.struct), 1.0, None,
+            "cross_bwd": lambda i: lib.moka_cross_bwd(w["part"].data_ptr(), _lib.ksplit_bwd(T, d_out, r), w["h"].data_ptr(), byref(rt.struct), 1.0, None,
                                                       w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), rt.cross_ws(r).data_ptr(), r, 1.0, c, sp()),
             "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, dAp, None, T, d_in, r, M, DROP, 1234, 0, sp()),
             "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, DROP, 1234, 0, sp()),
@@ -103,14 +104,15 @@ def main():
         for n in ("down_fwd", "cross_fwd", "up_fwd", "up_bwd(g+dB)", "cross_bwd"):
             assert cs[n](0) == 0, lib.moka_last_error()
         torch.cuda.synchronize()
-        algo = {"down_fwd": E * T * d_in, "up_fwd": 2 * E * T * d_out, "up_bwd(g only)": E * T * d_out, "up_bwd(g+dB)": E * T * d_out,
+        algo = {"down_fwd": E * T * d_in, "up_fwd": 2 * E * T * d_out, "up_bwd(g only)": E * T * d_out, "up_bwd(dB only)": E * T * d_out, "up_bwd(g+dB)": E * T * d_out,
                 "down_bwd(dA only)": E * T * d_in, "down_bwd(dx only)": 2 * E * T * d_in, "cross_fwd": 0, "cross_bwd": 0}
         sweeps = {
             "down_fwd": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_fwd": [("expand_bpc", v) for v in (2, 4, 6, 8)],
             "down_bwd(dx only)": [("expand_bpc", v) for v in (2, 4, 8)],
-            "up_bwd(g+dB)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2, 4)],
+            "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)] + [("no_fused_gy", 1)],
+            "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)],
             "down_bwd(dA only)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2)],
             "cross_fwd": [("cross_rows", v) for v in (32, 16, 8)],
             "cross_bwd": [("cross_rows", v) for v in (32, 16, 8)],
