@@ -847,7 +847,7 @@ struct ExpandBatch { ExpandArgs z[MOKA_MAX_GROUP]; };
 // for the whole block, other modalities' fragments are fetched from L2 for the (few) tiles that need them.
 // G > 1 (dx only): G projections read the same x (q/k/v, gate/up), so their input gradients land in the
 // same dx: one read-modify-write pass adds all G terms (each through its own dropout mask).
-template <int RP, int NQ, bool W_CK, int G>
+template <int RP, int NQ, bool W_CK, int G, int DEPTH>
 __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) {
     constexpr int KH = (RP + 31) / 32;                 // 32-wide rank blocks per hi (or lo) plane
     constexpr int WC = NQ * 32;                        // columns per wave
@@ -888,8 +888,8 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     const size_t prow = (size_t)(2 * RP) * 2;                     // pack row bytes
     const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // Two token tiles in flight per wave: while tile k is multiplied and stored, the routing byte, the
-    // pack rows and the in/out rows of tile k+1 are already on their way (HBM latency).  Every load of
+    // DEPTH token tiles in flight per wave: while tile k is multiplied and stored, the routing bytes, the
+    // pack rows and the in/out rows of the next DEPTH-1 tiles are already on their way (HBM latency).  Every load of
     // the prefetch is unconditional (the tile index is clamped), see the note on vmcnt in the reduce kernel.
     struct Tile {
         int mrow;
@@ -1049,13 +1049,19 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         }
     };
 
-    Tile TA, TB;
+    // ring of DEPTH tiles: while tile j is processed, tiles j+1 .. j+DEPTH-1 are in flight; processing tile j
+    // issues the prefetch of tile j+DEPTH-1 into the slot tile j-1 has just left
+    Tile ring[DEPTH];
     const int step = gridDim.y;
-    issue(TA, blockIdx.y);
-    for (int tile = blockIdx.y; tile < ntiles; tile += 2 * step) {
-        process(TA, tile, TB, tile + step);
-        if (tile + step >= ntiles) break;
-        process(TB, tile + step, TA, tile + 2 * step);
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(ring[d], blockIdx.y + d * step);
+    for (int tile = blockIdx.y; tile < ntiles; tile += DEPTH * step) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int tj = tile + d * step;
+            if (tj >= ntiles) break;
+            process(ring[d], tj, ring[(d + DEPTH - 1) % DEPTH], tj + (DEPTH - 1) * step);
+        }
     }
 }
 
@@ -1526,7 +1532,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1659,7 +1665,7 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
     return check_launch(fn);
 }
 
-template <int RP, int NQ, bool W_CK, int G>
+template <int RP, int NQ, bool W_CK, int G, int DEPTH>
 static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     constexpr int CW = 4 * NQ * 32;
     int Cmax = 0;
@@ -1670,19 +1676,20 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     int gy = (bpc * num_cu() + nc * nz - 1) / (nc * nz);   // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, ab);
+    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G, DEPTH>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, ab);
 }
 
 // W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
 template <bool W_CK>
 static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) {
+    const bool deep = g_tune_expand_depth != 2;
     if (W_CK || nz == 1) {
-        if (RP == 16) launch_expand_t<16, 4, W_CK, 1>(ab, nz, st);
-        else if (RP == 32) launch_expand_t<32, 2, W_CK, 1>(ab, nz, st);
-        else launch_expand_t<64, 1, W_CK, 1>(ab, nz, st);
+        if (RP == 16) { if (deep && !W_CK) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
+        else if (RP == 32) launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st);
+        else launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st);
     } else {                                             // can_group(): RP == 16
-        if (nz == 2) launch_expand_t<16, 2, false, 2>(ab, 1, st);
-        else launch_expand_t<16, 2, false, 3>(ab, 1, st);
+        if (nz == 2) { if (deep) launch_expand_t<16, 2, false, 2, 4>(ab, 1, st); else launch_expand_t<16, 2, false, 2, 2>(ab, 1, st); }
+        else { if (deep) launch_expand_t<16, 2, false, 3, 3>(ab, 1, st); else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st); }
     }
     return check_launch("moka_expand_kernel");
 }
@@ -1775,6 +1782,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_nw")) g_tune_wgrad_nw = value;
     else if (!strcmp(key, "no_fused_gy")) g_tune_no_fused_gy = value;
     else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
+    else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;

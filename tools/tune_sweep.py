@@ -109,8 +109,8 @@ def main():
         sweeps = {
             "down_fwd": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
-            "up_fwd": [("expand_bpc", v) for v in (2, 4, 6, 8)],
-            "down_bwd(dx only)": [("expand_bpc", v) for v in (2, 4, 8)],
+            "up_fwd": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
+            "down_bwd(dx only)": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
             "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)] + [("no_fused_gy", 1)],
             "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)],
             "down_bwd(dA only)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2)],
