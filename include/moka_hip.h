@@ -88,14 +88,14 @@ const char* moka_last_error(void);
 int         moka_device_check(void);
 
 /* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_u", "reduce_ks", "expand_bpc", "wgrad_ct",
- * "wgrad_bpc", "cross_rows", "no_fused_gy", "gy_ng", "expand_depth"; value 0 restores the default).  Results never depend on it. */
+ * "wgrad_bpc", "cross_rows", "no_fused_gy", "gy_ng", "expand_depth", "no_xa"; value 0 restores the default).  Results never depend on it. */
 int moka_tune(const char* key, int value);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
 int moka_rank_pad(int r);
 /* Token count rounded up to the pack granularity (32). */
 int moka_tok_pad(int T);
-/* Number of split-K partial slices the reduce kernel writes for T tokens of width C
+/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C (r <= 16: one per 512 columns)
  * (moka_down_fwd: C = d_in).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest

@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
         float v = 0.f;
         if (row < nrow) {
             const int t = b * a.S + r0 + row;
-            for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];   // garbage for tokens of no modality
+            v = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);     // garbage for tokens of no modality
         }
         Hs[row * KP + k] = v;
     }
@@ -493,8 +493,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
             const int j = e / RP, k = e % RP;
             const int t = Kt[j];
             float v = 0.f;
-            if (t >= 0)
-                for (int s = 0; s < a.ks; ++s) v += a.part[((size_t)s * a.T + t) * RP + k];
+            if (t >= 0) v = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
             Ks[j * KP + k] = v;
         }
         __syncthreads();
@@ -1485,6 +1484,139 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// F: down-projection for r <= 16 in the same block shape as the gy kernel:
+//      part_g[cb][t][k] = s_in * sum_{c in column block cb} drop_g(x)[t][c] A_{g,mod(t)}[k][c]
+// ------------------------------------------------------------------------------------------
+struct XaArgs {
+    const unsigned char* x;                                  // [T][C] bf16
+    const unsigned char* A[MOKA_MAX_GROUP][MOKA_MAX_MOD];    // [r][C] bf16
+    const unsigned char* tok_mod;
+    float* part[MOKA_MAX_GROUP];                             // [ncb][T][16]
+    float s_mod[4];
+    int T, C, r, M;
+    DropArgs drop[MOKA_MAX_GROUP];
+};
+
+// Block = 8 waves on a [NG*32 tokens x 512 columns] tile of x; wave w owns columns 64w..64w+63 and keeps the
+// weight fragments of ALL modalities (and of all G projections that share x) for them in registers, so the
+// stream is x alone: no weight traffic, and a group that straddles a span boundary costs one extra MFMA chain
+// (rows of the other modality zeroed in the x operand) instead of extra loads.  The [32 x 16] partial of a group
+// goes to a wave-private LDS slot; every PH groups the eight waves' slots are summed into one split-K slice.
+template <int G, int NG>
+__global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RP = 16, NW = 8, PH = 2;
+    constexpr int RSLOT = 32 * RP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ngroups = (a.T + 31) >> 5;
+    const int grp0 = blockIdx.y * NG;
+    if (grp0 >= ngroups) return;
+    const int c0 = blockIdx.x * 512 + 64 * wave;
+    const bool wactive = c0 < a.C;
+    float* rbuf = (float*)smem;                              // [NW][PH][G][32][RP]
+    float* myr = rbuf + (size_t)wave * PH * G * RSLOT;
+
+    bf16x8 wfr[G][MOKA_MAX_MOD][2];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = c0 + 32 * kk + 8 * g;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                // rank rows >= r do not exist: clamp the row, the result column is zeroed when the slice is written
+                if (m < a.M && c < a.C) v = *(const bf16x8*)(a.A[gi][m] + ((size_t)min(i, a.r - 1) * a.C + c) * 2);
+                wfr[gi][m][kk] = v;
+            }
+
+    const int grp_last = ngroups - 1;
+    auto issue = [&](bf16x8 (&F)[2][2], int (&mr)[2], int grp_) {
+        const int grp = min(grp_, grp_last);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int t = (grp << 5) + 16 * st + i;
+            mr[st] = a.tok_mod[t];                           // padded past T with MOKA_MOD_NONE
+            const size_t rowoff = (size_t)min(t, a.T - 1) * a.C;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = min(c0 + 32 * kk + 8 * g, a.C - 8);
+                F[st][kk] = *(const bf16x8*)(a.x + (rowoff + c) * 2);
+            }
+        }
+    };
+    auto compute = [&](bf16x8 (&F)[2][2], int (&mr)[2], int gi_) {
+        const int grp = grp0 + gi_;
+        const bool live = wactive && grp < ngroups;
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            float* slot = myr + ((size_t)(gi_ % PH) * G + gi) * RSLOT;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    unsigned pm = 0;
+#pragma unroll
+                    for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mr[st] == m)) pm |= 1u << m;
+                    bf16x8 xg[2];
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        xg[kk] = F[st][kk];
+                        if (a.drop[gi].thr) {
+                            const unsigned trow = (unsigned)min((grp << 5) + 16 * st + i, a.T - 1);
+                            xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 32 * kk) >> 3) + (unsigned)g));
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                        if (!(pm & (1u << m))) continue;
+                        const bool other = (pm != (1u << m)) && mr[st] != m;     // my row (token i) only counts in its own chain
+                        acc = MFMA16(other ? z8 : xg[0], wfr[gi][m][0], acc);
+                        if (c0 + 32 < a.C) acc = MFMA16(other ? z8 : xg[1], wfr[gi][m][1], acc);
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + i] = acc[reg];
+            }
+        }
+    };
+    auto reduce_phase = [&](int phase) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            float* slice = a.part[gi] + (size_t)blockIdx.x * a.T * RP;
+            for (int e = tid; e < PH * RSLOT; e += 512) {
+                const int ph = e / RSLOT, e1 = e - ph * RSLOT;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += rbuf[(((size_t)w * PH + ph) * G + gi) * RSLOT + e1];
+                const int t = (grp0 + phase * PH + ph) * 32 + e1 / RP, k = e1 % RP;
+                if (t < a.T) {
+                    const int mrw = a.tok_mod[t];
+                    slice[(size_t)t * RP + k] = (mrw < a.M && k < a.r) ? sum * mod_scale(a.s_mod, mrw) : 0.f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    bf16x8 FA[2][2], FB[2][2];
+    int mrA[2], mrB[2];
+    issue(FA, mrA, grp0);
+#pragma unroll
+    for (int gi_ = 0; gi_ < NG; gi_ += 2) {
+        issue(FB, mrB, grp0 + gi_ + 1);
+        compute(FA, mrA, gi_);
+        if (PH == 1) reduce_phase(gi_);
+        issue(FA, mrA, grp0 + gi_ + 2);
+        compute(FB, mrB, gi_ + 1);
+        reduce_phase(PH == 1 ? gi_ + 1 : gi_ / 2);
+    }
+}
+
 // Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
 __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
     const size_t nchunk = (size_t)T * (C >> 3);
@@ -1532,7 +1664,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1757,6 +1889,19 @@ static int launch_gy(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     return check_launch("moka_gy_kernel");
 }
 
+template <int G>
+static int launch_xa(const XaArgs& a, hipStream_t st) {
+    constexpr int NG = 4, PH = 2;
+    const int ncb = (a.C + 511) / 512, ntb = (((a.T + 31) >> 5) + NG - 1) / NG;
+    const size_t lds = (size_t)8 * PH * G * 32 * 16 * 4;
+    ensure_lds((const void*)moka_xa_kernel<G, NG>, lds);
+    hipLaunchKernelGGL((moka_xa_kernel<G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
+    return check_launch("moka_xa_kernel");
+}
+
+// number of part slices moka_down_fwd writes for input width C
+static int fwd_ks(int T, int C, int r) { return (rank_pad(r) == 16 && !g_tune_no_xa) ? (C + 511) / 512 : reduce_ks(T, C); }
+
 // number of g_part slices moka_up_bwd writes for output width C
 static int bwd_ks(int T, int C, int r) { return rank_pad(r) == 16 ? (C + 511) / 512 : reduce_ks(T, C); }
 
@@ -1783,6 +1928,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "no_fused_gy")) g_tune_no_fused_gy = value;
     else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
+    else if (!strcmp(key, "no_xa")) g_tune_no_xa = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
@@ -1802,7 +1948,7 @@ int moka_ksplit_bwd(int T, int C, int r) {
 
 int moka_ksplit(int T, int C, int r) {
     if (rank_pad(r) < 0 || C < 32 || (C % 32) != 0 || T < 1) return MOKA_EINVAL;
-    return reduce_ks(T, C);
+    return fwd_ks(T, C, r);
 }
 
 // shared-input groups run as ONE kernel for r <= 16; wider ranks fall back to one launch per projection
@@ -1833,6 +1979,18 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
     a.tok_mod = tok_mod; a.T = T; a.r = r; a.M = M; a.ks = reduce_ks(T, d_in);
     a.in[0] = (const unsigned char*)x; a.C[0] = d_in;
     const int RP = rank_pad(r);
+    if (RP == 16 && !g_tune_no_xa) {
+        // r <= 16: weights of all modalities (and of all G projections) resident per wave, one split-K slice per 512 columns
+        XaArgs xa;
+        memset(&xa, 0, sizeof(xa));
+        xa.x = (const unsigned char*)x; xa.tok_mod = tok_mod; xa.T = T; xa.C = d_in; xa.r = r; xa.M = M;
+        for (int m = 0; m < M; ++m) xa.s_mod[m] = a.s_mod[m];
+        for (int g = 0; g < G; ++g) {
+            xa.part[g] = part[g]; xa.drop[g] = a.drop[g];
+            for (int m = 0; m < M; ++m) xa.A[g][m] = (const unsigned char*)A[g * M + m];
+        }
+        return G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
+    }
     if (G == 1 || can_group(r, G)) {
         for (int g = 0; g < G; ++g) {
             a.out[g] = part[g];
