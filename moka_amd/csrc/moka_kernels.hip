@@ -449,6 +449,46 @@ static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t
 // global loads at kernel start (routing bytes, key-token indices, the block's partial rows), one
 // dependent batch (the key rows), then LDS-only work: one wave per query row, one lane per key.
 // Every block also transposes a slice of Bw into BwT (weights do not change until the backward).
+// Weight shadows for the backward (the weights do not change before it runs), written by dedicated blocks of
+// the cross_fwd launch so that they run beside the row blocks instead of lengthening some of them:
+// BwT[k][c] = Bw[c][k]   and   AT[m][c][k] = A_m[k][c]
+template <int RP>
+static __device__ __forceinline__ void cross_weight_shadows(const CrossArgs& a, int bid, int nblk, int tid) {
+    if (a.BwT) {
+        for (int c = bid * 512 + tid; c < a.C; c += nblk * 512) {
+            // one contiguous row of Bw per thread (vector loads when r == RP), coalesced column writes
+            unsigned short row[RP];
+            if (a.r == RP) {
+#pragma unroll
+                for (int k8 = 0; k8 < RP / 8; ++k8) {
+                    const bf16x8 v = *(const bf16x8*)(a.Bw + (size_t)c * RP + 8 * k8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) row[8 * k8 + k] = (unsigned short)v[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RP; ++k) row[k] = (k < a.r) ? a.Bw[(size_t)c * a.r + k] : (unsigned short)0;
+            }
+#pragma unroll
+            for (int k = 0; k < RP; ++k) a.BwT[(size_t)k * a.C + c] = row[k];
+        }
+    }
+    if (a.AT) {
+        for (int e = bid * 512 + tid; e < a.M * a.Cin; e += nblk * 512) {
+            const int m = e / a.Cin, c = e % a.Cin;
+            bf16x8* dst = (bf16x8*)(a.AT + (size_t)e * RP);
+            const unsigned short* src = a.Aw[m] + c;
+#pragma unroll
+            for (int k8 = 0; k8 < RP / 8; ++k8) {
+                bf16x8 v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (8 * k8 + k < a.r) ? (short)src[(size_t)(8 * k8 + k) * a.Cin] : (short)0;
+                dst[k8] = v;
+            }
+        }
+    }
+}
+
 template <int RP, int KCH>
 __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cross_fwd_kernel(const CrossBatch ab) {
     const CrossArgs& a = ab.z[blockIdx.z];
@@ -460,6 +500,11 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     int* Kt = (int*)(Ks + (size_t)a.Lkp * KP); // [Lkp] flat key token indices
     __shared__ int s_mod[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrb = (a.S + a.RB - 1) / a.RB;            // row blocks; the blocks behind them only write the weight shadows
+    if ((int)blockIdx.y >= nrb) {
+        cross_weight_shadows<RP>(a, ((int)blockIdx.y - nrb) * gridDim.x + blockIdx.x, ((int)gridDim.y - nrb) * gridDim.x, tid);
+        return;
+    }
     const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
     const int nrow = min(a.RB, a.S - r0);
     // ---- batch 1: everything that does not depend on other loads
@@ -556,44 +601,8 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
         write_packs_fwd<RP>(a, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
     }
     // pack tail [T, Tp): zero (the weight-gradient kernel reads whole groups of 32 tokens)
-    if (b == a.B - 1 && blockIdx.y == gridDim.y - 1) {
+    if (b == a.B - 1 && blockIdx.y == nrb - 1) {
         for (int e = tid; e < (a.Tp - a.T) * RP; e += 512) write_packs_fwd<RP>(a, a.T + e / RP, e % RP, 0.f);
-    }
-    // weight shadows for the backward (weights do not change before it runs):
-    // BwT[k][c] = Bw[c][k]   and   AT[m][c][k] = A_m[k][c]
-    const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (a.BwT) {
-        for (int c = bid * 512 + tid; c < a.C; c += nblk * 512) {
-            // one contiguous row of Bw per thread (vector loads when r == RP), coalesced column writes
-            unsigned short row[RP];
-            if (a.r == RP) {
-#pragma unroll
-                for (int k8 = 0; k8 < RP / 8; ++k8) {
-                    const bf16x8 v = *(const bf16x8*)(a.Bw + (size_t)c * RP + 8 * k8);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) row[8 * k8 + k] = (unsigned short)v[k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < RP; ++k) row[k] = (k < a.r) ? a.Bw[(size_t)c * a.r + k] : (unsigned short)0;
-            }
-#pragma unroll
-            for (int k = 0; k < RP; ++k) a.BwT[(size_t)k * a.C + c] = row[k];
-        }
-    }
-    if (a.AT) {
-        for (int e = bid * 512 + tid; e < a.M * a.Cin; e += nblk * 512) {
-            const int m = e / a.Cin, c = e % a.Cin;
-            bf16x8* dst = (bf16x8*)(a.AT + (size_t)e * RP);
-            const unsigned short* src = a.Aw[m] + c;
-#pragma unroll
-            for (int k8 = 0; k8 < RP / 8; ++k8) {
-                bf16x8 v;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (8 * k8 + k < a.r) ? (short)src[(size_t)(8 * k8 + k) * a.Cin] : (short)0;
-                dst[k8] = v;
-            }
-        }
     }
 }
 
@@ -1755,7 +1764,14 @@ static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t s
     if (!bwd) {
         const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
         ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH>, lds);
-        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH>), grid, block, lds, st, ab);
+        // + blocks that write the weight shadows (one thread per BwT column / AT row)
+        long items = 0;
+        for (int z = 0; z < nz; ++z) {
+            const long it = (ab.z[z].BwT ? ab.z[z].C : 0) > (ab.z[z].AT ? (long)ab.z[z].M * ab.z[z].Cin : 0) ? ab.z[z].C : (ab.z[z].AT ? (long)ab.z[z].M * ab.z[z].Cin : 0);
+            items = it > items ? it : items;
+        }
+        dim3 gridf(grid.x, grid.y + (unsigned)((items + 512L * a.B - 1) / (512L * a.B)), nz);
+        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH>), gridf, block, lds, st, ab);
     } else {
         const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
         ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH>, lds);
@@ -1816,7 +1832,7 @@ template <bool W_CK>
 static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) {
     const bool deep = g_tune_expand_depth != 2;
     if (W_CK || nz == 1) {
-        if (RP == 16) { if (deep && !W_CK) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
+        if (RP == 16) { if ((deep && !W_CK) || g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
         else if (RP == 32) launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st);
         else launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st);
     } else {                                             // can_group(): RP == 16

@@ -109,7 +109,7 @@ def main():
         sweeps = {
             "down_fwd": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
-            "up_fwd": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
+            "up_fwd": [("expand_depth", 3)] + [("expand_bpc", v) for v in (2, 4, 8, 12, 16)],
             "down_bwd(dx only)": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
             "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)] + [("no_fused_gy", 1)],
             "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)],
