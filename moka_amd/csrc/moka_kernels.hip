@@ -1739,13 +1739,12 @@ static void launch_reduce_t(const ReduceArgs& a, int nz, hipStream_t st) {
     hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U, G, MIX>), grid, block, lds, st, a);
 }
 
-// G > 1: shared-input group (RP == 16 only, see can_group); G == 1: nz batched problems
-static int launch_reduce(const ReduceArgs& a, int RP, int G, int nz, hipStream_t st) {
+// nz batched problems (grid z).  The kernel's G > 1 mode (shared input) is kept in the source but no longer
+// instantiated: for r <= 16 moka_xa_kernel does that job, wider ranks run one launch per projection.
+static int launch_reduce(const ReduceArgs& a, int RP, int /*G*/, int nz, hipStream_t st) {
     if (RP == 16) {
         const int nw = g_tune_reduce_nw == 8 ? 8 : 4, u = g_tune_reduce_u == 4 ? 4 : 2;
-        if (G == 3) launch_reduce_t<16, 4, 2, 3, true>(a, 1, st);
-        else if (G == 2) launch_reduce_t<16, 4, 2, 2, true>(a, 1, st);
-        else if (a.shared_w) {
+        if (a.shared_w) {
             if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4, 1, false>(a, nz, st); else launch_reduce_t<16, 4, 2, 1, false>(a, nz, st); }
             else { if (u == 4) launch_reduce_t<16, 8, 4, 1, false>(a, nz, st); else launch_reduce_t<16, 8, 2, 1, false>(a, nz, st); }
         } else {
@@ -2007,14 +2006,7 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
         }
         return G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
     }
-    if (G == 1 || can_group(r, G)) {
-        for (int g = 0; g < G; ++g) {
-            a.out[g] = part[g];
-            for (int m = 0; m < M; ++m) a.W[g][m] = (const unsigned char*)A[g * M + m];
-        }
-        return launch_reduce(a, RP, G, 1, (hipStream_t)stream);
-    }
-    for (int g = 0; g < G; ++g) {                      // one launch per projection
+    for (int g = 0; g < G; ++g) {                      // r > 16 (or the no_xa diagnostic): one launch per projection
         ReduceArgs b = a;
         b.out[0] = part[g]; b.drop[0] = a.drop[g];
         for (int m = 0; m < M; ++m) b.W[0][m] = (const unsigned char*)A[g * M + m];
