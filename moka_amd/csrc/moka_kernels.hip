@@ -1867,7 +1867,7 @@ static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
     if (OUT_CK || nz == 1) {
         if (RP == 16) {
             if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK, 1>(ab, nz, st);
-            else if (g_tune_wgrad_nw == 4) launch_wgrad_t<16, 1, 4, OUT_CK, 1>(ab, nz, st);
+            else if (g_tune_wgrad_nw == 4 || (g_tune_wgrad_nw == 0 && !OUT_CK && ab.z[0].C > 8192)) launch_wgrad_t<16, 1, 4, OUT_CK, 1>(ab, nz, st);   // measured at C = 11008: 56 vs 60 us
             else launch_wgrad_t<16, 1, 8, OUT_CK, 1>(ab, nz, st);
         } else if (RP == 32) launch_wgrad_t<32, 1, 8, OUT_CK, 1>(ab, nz, st);
         else launch_wgrad_t<64, 1, 4, OUT_CK, 1>(ab, nz, st);
