@@ -278,6 +278,26 @@ def draw_seed() -> int:
     return (a << 31) | b
 
 
+def _grad_accumulators(shapes: Sequence[Tuple[int, int]], device) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """One zeroed fp32 buffer carved into the [rows, cols] accumulators the weight-gradient kernels add into
+    (one memset and, afterwards, one cast for all of them instead of one tiny kernel per tensor)."""
+    sizes = [a * b for a, b in shapes]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    views, off = [], 0
+    for (a, b), n in zip(shapes, sizes):
+        views.append(flat[off:off + n].view(a, b))
+        off += n
+    return flat, views
+
+
+def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[torch.Tensor]:
+    out, off = [], 0
+    for a, b in shapes:
+        out.append(flat[off:off + a * b].view(a, b))
+        off += a * b
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # autograd node of one adapted projection
 # --------------------------------------------------------------------------------------
@@ -341,19 +361,25 @@ class MokaLinearFn(torch.autograd.Function):
         need_A = any(ctx.needs_input_grad[6:])
         if ctx.needs_input_grad[1]:
             raise _lib.MokaError("moka_amd: the base weight is frozen in MokA; requires_grad on it is not supported")
-        dB_acc = torch.zeros((Bw.shape[0], r), dtype=torch.float32, device=gy2.device) if need_B else None
+        shapes = ([(Bw.shape[0], r)] if need_B else []) + ([(r, x2.shape[1])] * len(A) if need_A else [])
+        flat, acc = _grad_accumulators(shapes, gy2.device) if shapes else (None, [])
+        dB_acc = acc[0] if need_B else None
+        dA_acc = acc[(1 if need_B else 0):] if need_A else None
         g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc)
         dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
-        gA = [None] * len(A)
         if need_A or need_x:
             bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
-            dA_acc = [torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=gy2.device) for _ in A] if need_A else None
             down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed)
+        gB, gA = None, [None] * len(A)
+        if flat is not None:
+            cast = _split_like(flat.to(Bw.dtype), shapes)             # one cast kernel for all weight gradients
+            if need_B:
+                gB = cast[0]
             if need_A:
-                gA = [dA_acc[m].to(A[m].dtype) if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
+                ca = cast[(1 if need_B else 0):]
+                gA = [ca[m] if ctx.needs_input_grad[6 + m] else None for m in range(len(A))]
         gbias = gy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return (None if dx2 is None else dx2.reshape(ctx.x_shape), None, gbias,
-                None if dB_acc is None else dB_acc.to(Bw.dtype), None, None, *gA)
+        return (None if dx2 is None else dx2.reshape(ctx.x_shape), None, gbias, gB, None, None, *gA)
 
 
 def moka_linear(x, W, bias, Bw, A: Sequence[torch.Tensor], rt: MokaRouting, spec: AdapterSpec):
@@ -446,7 +472,9 @@ class MokaLinearGroupFn(torch.autograd.Function):
         need_x = nig[0]
         need_B = any(nig[base + g * per + 2] for g in range(G))
         need_A = any(nig[base + g * per + 3 + m] for g in range(G) for m in range(M))
-        dB_accs = [torch.zeros((Bws[g].shape[0], r), dtype=torch.float32, device=dev) for g in range(G)] if need_B else None
+        shapes = ([(Bws[g].shape[0], r) for g in range(G)] if need_B else []) + ([(r, x2.shape[1])] * (G * M) if need_A else [])
+        flat, acc = _grad_accumulators(shapes, dev) if shapes else (None, [])
+        dB_accs = acc[:G] if need_B else None
         g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs)
         dx2 = None
         if need_x:
@@ -457,13 +485,16 @@ class MokaLinearGroupFn(torch.autograd.Function):
         if need_A or need_x:
             bsts = cross_bwd_group(g_parts, hs, rt, r, sp.s_in, sp.w, sp.inv_sqrt_dk)
             if need_A:
-                dA_accs = [[torch.zeros((r, x2.shape[1]), dtype=torch.float32, device=dev) for _ in range(M)] for _ in range(G)]
+                a0 = G if need_B else 0
+                dA_accs = [acc[a0 + g * M:a0 + (g + 1) * M] for g in range(G)]
             down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, [s_.seed for s_ in specs])
+        cast = _split_like(flat.to(x2.dtype), shapes) if flat is not None else []      # one cast kernel for all weight gradients
         grads = []
         for g in range(G):
             gbias = gy2[g].sum(0) if (ctx.has_bias[g] and nig[base + g * per + 1]) else None
-            gB = dB_accs[g].to(Bws[g].dtype) if (need_B and nig[base + g * per + 2]) else None
-            gA = [dA_accs[g][m].to(As[g][m].dtype) if (need_A and nig[base + g * per + 3 + m]) else None for m in range(M)]
+            gB = cast[g] if (need_B and nig[base + g * per + 2]) else None
+            a0 = G if need_B else 0
+            gA = [cast[a0 + g * M + m] if (need_A and nig[base + g * per + 3 + m]) else None for m in range(M)]
             grads += [None, gbias, gB, *gA]
         return (None if dx2 is None else dx2.reshape(ctx.x_shape), None, None, None, None, *grads)
 
