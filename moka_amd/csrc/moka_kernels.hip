@@ -453,9 +453,9 @@ static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t
 // the cross_fwd launch so that they run beside the row blocks instead of lengthening some of them:
 // BwT[k][c] = Bw[c][k]   and   AT[m][c][k] = A_m[k][c]
 template <int RP>
-static __device__ __forceinline__ void cross_weight_shadows(const CrossArgs& a, int bid, int nblk, int tid) {
+static __device__ __forceinline__ void cross_weight_shadows(const CrossArgs& a, int bid, int nblk, int tid, int nth) {
     if (a.BwT) {
-        for (int c = bid * 512 + tid; c < a.C; c += nblk * 512) {
+        for (int c = bid * nth + tid; c < a.C; c += nblk * nth) {
             // one contiguous row of Bw per thread (vector loads when r == RP), coalesced column writes
             unsigned short row[RP];
             if (a.r == RP) {
@@ -474,7 +474,7 @@ static __device__ __forceinline__ void cross_weight_shadows(const CrossArgs& a, 
         }
     }
     if (a.AT) {
-        for (int e = bid * 512 + tid; e < a.M * a.Cin; e += nblk * 512) {
+        for (int e = bid * nth + tid; e < a.M * a.Cin; e += nblk * nth) {
             const int m = e / a.Cin, c = e % a.Cin;
             bf16x8* dst = (bf16x8*)(a.AT + (size_t)e * RP);
             const unsigned short* src = a.Aw[m] + c;
@@ -489,8 +489,9 @@ static __device__ __forceinline__ void cross_weight_shadows(const CrossArgs& a, 
     }
 }
 
-template <int RP, int KCH>
-__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cross_fwd_kernel(const CrossBatch ab) {
+template <int RP, int KCH, int NTH>
+__global__ void __launch_bounds__(NTH) moka_cross_fwd_kernel(const CrossBatch ab) {
+    constexpr int NWV = NTH / 64;
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = RP + 1;
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrb = (a.S + a.RB - 1) / a.RB;            // row blocks; the blocks behind them only write the weight shadows
     if ((int)blockIdx.y >= nrb) {
-        cross_weight_shadows<RP>(a, ((int)blockIdx.y - nrb) * gridDim.x + blockIdx.x, ((int)gridDim.y - nrb) * gridDim.x, tid);
+        cross_weight_shadows<RP>(a, ((int)blockIdx.y - nrb) * gridDim.x + blockIdx.x, ((int)gridDim.y - nrb) * gridDim.x, tid, NTH);
         return;
     }
     const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
@@ -511,8 +512,8 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     const int klen_b = a.klen[b];
     int my_mod = MOKA_MOD_NONE;
     if (tid < nrow) my_mod = a.tok_mod[b * a.S + r0 + tid];
-    for (int j = tid; j < a.Lkp; j += 512) Kt[j] = a.ktok[b * a.Lkp + j];
-    for (int e = tid; e < 32 * RP; e += 512) {
+    for (int j = tid; j < a.Lkp; j += NTH) Kt[j] = a.ktok[b * a.Lkp + j];
+    for (int e = tid; e < 32 * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         float v = 0.f;
         if (row < nrow) {
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     const int Lk = min(klen_b, a.Lk_max);
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     // tokens of no modality: h = 0 (their partial rows were never written)
-    for (int e = tid; e < 32 * RP; e += 512) {
+    for (int e = tid; e < 32 * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         float v = Hs[row * KP + k];
         if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     }
     if (anyq) {
         // ---- batch 2: the sample's key rows (indices are in LDS by now)
-        for (int e = tid; e < Lk * RP; e += 512) {
+        for (int e = tid; e < Lk * RP; e += NTH) {
             const int j = e / RP, k = e % RP;
             const int t = Kt[j];
             float v = 0.f;
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
             Ks[j * KP + k] = v;
         }
         __syncthreads();
-        for (int row = wave; row < nrow; row += 8) {
+        for (int row = wave; row < nrow; row += NWV) {
             const int m = s_mod[row];
             if (m == 0 || m == MOKA_MOD_NONE) continue;           // wave uniform
             float q[RP];
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
         }
     }
     __syncthreads();
-    for (int e = tid; e < nrow * RP; e += 512) {
+    for (int e = tid; e < nrow * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         const int t = b * a.S + r0 + row;
         const float hv = Hs[row * KP + k], hpv = Hp[row * KP + k];
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
     }
     // pack tail [T, Tp): zero (the weight-gradient kernel reads whole groups of 32 tokens)
     if (b == a.B - 1 && blockIdx.y == nrb - 1) {
-        for (int e = tid; e < (a.Tp - a.T) * RP; e += 512) write_packs_fwd<RP>(a, a.T + e / RP, e % RP, 0.f);
+        for (int e = tid; e < (a.Tp - a.T) * RP; e += NTH) write_packs_fwd<RP>(a, a.T + e / RP, e % RP, 0.f);
     }
 }
 
@@ -610,8 +611,9 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 2) ? 4 : 2) moka_cros
 // and per-lane key/value gradients; the block's dK is combined in LDS and written to the block's own
 // partial slot.  Rows that are themselves key rows are finished by part b (their dq, if any, joins
 // their dK slot).
-template <int RP, int KCH>
-__global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cross_bwd_kernel(const CrossBatch ab) {
+template <int RP, int KCH, int NTH>
+__global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab) {
+    constexpr int NWV = NTH / 64;
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KP = RP + 1;
@@ -630,13 +632,13 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
     const int klen_b = a.klen[b];
     int my_mod = MOKA_MOD_NONE, my_slot = -1;
     if (tid < nrow) { my_mod = a.tok_mod[b * a.S + r0 + tid]; my_slot = a.kslot[b * a.S + r0 + tid]; }
-    for (int j = tid; j < a.Lkp; j += 512) Kt[j] = a.ktok[b * a.Lkp + j];
+    for (int j = tid; j < a.Lkp; j += NTH) Kt[j] = a.ktok[b * a.Lkp + j];
     // g rows = sum of the split-K slices (up to 22 for a 11008-wide gy): all 512 threads take part, the slices of
     // one element are dealt round-robin to 512 / (RB * RP) thread groups, partial sums meet in LDS (Dh as scratch)
     const int NE = a.RB * RP;                              // elements of the block
     const bool split = (NE <= 256);
     if (split) {
-        const int nsg = 512 / NE, sg = tid / NE, el = tid - sg * NE;
+        const int nsg = NTH / NE, sg = tid / NE, el = tid - sg * NE;
         if (sg < nsg) {
             const int row = el / RP, k = el % RP;
             float v = 0.f;
@@ -644,7 +646,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
             Dh[sg * NE + el] = v;                          // NE * nsg <= 512 <= 32 * KP floats
         }
     }
-    for (int e = tid; e < 32 * RP; e += 512) {
+    for (int e = tid; e < 32 * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         float v = 0.f, hv = 0.f;
         if (row < nrow) {
@@ -659,8 +661,8 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
     const int Lk = min(klen_b, a.Lk_max);
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     if (split) {
-        const int nsg = 512 / NE;
-        for (int e = tid; e < 32 * RP; e += 512) {
+        const int nsg = NTH / NE;
+        for (int e = tid; e < 32 * RP; e += NTH) {
             const int row = e / RP, k = e % RP;
             float v = 0.f;
             if (row < a.RB) {
@@ -670,7 +672,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
         }
         __syncthreads();
     }
-    for (int e = tid; e < 32 * RP; e += 512) {
+    for (int e = tid; e < 32 * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         float v = Gs[row * KP + k];
         if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;   // unwritten partial rows
@@ -679,7 +681,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
     }
     if (anyq) {
         // ---- batch 2: key rows of h
-        for (int e = tid; e < Lk * RP; e += 512) {
+        for (int e = tid; e < Lk * RP; e += NTH) {
             const int j = e / RP, k = e % RP;
             const int t = Kt[j];
             Ks[j * KP + k] = (t >= 0) ? a.hfull[(size_t)t * RP + k] : 0.f;
@@ -691,7 +693,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
         for (int ch = 0; ch < KCH; ++ch)
 #pragma unroll
             for (int k = 0; k < RP; ++k) dK[ch][k] = 0.f;
-        for (int row = wave; row < nrow; row += 8) {
+        for (int row = wave; row < nrow; row += NWV) {
             const int m = s_mod[row];
             if (m == 0 || m == MOKA_MOD_NONE) continue;
             float q[RP], dO[RP];
@@ -749,7 +751,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
         }
         // combine the 8 waves' key/value gradients: one wave at a time, plain LDS read-modify-write
         // (measured: LDS fp32 atomics cost ~700 cycles per wave instruction under 8-wave contention)
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < NWV; ++w) {
             if (wave == w) {
 #pragma unroll
                 for (int ch = 0; ch < KCH; ++ch) {
@@ -763,19 +765,19 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
             __syncthreads();
         }
         // a key row that is also a query row (masks may overlap in VT): its dq joins its own dK slot
-        for (int e = tid; e < nrow * RP; e += 512) {
+        for (int e = tid; e < nrow * RP; e += NTH) {
             const int row = e / RP, k = e % RP;
             const int slot = s_slot[row];
             if (slot >= 0) dKs[slot * KP + k] += Dh[row * KP + k] - Gs[row * KP + k];
         }
         __syncthreads();
         float* dst = a.dk_part + ((size_t)b * gridDim.y + blockIdx.y) * a.Lkp * RP;
-        for (int e = tid; e < Lk * RP; e += 512) dst[e] = dKs[(e / RP) * KP + (e % RP)];
+        for (int e = tid; e < Lk * RP; e += NTH) dst[e] = dKs[(e / RP) * KP + (e % RP)];
     } else {
         __syncthreads();
     }
     if (tid == 0) a.dk_flag[b * gridDim.y + blockIdx.y] = anyq ? 1 : 0;
-    for (int e = tid; e < nrow * RP; e += 512) {
+    for (int e = tid; e < nrow * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         if (s_slot[row] >= 0) continue;                   // key row: finished by part b
         const int t = b * a.S + r0 + row;
@@ -785,7 +787,7 @@ __global__ void __launch_bounds__(512, (RP == 16 && KCH <= 1) ? 4 : 2) moka_cros
         write_packs_bwd<RP>(a, t, k, m, (m == MOKA_MOD_NONE) ? 0.f : dv * a.s_mod[0]);
     }
     if (b == a.B - 1 && blockIdx.y == gridDim.y - 1) {
-        for (int e = tid; e < (a.Tp - a.T) * RP; e += 512) write_packs_bwd<RP>(a, a.T + e / RP, e % RP, MOKA_MOD_NONE, 0.f);
+        for (int e = tid; e < (a.Tp - a.T) * RP; e += NTH) write_packs_bwd<RP>(a, a.T + e / RP, e % RP, MOKA_MOD_NONE, 0.f);
     }
 }
 
@@ -1673,7 +1675,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1756,27 +1758,35 @@ static int launch_reduce(const ReduceArgs& a, int RP, int /*G*/, int nz, hipStre
     return check_launch("moka_reduce_kernel");
 }
 
-template <int RP, int KCH>
-static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
+template <int RP, int KCH, int NTH>
+static void launch_cross_t2(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
     const CrossArgs& a = ab.z[0];
-    dim3 grid(a.B, (a.S + a.RB - 1) / a.RB, nz), block(512);
+    dim3 grid(a.B, (a.S + a.RB - 1) / a.RB, nz), block(NTH);
     if (!bwd) {
         const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
-        ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH>, lds);
+        ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH, NTH>, lds);
         // + blocks that write the weight shadows (one thread per BwT column / AT row)
         long items = 0;
         for (int z = 0; z < nz; ++z) {
             const long it = (ab.z[z].BwT ? ab.z[z].C : 0) > (ab.z[z].AT ? (long)ab.z[z].M * ab.z[z].Cin : 0) ? ab.z[z].C : (ab.z[z].AT ? (long)ab.z[z].M * ab.z[z].Cin : 0);
             items = it > items ? it : items;
         }
-        dim3 gridf(grid.x, grid.y + (unsigned)((items + 512L * a.B - 1) / (512L * a.B)), nz);
-        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH>), gridf, block, lds, st, ab);
+        dim3 gridf(grid.x, grid.y + (unsigned)((items + (long)NTH * a.B - 1) / ((long)NTH * a.B)), nz);
+        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH, NTH>), gridf, block, lds, st, ab);
     } else {
         const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
-        ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH>, lds);
-        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH>), grid, block, lds, st, ab);
+        ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH, NTH>, lds);
+        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH, NTH>), grid, block, lds, st, ab);
         hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16, nz), dim3(256), (size_t)grid.y * 4, st, ab, (int)grid.y);
     }
+}
+
+// 4-wave blocks: the blocks are latency- not throughput-bound, so twice as many of them per CU halve the number of
+// rounds (the common r <= 16 / Lk <= 64 case; the wider variants keep 8 waves for their register budget)
+template <int RP, int KCH>
+static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
+    if (RP == 16 && KCH == 1 && g_tune_cross_nth != 512 && (bwd || nz > 1 || g_tune_cross_nth == 256)) launch_cross_t2<RP, KCH, (RP == 16 && KCH == 1) ? 256 : 512>(bwd, ab, nz, st);
+    else launch_cross_t2<RP, KCH, 512>(bwd, ab, nz, st);
 }
 
 // fills the routing fields of every problem and launches the batch
@@ -1944,6 +1954,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
     else if (!strcmp(key, "no_xa")) g_tune_no_xa = value;
+    else if (!strcmp(key, "cross_nth")) g_tune_cross_nth = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;

@@ -114,8 +114,8 @@ def main():
             "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)] + [("no_fused_gy", 1)],
             "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)],
             "down_bwd(dA only)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2)],
-            "cross_fwd": [("cross_rows", v) for v in (32, 16, 8)],
-            "cross_bwd": [("cross_rows", v) for v in (32, 16, 8)],
+            "cross_fwd": [("cross_nth", 512)] + [("cross_rows", v) for v in (16, 8)],
+            "cross_bwd": [("cross_nth", 512)] + [("cross_rows", v) for v in (16, 8)],
         }
         print(f"\n=== {d_in} -> {d_out}  (T={T}) ===")
         for name, fn in cs.items():
