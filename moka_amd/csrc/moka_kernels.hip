@@ -901,11 +901,18 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     // DEPTH token tiles in flight per wave: while tile k is multiplied and stored, the routing bytes, the
     // pack rows and the in/out rows of the next DEPTH-1 tiles are already on their way (HBM latency).  Every load of
     // the prefetch is unconditional (the tile index is clamped), see the note on vmcnt in the reduce kernel.
+    // FAST (decided once per wave): my columns are all inside C, T is a multiple of 16 and none of my tiles is pure
+    // padding -> every load AND every store of the loop is unconditional.  A conditionally issued memory
+    // operation makes the compiler's vmcnt bookkeeping conservative; with conditional stores in the loop every
+    // tile waited for the stores of the previous one to be acknowledged (ISA: s_waitcnt vmcnt(2) in front of each
+    // store, vmcnt(0) at the loop head).  The general path keeps the guards.
     struct Tile {
         int mrow;
         bf16x8 bh[G][KH], bl[G][KH];
         bf16x8 o[NQ];
     };
+    auto body = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     auto issue = [&](Tile& R, int tile) {
         const int tt = min(tile, ntiles - 1);
         const int t = min((tt << 4) + i, a.T - 1);                // operand / result lanes: token = lane & 15
@@ -927,7 +934,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         const unsigned char* orow = a.out + ((size_t)t * a.C + c_wave + 8 * g) * 2;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (c_wave + 32 * q < a.C) R.o[q] = *(const bf16x8*)(orow + 64 * q);   // block-uniform condition
+            if (FAST || c_wave + 32 * q < a.C) R.o[q] = *(const bf16x8*)(orow + 64 * q);   // wave-uniform condition
     };
 
     auto process = [&](Tile& R, int tile, Tile& N, int next_tile) {
@@ -936,7 +943,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         const int mrow = R.mrow;
         const int m0 = __builtin_amdgcn_readfirstlane(mrow);
         const bool same = __all(mrow == m0);
-        if (same && m0 == MOKA_MOD_NONE) { issue(N, next_tile); return; }      // padding tile: nothing to add
+        if (!FAST && same && m0 == MOKA_MOD_NONE) { issue(N, next_tile); return; }      // padding tile: nothing to add
         unsigned char* orow = a.out + ((size_t)min(t, a.T - 1) * a.C + c_wave + 8 * g) * 2;
 
         float sum[NQ][8];
@@ -1014,7 +1021,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
             const ExpandArgs& ag = ab.z[G == 1 ? blockIdx.z : gi];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (c_wave + 32 * q >= a.C) continue;
+                if (!FAST && c_wave + 32 * q >= a.C) continue;
                 // element e of my 16-byte chunk = d[q][e >> 2][e & 3]; dropout keeps it iff its 16-bit mask field is set:
                 // the field is sign-extended to a dword mask and ANDed onto the fp32 product (3 VALU ops per element)
                 float v[8];
@@ -1038,7 +1045,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
                     for (int w2 = 0; w2 < 4; ++w2)
                         res.u[w2] = f2bf_pk(fmaf(v[2 * w2], dsc, __uint_as_float(ou.u[w2] << 16)),
                                             fmaf(v[2 * w2 + 1], dsc, __uint_as_float(ou.u[w2] & 0xffff0000u)));
-                    if (valid) *(bf16x8*)(orow + 64 * q) = res.b;
+                    if (FAST || valid) *(bf16x8*)(orow + 64 * q) = res.b;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sum[q][e] = fmaf(v[e], dsc, sum[q][e]);
@@ -1048,13 +1055,13 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         if constexpr (G > 1) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (c_wave + 32 * q >= a.C) continue;
+                if (!FAST && c_wave + 32 * q >= a.C) continue;
                 union { bf16x8 b; unsigned u[4]; } ou, res;
                 ou.b = R.o[q];
 #pragma unroll
                 for (int w2 = 0; w2 < 4; ++w2)
                     res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[q][2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[q][2 * w2 + 1]);
-                if (valid) *(bf16x8*)(orow + 64 * q) = res.b;
+                if (FAST || valid) *(bf16x8*)(orow + 64 * q) = res.b;
             }
         }
     };
@@ -1073,6 +1080,25 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
             process(ring[d], tj, ring[(d + DEPTH - 1) % DEPTH], tj + (DEPTH - 1) * step);
         }
     }
+    };   // body
+
+    // one 16-byte look at the routing bytes of each of my tiles (lane j <-> my j-th tile) decides the path
+    bool fast = (c_wave + WC <= a.C) && (a.T % 16 == 0) && (((size_t)a.tok_mod & 15) == 0);
+    {
+        const int step = gridDim.y;
+        const int nmine = (ntiles - (int)blockIdx.y + step - 1) / step;
+        if (nmine > 64) fast = false;
+        if (fast) {
+            bool pad = false;
+            if (lane < nmine) {
+                const uint4 m = *(const uint4*)(a.tok_mod + ((size_t)(blockIdx.y + lane * step) << 4));
+                pad = (m.x & m.y & m.z & m.w) == 0xffffffffu;      // all 16 tokens of the tile have no modality
+            }
+            if (__any(pad)) fast = false;
+        }
+    }
+    if (fast) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1839,14 +1865,14 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
 // W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
 template <bool W_CK>
 static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) {
-    const bool deep = g_tune_expand_depth != 2;
+    // two tiles in flight per wave everywhere (measured: 3-4 deep rings gain nothing once loads and stores are unconditional)
     if (W_CK || nz == 1) {
-        if (RP == 16) { if ((deep && !W_CK) || g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
+        if (RP == 16) { if (g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
         else if (RP == 32) launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st);
         else launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st);
     } else {                                             // can_group(): RP == 16
-        if (nz == 2) { if (deep) launch_expand_t<16, 2, false, 2, 4>(ab, 1, st); else launch_expand_t<16, 2, false, 2, 2>(ab, 1, st); }
-        else { if (deep) launch_expand_t<16, 2, false, 3, 3>(ab, 1, st); else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st); }
+        if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
+        else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st);
     }
     return check_launch("moka_expand_kernel");
 }
