@@ -1884,7 +1884,8 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     for (int z = 0; z < nz; ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
     const int nc = (Cmax + CCB - 1) / CCB;
     const int ngroups = ab.z[0].Tp / 32;
-    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : 1;
+    // 4-wave blocks (wide inputs): three per CU, so that the 172 column blocks of an 11008-wide input spread evenly (55 -> 50 us)
+    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : ((NW == 4 && G == 1) ? 3 : 1);
     const int nzg = (G == 1) ? nz : 1;                  // grid z
     int nb = (bpc * num_cu() + nc * nzg - 1) / (nc * nzg);
     if (nb > (ngroups + NW - 1) / NW) nb = (ngroups + NW - 1) / NW;

@@ -113,7 +113,7 @@ def main():
             "down_bwd(dx only)": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
             "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)] + [("no_fused_gy", 1)],
             "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)],
-            "down_bwd(dA only)": [("wgrad_nw", v) for v in (4,)] + [("wgrad_bpc", v) for v in (1, 2)],
+            "down_bwd(dA only)": [("wgrad_bpc", v) for v in (1, 2, 3, 4, 6, 8)],
             "cross_fwd": [("cross_nth", 512)] + [("cross_rows", v) for v in (16, 8)],
             "cross_bwd": [("cross_nth", 512)] + [("cross_rows", v) for v in (16, 8)],
         }
