@@ -88,7 +88,7 @@ const char* moka_last_error(void);
 int         moka_device_check(void);
 
 /* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_u", "reduce_ks", "expand_bpc", "wgrad_ct",
- * "wgrad_bpc", "cross_rows", "no_fused_gy", "gy_ng", "expand_depth", "no_xa", "cross_nth"; value 0 restores the default).  Results never depend on it. */
+ * "wgrad_bpc", "cross_rows", "no_fused_gy", "gy_ng", "expand_depth", "no_xa", "cross_nth", "xa_ng"; value 0 restores the default).  Results never depend on it. */
 int moka_tune(const char* key, int value);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */

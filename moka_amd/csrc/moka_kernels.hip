@@ -1701,7 +1701,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_xa_ng = 0, g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1941,13 +1941,23 @@ static int launch_gy(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     return check_launch("moka_gy_kernel");
 }
 
-template <int G>
-static int launch_xa(const XaArgs& a, hipStream_t st) {
-    constexpr int NG = 4, PH = 2;
+template <int G, int NG>
+static void launch_xa_t(const XaArgs& a, hipStream_t st) {
+    constexpr int PH = 2;
     const int ncb = (a.C + 511) / 512, ntb = (((a.T + 31) >> 5) + NG - 1) / NG;
     const size_t lds = (size_t)8 * PH * G * 32 * 16 * 4;
     ensure_lds((const void*)moka_xa_kernel<G, NG>, lds);
     hipLaunchKernelGGL((moka_xa_kernel<G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
+}
+
+template <int G>
+static int launch_xa(const XaArgs& a, hipStream_t st) {
+    // groups per block (measured at T = 8192): three projections amortise their 18 resident weight fragments over longer runs,
+    // a wide single projection prefers more, shorter blocks
+    const int ng = (g_tune_xa_ng == 2 || g_tune_xa_ng == 4 || g_tune_xa_ng == 8) ? g_tune_xa_ng : (G == 3 ? 8 : ((G == 1 && a.C > 8192) ? 2 : 4));
+    if (ng == 2) launch_xa_t<G, 2>(a, st);
+    else if (ng == 8) launch_xa_t<G, 8>(a, st);
+    else launch_xa_t<G, 4>(a, st);
     return check_launch("moka_xa_kernel");
 }
 
@@ -1982,6 +1992,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
     else if (!strcmp(key, "no_xa")) g_tune_no_xa = value;
     else if (!strcmp(key, "cross_nth")) g_tune_cross_nth = value;
+    else if (!strcmp(key, "xa_ng")) g_tune_xa_ng = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;

@@ -70,7 +70,7 @@ def main():
             "down_bwd(dx only)": (lambda i: F.down_bwd_group_(bsts, xs[i % NBUF], [s.AT for s in sts], rt, r, None, dxs[i % NBUF], DROP, seeds), 2 * E * T * d_in * G),
         }
         sweeps = {"up_fwd": [("expand_bpc", v) for v in (2, 4, 8)], "down_bwd(dx only)": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
-                  "down_bwd(dA only)": [("wgrad_bpc", v) for v in (1, 2)], "down_fwd": [("reduce_ks", v) for v in (1, 2, 4)],
+                  "down_bwd(dA only)": [("wgrad_bpc", v) for v in (1, 2)], "down_fwd": [("xa_ng", v) for v in (2, 4, 8)],
                   "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)], "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)]}
         print(f"\n=== G={G}: {d_in} -> {'/'.join(map(str, d_outs))}  (T={T}, dropout {DROP}) ===")
         for name, (fn, nb) in calls.items():

@@ -107,7 +107,7 @@ def main():
         algo = {"down_fwd": E * T * d_in, "up_fwd": 2 * E * T * d_out, "up_bwd(g only)": E * T * d_out, "up_bwd(dB only)": E * T * d_out, "up_bwd(g+dB)": E * T * d_out,
                 "down_bwd(dA only)": E * T * d_in, "down_bwd(dx only)": 2 * E * T * d_in, "cross_fwd": 0, "cross_bwd": 0}
         sweeps = {
-            "down_fwd": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
+            "down_fwd": [("xa_ng", v) for v in (2, 4, 8)] + [("no_xa", 1)],
             "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
             "up_fwd": [("expand_depth", 3)] + [("expand_bpc", v) for v in (2, 4, 8, 12, 16)],
             "down_bwd(dx only)": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
