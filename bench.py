@@ -462,10 +462,10 @@ def main():
             "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Llama-2-7B dims, MokA r=16 M=3 (AVT semantics), adapter fwd+bwd of 7x%d projections, "
+            "config": {"workload": "Llama-2-7B dims, MokA r=%d M=3 (AVT semantics), adapter fwd+bwd of 7x%d projections, "
                                    "seq=2048 (256 image + 128 audio + 64 question + text), lora_dropout %g, batch %d seq/GPU, %s, "
                                    "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params"
-                                   % (args.layers, args.dropout, args.batch,
+                                   % (args.rank, args.layers, args.dropout, args.batch,
                                       "one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points"),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
