@@ -124,13 +124,20 @@ class Unit:
 def build_workload(args, dev, lib, bucket_factory):
     from moka_amd import _lib
     from moka_amd.routing import MokaRouting
-    B, S, r, M = args.batch, args.seq, args.rank, 3
+    vt = args.variant == "vt"
+    B, S, r, M = args.batch, args.seq, args.rank, (2 if vt else 3)
     d, ff, L = LLAMA7B["d"], LLAMA7B["ff"], args.layers
     T = B * S
     tok, q = synthetic_layout(S)
-    masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
-    masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
-    rt = MokaRouting.from_avt_masks(masks)
+    if vt:
+        # BASELINE.json configs[1]: visual-text -- the audio span becomes text, bool [B,S] masks (VisualText/train/train.py:206-231)
+        tok = torch.where(tok == 2, torch.zeros_like(tok), tok)
+        masks = [(tok == 0).reshape(1, S).repeat(B, 1).to(dev), (tok == 1).reshape(1, S).repeat(B, 1).to(dev), q.reshape(1, S).repeat(B, 1).to(dev)]
+        rt = MokaRouting.from_vt_masks(*masks)
+    else:
+        masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
+        masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
+        rt = MokaRouting.from_avt_masks(masks)
     RP = _lib.rank_pad(r)
     bf, f32 = torch.bfloat16, torch.float32
     width = lambda k: d if k == "d" else ff          # noqa: E731
@@ -196,7 +203,8 @@ def build_workload(args, dev, lib, bucket_factory):
         for src, pis in unit_defs:
             mem = [members[pi] for pi in pis]
             units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch,
-                              s, [1.0] * M, 1.0, 1.0 / math.sqrt(r), args.dropout, [1000003 * l + pi for pi in pis]))
+                              1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
+                              [1000003 * l + pi for pi in pis]))
         layer_end.append(off)
     assert off == n_params
     work.copy_(master)
@@ -343,6 +351,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--variant", choices=("avt", "vt"), default="avt",
+                    help="avt: 3 modalities, the headline workload; vt: 2 modalities (BASELINE.json configs[1], 256 image tokens + text)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -462,10 +472,12 @@ def main():
             "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Llama-2-7B dims, MokA r=%d M=3 (AVT semantics), adapter fwd+bwd of 7x%d projections, "
-                                   "seq=2048 (256 image + 128 audio + 64 question + text), lora_dropout %g, batch %d seq/GPU, %s, "
+            "config": {"workload": "Llama-2-7B dims, MokA r=%d %s, adapter fwd+bwd of 7x%d projections, "
+                                   "seq=%d (%s), lora_dropout %g, batch %d seq/GPU, %s, "
                                    "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params"
-                                   % (args.rank, args.layers, args.dropout, args.batch,
+                                   % (args.rank, "M=2 (VT semantics)" if args.variant == "vt" else "M=3 (AVT semantics)", args.layers, args.seq,
+                                      "256 image + 64 question + text" if args.variant == "vt" else "256 image + 128 audio + 64 question + text",
+                                      args.dropout, args.batch,
                                       "one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points"),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
