@@ -1701,7 +1701,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_xa_ng = 0, g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
+static int g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
            g_tune_cross_rows = 0;
 
 static int num_cu() {
@@ -1868,8 +1868,9 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
     // two tiles in flight per wave everywhere (measured: 3-4 deep rings gain nothing once loads and stores are unconditional)
     if (W_CK || nz == 1) {
         if (RP == 16) { if (g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
-        else if (RP == 32) launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st);
-        else launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st);
+        // wider ranks: the y kernel keeps 128 columns per wave (r = 64: 48 -> 34 us at 4096), the dx kernel 64
+        else if (RP == 32) { if (W_CK && g_tune_expand_nq != 2) launch_expand_t<32, 4, W_CK, 1, 2>(ab, nz, st); else launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st); }
+        else { if (W_CK && g_tune_expand_nq != 1 && g_tune_expand_nq != 2) launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); else if (g_tune_expand_nq == 1) launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st); else launch_expand_t<64, 2, W_CK, 1, 2>(ab, nz, st); }
     } else {                                             // can_group(): RP == 16
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
         else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st);
@@ -1993,6 +1994,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "no_xa")) g_tune_no_xa = value;
     else if (!strcmp(key, "cross_nth")) g_tune_cross_nth = value;
     else if (!strcmp(key, "xa_ng")) g_tune_xa_ng = value;
+    else if (!strcmp(key, "expand_nq")) g_tune_expand_nq = value;
     else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
