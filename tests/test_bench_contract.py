@@ -1,0 +1,42 @@
+"""bench.py helpers that carry the measurement contract -- no GPU needed."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+bench = importlib.import_module("bench")
+
+
+def test_algorithmic_bytes_match_survey_totals():
+    fwd, bwd = bench.algorithmic_bytes_per_token(4096, 11008, 16, 32)
+    # 7B r=16: fwd 7.731 + bwd 9.573 = 17.305 MB/token
+    assert abs(fwd / 1e6 - 7.731) < 2e-3 and abs(bwd / 1e6 - 9.573) < 2e-3
+    assert abs((fwd + bwd) / 1e6 - 17.305) < 3e-3
+
+
+def test_synthetic_layout_is_the_survey_layout():
+    from oracle import cases as C
+    for S in (2048, 4096, 512):
+        tok, q = bench.synthetic_layout(S)
+        tok2, q2 = C.build_layout(C.synthetic_sequence_layout(S), S)
+        assert torch.equal(tok, tok2) and torch.equal(q, q2)
+    tok, q = bench.synthetic_layout(2048)
+    assert int((tok == 1).sum()) == 256 and int((tok == 2).sum()) == 128 and int(q.sum()) == 64
+    assert bool((tok[q] == 0).all())                      # question tokens are text tokens, contiguous
+    idx = torch.where(q)[0]
+    assert int(idx[-1] - idx[0]) == 63
+
+
+def test_projection_units_follow_the_decoder():
+    # q/k/v share the hidden states, gate/up the post-attention norm output; o and down stand alone
+    srcs = [p[3] for p in bench.PROJS]
+    assert srcs == ["hid", "hid", "hid", "attn", "hid2", "hid2", "act"]
+    assert [p[0] for p in bench.PROJS] == ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+
+
+def test_usable_cpus_is_positive():
+    assert bench.usable_cpus() >= 1
