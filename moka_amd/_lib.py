@@ -12,7 +12,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoka_hip.so")
+# MOKA_HIP_LIB: alternative build of the same ABI (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("MOKA_HIP_LIB") or os.path.join(_HERE, "libmoka_hip.so")
 
 MOKA_BF16 = 0
 MOKA_MOD_NONE = 255

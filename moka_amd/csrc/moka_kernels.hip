@@ -1584,13 +1584,13 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
             }
         }
     };
-    auto compute = [&](bf16x8 (&F)[2][2], int (&mr)[2], int gi_) {
+    auto compute = [&](bf16x8 (&F)[2][2], int (&mr)[2], int gi_, int ph_) {
         const int grp = grp0 + gi_;
         const bool live = wactive && grp < ngroups;
         const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            float* slot = myr + ((size_t)(gi_ % PH) * G + gi) * RSLOT;
+            float* slot = myr + ((size_t)ph_ * G + gi) * RSLOT;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1643,14 +1643,16 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
     bf16x8 FA[2][2], FB[2][2];
     int mrA[2], mrB[2];
     issue(FA, mrA, grp0);
-#pragma unroll
+    // a real loop over pairs of groups (one pair = one reduction phase): unrolled, the G = 3 body is 72 KB of code.  In the
+    // back-to-back kernel sequence of a training step the smaller body wins (down_fwd 5.26 -> 4.95 ms per pass, same-box A/B via
+    // MOKA_HIP_LIB) although an isolated, instruction-cache-warm sweep shows no difference; the gy kernel prefers unrolling.
+#pragma unroll 1
     for (int gi_ = 0; gi_ < NG; gi_ += 2) {
         issue(FB, mrB, grp0 + gi_ + 1);
-        compute(FA, mrA, gi_);
-        if (PH == 1) reduce_phase(gi_);
+        compute(FA, mrA, gi_, 0);
         issue(FA, mrA, grp0 + gi_ + 2);
-        compute(FB, mrB, gi_ + 1);
-        reduce_phase(PH == 1 ? gi_ + 1 : gi_ / 2);
+        compute(FB, mrB, gi_ + 1, 1);
+        reduce_phase(gi_ / 2);
     }
 }
 
