@@ -103,6 +103,12 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # MOKA_TUNE="key=value,key=value": launch-heuristic overrides (moka_tune) applied at load time -- lets bench.py and
+    # the tests run unchanged under a different setting (diagnostics only; results never depend on it)
+    for item in filter(None, os.environ.get("MOKA_TUNE", "").split(",")):
+        key, _, val = item.partition("=")
+        if lib.moka_tune(key.strip().encode(), int(val)) != 0:
+            raise MokaError(f"MOKA_TUNE: unknown key {key!r}")
     _lib = lib
     return lib
 
