@@ -267,7 +267,7 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None):
             on_layer_done(l)
 
 
-# HBM bytes per launch from the PMC counters of profiles/r01_v10_pmc_{fetch,write}_size.md (rocprofv3 --pmc FETCH_SIZE and
+# HBM bytes per launch from the PMC counters of profiles/r01_v11_pmc_{fetch,write}_size.md (rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is),
 # measured at T = 8192 tokens per launch; MiB per projection of the given d_out (a batched launch moves the sum of its members).
 PMC_TRAFFIC_MIB_T8192 = {("moka_up_fwd", 4096): 68.36 + 64.00, ("moka_up_fwd", 11008): 183.90 + 172.54}
