@@ -41,6 +41,11 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_TR_PTR(p) ((__attribute__((address_space(3))) bf16x4*)(p))
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// Guard between MFMAs that sit behind wave-uniform branches and an LDS/global store that reads the accumulator
+// directly: on the path that skips a trailing MFMA the compiler's hazard recogniser let the store read the result
+// of the previous MFMA too early (NaN rows on hardware, tests "ragged" group case).  32 wait states cover the
+// 8-pass MFMA; the accumulator is an operand so the instruction cannot be moved across.
+#define MFMA_SETTLE(acc) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc))
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -1447,9 +1452,11 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 accR = {0.f, 0.f, 0.f, 0.f};
                 if (live) {
+                    const bf16x8 z8r = {0, 0, 0, 0, 0, 0, 0, 0};
                     accR = MFMA16(F[st][0], bwt[0][nt], accR);
-                    if (c0 + 32 < a.C) accR = MFMA16(F[st][1], bwt[1][nt], accR);
+                    accR = MFMA16((c0 + 32 < a.C) ? F[st][1] : z8r, bwt[1][nt], accR);   // branch-free, see moka_xa_kernel
                 }
+                MFMA_SETTLE(accR);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = accR[reg];
             }
@@ -1612,9 +1619,13 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
                         if (!(pm & (1u << m))) continue;
                         const bool other = (pm != (1u << m)) && mr[st] != m;     // my row (token i) only counts in its own chain
                         acc = MFMA16(other ? z8 : xg[0], wfr[gi][m][0], acc);
-                        if (c0 + 32 < a.C) acc = MFMA16(other ? z8 : xg[1], wfr[gi][m][1], acc);
+                        // second K step: branch-free (operand zeroed when my wave only has 32 valid columns).  A wave-uniform branch
+                        // around this MFMA produced NaN rows on hardware -- the result of the first MFMA was read too early on
+                        // the skipping path (found by tests/test_gpu_parity.py cfg "ragged")
+                        acc = MFMA16((other || c0 + 32 >= a.C) ? z8 : xg[1], wfr[gi][m][1], acc);
                     }
                 }
+                MFMA_SETTLE(acc);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + i] = acc[reg];
             }

@@ -379,6 +379,8 @@ def _group_data(variant, B, S, d_in, d_outs, r, seed, layouts=None):
     dict(variant="vt", B=2, S=2048, d_in=4096, d_outs=(4096, 4096, 4096), r=16, p=0.05),
     dict(variant="avt", B=3, S=80, d_in=256, d_outs=(256, 128, 384), r=8, p=0.1, tiny=True),
     dict(variant="avt", B=1, S=1024, d_in=1024, d_outs=(1024, 512), r=64, p=0.1),            # r > 16: per-projection fallback
+    dict(variant="avt", B=3, S=700, d_in=1376, d_outs=(352, 96, 1376), r=16, p=0.1),         # ragged: T % 32 != 0, widths % 64 != 0, % 512 != 0
+    dict(variant="vt", B=2, S=333, d_in=11008, d_outs=(4096, 160), r=8, p=0.05),             # 11008-wide input, r < 16, odd T
 ])
 def test_group_matches_single_projection_nodes(cfg):
     """The grouped autograd node against G single-projection nodes on the same inputs and seeds:
@@ -536,3 +538,38 @@ def test_decoder_shim_matches_per_projection_calls(train):
         if g1[n].float().norm().item() > 0:
             assert rel(g2[n], g1[n]) < 4e-3, n                    # bf16 casts of fp32 sums in a different order
     assert rel(dx2, dx1) < 1e-2
+
+
+@pytest.mark.parametrize("C", [96, 160, 1056, 1376])
+def test_widths_with_a_half_filled_wave(C):
+    """Widths with C % 64 == 32 leave one wave of the xa / gy kernels with a single valid 32-column K step.  A wave-uniform
+    branch around the second MFMA once let the LDS store read the first MFMA's result too early on that path (NaN rows,
+    intermittent): repeat the launches and compare with a plain fp32 GEMM every time."""
+    from moka_amd import functional as F
+    from moka_amd.routing import MokaRouting
+    dev = _dev()
+    bf = torch.bfloat16
+    B, S, r = 2, 200, 16
+    T = B * S
+    rt = MokaRouting.plain(B, S, dev, M=1)
+    g = torch.Generator().manual_seed(C)
+    x2 = torch.randn(T, C, generator=g).to(dev, bf)
+    A = [(torch.randn(r, C, generator=g) * 0.1).to(dev, bf)]
+    Bw = (torch.randn(C, r, generator=g) * 0.1).to(dev, bf)
+    gy = torch.randn(T, C, generator=g).to(dev, bf)
+    h_ref = x2.float() @ A[0].float().t()
+    g_ref = gy.float() @ Bw.float()
+    for _ in range(6):
+        junk = torch.full((8, T, 16), float("nan"), device=dev)      # poison the blocks the outputs will be carved from
+        del junk
+        part = F.down_fwd(x2, A, rt, r, 1.0)
+        h = part.sum(0)
+        assert not torch.isnan(h).any()
+        assert rel(h, h_ref) < 1e-5
+        st = F.cross_fwd(part, rt, r, [1.0], 0.0, 0.25, Bw=Bw, A=A)
+        dB = torch.zeros(C, r, dtype=torch.float32, device=dev)
+        g_part = F.up_bwd(gy, st.hp_kmj, st.BwT, rt, r, [1.0], dB)
+        gsum = g_part.sum(0)
+        assert not torch.isnan(gsum).any() and not torch.isnan(dB).any()
+        assert rel(gsum, g_ref) < 1e-5
+        assert rel(dB, gy.float().t() @ h_ref) < 5e-5
