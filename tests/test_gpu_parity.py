@@ -383,13 +383,39 @@ def _group_data(variant, B, S, d_in, d_outs, r, seed, layouts=None):
     dict(variant="vt", B=2, S=333, d_in=11008, d_outs=(4096, 160), r=8, p=0.05),             # 11008-wide input, r < 16, odd T
 ])
 def test_group_matches_single_projection_nodes(cfg):
+    _group_vs_singles(cfg)
+
+
+def _random_group_cfg(seed):
+    import random
+    rnd = random.Random(100 + seed)
+    variant = rnd.choice(["avt", "vt"])
+    B = rnd.randint(1, 3)
+    S = rnd.choice([48, 95, 130, 257, 333, 640])
+    G = rnd.choice([2, 3])
+    kinds = ["p", "t", "v", "t"] + (["a"] if variant == "avt" else ["v"]) + ["t", "q", "t"]
+    lay = []
+    for b in range(B):
+        cuts = sorted(rnd.sample(range(1, S), len(kinds) - 1))
+        lay.append(list(zip(kinds, [b_ - a_ for a_, b_ in zip([0] + cuts, cuts + [S])])))
+    return dict(variant=variant, B=B, S=S, d_in=32 * rnd.choice([2, 3, 5, 16, 33, 43]),
+                d_outs=tuple(32 * rnd.choice([1, 3, 4, 16, 17, 35]) for _ in range(G)),
+                r=rnd.choice([8, 16, 16]), p=rnd.choice([0.0, 0.1]), layouts=lay)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_groups_match_single_projection_nodes(seed):
+    _group_vs_singles(_random_group_cfg(seed))
+
+
+def _group_vs_singles(cfg):
     """The grouped autograd node against G single-projection nodes on the same inputs and seeds:
     y bit-identical (same kernels, same accumulation order); dA/dB equal up to the order of the fp32
     atomics; dx equal up to bf16 rounding (the group rounds once, the singles after every projection)."""
     from moka_amd.functional import AdapterSpec, moka_linear, moka_linear_group
     dev = _dev()
     bf = torch.bfloat16
-    lay = None
+    lay = cfg.get("layouts")
     if cfg.get("tiny"):
         lay = [[("p", 3), ("t", 9), ("v", 21), ("t", 2), ("a", 14), ("q", 9), ("t", 22)],
                [("t", 5), ("v", 30), ("a", 10), ("q", 12), ("t", 23)],
@@ -573,3 +599,35 @@ def test_widths_with_a_half_filled_wave(C):
         assert not torch.isnan(gsum).any() and not torch.isnan(dB).any()
         assert rel(gsum, g_ref) < 1e-5
         assert rel(dB, gy.float().t() @ h_ref) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------
+# randomised shapes / layouts: every C entry point against the fp64 oracle (same checks as the fixed cases)
+# ------------------------------------------------------------------------------------------
+def _random_case(seed):
+    import random
+    rnd = random.Random(seed)
+    variant = rnd.choice(["avt", "vt"])
+    B = rnd.randint(1, 3)
+    S = rnd.choice([37, 64, 95, 130, 257, 333, 512, 700])
+    d_in = 32 * rnd.choice([1, 2, 3, 5, 7, 16, 17, 33, 43])
+    d_out = 32 * rnd.choice([1, 2, 3, 4, 9, 16, 31, 35])
+    r = rnd.choice([4, 8, 16, 16, 16, 32])
+    layouts = []
+    for b in range(B):
+        # random spans: padding, text, image, (audio), question, text; lengths sum to S
+        kinds = ["p", "t", "v", "t"] + (["a"] if variant == "avt" else ["v"]) + ["t", "q", "t"]
+        if rnd.random() < 0.3:
+            kinds = ["t", "v", "q", "t", "v" if variant == "vt" else "a", "t"]
+        cuts = sorted(rnd.sample(range(1, S), len(kinds) - 1))
+        lens = [b_ - a_ for a_, b_ in zip([0] + cuts, cuts + [S])]
+        layouts.append(list(zip(kinds, lens)))
+    name = f"fuzz_{seed}"
+    C._CASES[name] = dict(variant=variant, B=B, S=S, d_in=d_in, d_out=d_out, r=r, alpha=16.0,
+                          w=rnd.choice([1.0, 0.05, 0.0]), layouts=layouts, seed=1000 + seed, big=True)
+    return C.make_case_data(name)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_shapes_and_layouts(seed):
+    _stage_check(_random_case(seed))
