@@ -1377,7 +1377,7 @@ template <int RP, bool WITH_DB, int NG>
 __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
-    constexpr int NW = 8, PH = 2, CT = 4;              // NG = 32-token groups per block
+    constexpr int NW = 8, PH = (RP == 64) ? 1 : 2, CT = 4;   // NG = 32-token groups per block; PH: LDS budget (RP = 64: 64 KB of slots per phase)
     constexpr int PITCH = 64 * 2 + 32, REGION = 32 * PITCH;
     constexpr int RSLOT = 32 * RP;                       // floats per (wave, group) partial
     const GyArgs& a = ab.z[blockIdx.z];
@@ -1397,8 +1397,8 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     }
     const int c0 = cb0 + 64 * wave;
     const bool wactive = c0 < a.C;                       // wave uniform (C % 32 == 0: a wave may own 32 valid columns)
-    unsigned char* my = smem + wave * REGION;
-    float* rbuf = (float*)(smem + NW * REGION);          // [NW][PH][32][RP]
+    unsigned char* my = smem + wave * REGION;            // (WITH_DB only: the g-only form carries no tile regions, more blocks per CU)
+    float* rbuf = (float*)(smem + (WITH_DB ? NW * REGION : 0));   // [NW][PH][32][RP]
     float* myr = rbuf + (size_t)wave * PH * RSLOT;
 
     // weight fragments of my 64 columns (two K steps), resident: lane (n = rank i, k chunk g)
@@ -1505,25 +1505,32 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
         issue(FB, bhB, blB, grp0 + gi + 1);
         compute(FA, bhA, blA, gi);
         issue(FA, bhA, blA, grp0 + gi + 2);
+        if (PH == 1) reduce_phase(gi);
         compute(FB, bhB, blB, gi + 1);
-        if ((gi + 2) % PH == 0) reduce_phase((gi + 1) / PH);
+        if (PH == 1) reduce_phase(gi + 1);
+        else reduce_phase(gi / 2);
     }
 
     if (WITH_DB) {
-        // block reduction of dB (layout [column][rank]), own tile regions as buffers, LDS-only barrier
-        float* mine = (float*)my;
+        // dB leaves as [column][rank] rows: wave w's accumulators hold columns cb0 + 64w .. of it, the destination rows of the waves
+        // are disjoint, so there is no cross-wave sum -- only a wave-private transposition through LDS (own tile region for RP = 16,
+        // own slot area -- free after the last reduce_phase barrier -- for the wider ranks, CTB column tiles at a time)
+        constexpr int CTB = (RP == 64) ? 2 : CT;
+        float* mine = (RP == 16) ? (float*)my : myr;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int cb = 0; cb < CT; cb += CTB) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int ct = 0; ct < CTB; ++ct)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) mine[(ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = accW[ct][nt][reg];
-        // wave w's tile holds columns cb0 + 64w ..: the destination rows are disjoint, no cross-wave sum needed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int e = lane; e < 64 * RP; e += 64) {
-            const int cl = e / RP, k = e % RP;
-            const int c = c0 + cl;
-            if (c < a.C && k < a.r) atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) mine[(ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = accW[cb + ct][nt][reg];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int e = lane; e < CTB * 16 * RP; e += 64) {
+                const int cl = e / RP, k = e % RP;
+                const int c = c0 + cb * 16 + cl;
+                if (c < a.C && k < a.r) atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
+            }
         }
     }
 }
@@ -1547,10 +1554,10 @@ struct XaArgs {
 // stream is x alone: no weight traffic, and a group that straddles a span boundary costs one extra MFMA chain
 // (rows of the other modality zeroed in the x operand) instead of extra loads.  The [32 x 16] partial of a group
 // goes to a wave-private LDS slot; every PH groups the eight waves' slots are summed into one split-K slice.
-template <int G, int NG>
+template <int RP, int G, int NG>
 __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RP = 16, NW = 8, PH = 2;
+    constexpr int NT = RP / 16, NW = 8, PH = 2;
     constexpr int RSLOT = 32 * RP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -1562,19 +1569,21 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
     float* rbuf = (float*)smem;                              // [NW][PH][G][32][RP]
     float* myr = rbuf + (size_t)wave * PH * G * RSLOT;
 
-    bf16x8 wfr[G][MOKA_MAX_MOD][2];
+    bf16x8 wfr[G][MOKA_MAX_MOD][2][NT];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
         for (int m = 0; m < MOKA_MAX_MOD; ++m)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = c0 + 32 * kk + 8 * g;
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                // rank rows >= r do not exist: clamp the row, the result column is zeroed when the slice is written
-                if (m < a.M && c < a.C) v = *(const bf16x8*)(a.A[gi][m] + ((size_t)min(i, a.r - 1) * a.C + c) * 2);
-                wfr[gi][m][kk] = v;
-            }
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = c0 + 32 * kk + 8 * g;
+                    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    // rank rows >= r do not exist: clamp the row, the result column is zeroed when the slice is written
+                    if (m < a.M && c < a.C) v = *(const bf16x8*)(a.A[gi][m] + ((size_t)min(nt * 16 + i, a.r - 1) * a.C + c) * 2);
+                    wfr[gi][m][kk][nt] = v;
+                }
 
     const int grp_last = ngroups - 1;
     auto issue = [&](bf16x8 (&F)[2][2], int (&mr)[2], int grp_) {
@@ -1600,7 +1609,9 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
             float* slot = myr + ((size_t)ph_ * G + gi) * RSLOT;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (live) {
                     unsigned pm = 0;
 #pragma unroll
@@ -1618,16 +1629,24 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
                     for (int m = 0; m < MOKA_MAX_MOD; ++m) {
                         if (!(pm & (1u << m))) continue;
                         const bool other = (pm != (1u << m)) && mr[st] != m;     // my row (token i) only counts in its own chain
-                        acc = MFMA16(other ? z8 : xg[0], wfr[gi][m][0], acc);
+                        const bf16x8 x0 = other ? z8 : xg[0];
                         // second K step: branch-free (operand zeroed when my wave only has 32 valid columns).  A wave-uniform branch
                         // around this MFMA produced NaN rows on hardware -- the result of the first MFMA was read too early on
                         // the skipping path (found by tests/test_gpu_parity.py cfg "ragged")
-                        acc = MFMA16((other || c0 + 32 >= a.C) ? z8 : xg[1], wfr[gi][m][1], acc);
+                        const bf16x8 x1 = (other || c0 + 32 >= a.C) ? z8 : xg[1];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[nt] = MFMA16(x0, wfr[gi][m][0][nt], acc[nt]);
+                            acc[nt] = MFMA16(x1, wfr[gi][m][1][nt], acc[nt]);
+                        }
                     }
                 }
-                MFMA_SETTLE(acc);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + i] = acc[reg];
+                for (int nt = 0; nt < NT; ++nt) {
+                    MFMA_SETTLE(acc[nt]);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = acc[nt][reg];
+                }
             }
         }
     };
@@ -1761,7 +1780,12 @@ static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs*
     return MOKA_OK;
 }
 
-static int cross_rows_per_block() { return (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) ? g_tune_cross_rows : 8; }
+// rows per block (measured at T = 8192, Lk = 64): 8 for r <= 16; the wider ranks re-sum the sample's key rows from the split-K
+// slices in every block, so longer blocks pay (RP = 64 forward 33 -> 26 us, RP = 32 backward 29 -> 23 us)
+static int cross_rows_per_block(int RP, bool bwd) {
+    if (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) return g_tune_cross_rows;
+    return ((RP == 64 && !bwd) || (RP == 32 && bwd)) ? 16 : 8;
+}
 
 static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     if (dtype != MOKA_BF16) return fail(MOKA_EDTYPE, "%s: only bf16 storage is implemented (dtype=%d)", fn, dtype);
@@ -1846,7 +1870,7 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
         a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot;
         a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
         a.r = r; a.M = rt->M;
-        a.RB = cross_rows_per_block();
+        a.RB = cross_rows_per_block(RP, bwd);
     }
     if ((size_t)(96 + 2 * ab.z[0].Lkp) * (RP + 1) * 4 > 150 * 1024) return fail(MOKA_EINVAL, "%s: key block does not fit LDS", fn);
     if (RP == 16) {
@@ -1899,7 +1923,8 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     const int nc = (Cmax + CCB - 1) / CCB;
     const int ngroups = ab.z[0].Tp / 32;
     // 4-wave blocks (wide inputs): three per CU, so that the 172 column blocks of an 11008-wide input spread evenly (55 -> 50 us)
-    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : ((NW == 4 && G == 1) ? 3 : 1);
+    // (RP = 64 runs 4-wave blocks for its register budget, not for width: one per CU, 61 -> 43 us)
+    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : ((NW == 4 && G == 1 && RP < 64) ? 3 : 1);
     const int nzg = (G == 1) ? nz : 1;                  // grid z
     int nb = (bpc * num_cu() + nc * nzg - 1) / (nc * nzg);
     if (nb > (ngroups + NW - 1) / NW) nb = (ngroups + NW - 1) / NW;
@@ -1929,16 +1954,17 @@ static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
     return check_launch("moka_wgrad_kernel");
 }
 
-template <bool WITH_DB, int NG>
+template <int RP, bool WITH_DB, int NG>
 static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
+    constexpr int PH = (RP == 64) ? 1 : 2;
     const int ntb = ((gb.z[0].Tp >> 5) + NG - 1) / NG;
-    const size_t lds = (size_t)8 * (32 * 160) + (size_t)8 * 2 * 32 * 16 * 4;
-    ensure_lds((const void*)moka_gy_kernel<16, WITH_DB, NG>, lds);
-    hipLaunchKernelGGL((moka_gy_kernel<16, WITH_DB, NG>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+    const size_t lds = (WITH_DB ? (size_t)8 * (32 * 160) : 0) + (size_t)8 * PH * 32 * RP * 4;
+    ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG>, lds);
+    hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
 }
 
-template <bool WITH_DB>
-static int launch_gy(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
+template <int RP, bool WITH_DB>
+static int launch_gy_rp(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     const int ncb = (Cmax + 511) / 512;
     const int ngroups = gb.z[0].Tp >> 5;
     // groups per block: without dB short runs (more blocks); with dB the longest run that still gives every CU a block
@@ -1949,19 +1975,38 @@ static int launch_gy(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
         ng = blocks(16) >= 2L * num_cu() ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
     }
     if (g_tune_gy_ng == 4 || g_tune_gy_ng == 8 || g_tune_gy_ng == 16) ng = g_tune_gy_ng;
-    if (ng == 16) launch_gy_t<WITH_DB, 16>(gb, nz, ncb, st);
-    else if (ng == 8) launch_gy_t<WITH_DB, 8>(gb, nz, ncb, st);
-    else launch_gy_t<WITH_DB, 4>(gb, nz, ncb, st);
+    if (ng == 16) launch_gy_t<RP, WITH_DB, 16>(gb, nz, ncb, st);
+    else if (ng == 8) launch_gy_t<RP, WITH_DB, 8>(gb, nz, ncb, st);
+    else launch_gy_t<RP, WITH_DB, 4>(gb, nz, ncb, st);
     return check_launch("moka_gy_kernel");
 }
 
-template <int G, int NG>
+template <bool WITH_DB>
+static int launch_gy(const GyBatch& gb, int nz, int Cmax, int RP, hipStream_t st) {
+    if (RP == 16) return launch_gy_rp<16, WITH_DB>(gb, nz, Cmax, st);
+    if (WITH_DB) return fail(MOKA_EINVAL, "moka_up_bwd: the one-pass g + dB kernel is built for r <= 16 only");
+    if (RP == 32) return launch_gy_rp<32, false>(gb, nz, Cmax, st);
+    return launch_gy_rp<64, false>(gb, nz, Cmax, st);
+}
+
+template <int RP, int G, int NG>
 static void launch_xa_t(const XaArgs& a, hipStream_t st) {
     constexpr int PH = 2;
     const int ncb = (a.C + 511) / 512, ntb = (((a.T + 31) >> 5) + NG - 1) / NG;
-    const size_t lds = (size_t)8 * PH * G * 32 * 16 * 4;
-    ensure_lds((const void*)moka_xa_kernel<G, NG>, lds);
-    hipLaunchKernelGGL((moka_xa_kernel<G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
+    const size_t lds = (size_t)8 * PH * G * 32 * RP * 4;
+    ensure_lds((const void*)moka_xa_kernel<RP, G, NG>, lds);
+    hipLaunchKernelGGL((moka_xa_kernel<RP, G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
+}
+
+// r > 16: one projection per launch (G x 3 x 2 x RP/16 resident weight fragments do not fit for G > 1)
+template <int RP>
+static int launch_xa_wide(const XaArgs& a, hipStream_t st) {
+    // 3 x 2 x RP/16 resident weight fragments per wave: RP = 64 needs long token runs to amortise them (41 -> 37 us at 4096)
+    const int ng = (g_tune_xa_ng == 2 || g_tune_xa_ng == 4 || g_tune_xa_ng == 8) ? g_tune_xa_ng : (RP == 64 ? 8 : 4);
+    if (ng == 2) launch_xa_t<RP, 1, 2>(a, st);
+    else if (ng == 8) launch_xa_t<RP, 1, 8>(a, st);
+    else launch_xa_t<RP, 1, 4>(a, st);
+    return check_launch("moka_xa_kernel");
 }
 
 template <int G>
@@ -1969,17 +2014,17 @@ static int launch_xa(const XaArgs& a, hipStream_t st) {
     // groups per block (measured at T = 8192): three projections amortise their 18 resident weight fragments over longer runs,
     // a wide single projection prefers more, shorter blocks
     const int ng = (g_tune_xa_ng == 2 || g_tune_xa_ng == 4 || g_tune_xa_ng == 8) ? g_tune_xa_ng : (G == 3 ? 8 : ((G == 1 && a.C > 8192) ? 2 : 4));
-    if (ng == 2) launch_xa_t<G, 2>(a, st);
-    else if (ng == 8) launch_xa_t<G, 8>(a, st);
-    else launch_xa_t<G, 4>(a, st);
+    if (ng == 2) launch_xa_t<16, G, 2>(a, st);
+    else if (ng == 8) launch_xa_t<16, G, 8>(a, st);
+    else launch_xa_t<16, G, 4>(a, st);
     return check_launch("moka_xa_kernel");
 }
 
 // number of part slices moka_down_fwd writes for input width C
-static int fwd_ks(int T, int C, int r) { return (rank_pad(r) == 16 && !g_tune_no_xa) ? (C + 511) / 512 : reduce_ks(T, C); }
+static int fwd_ks(int T, int C, int r) { return !g_tune_no_xa ? (C + 511) / 512 : reduce_ks(T, C); }
 
 // number of g_part slices moka_up_bwd writes for output width C
-static int bwd_ks(int T, int C, int r) { return rank_pad(r) == 16 ? (C + 511) / 512 : reduce_ks(T, C); }
+static int bwd_ks(int T, int C, int r) { return !g_tune_no_fused_gy || rank_pad(r) == 16 ? (C + 511) / 512 : reduce_ks(T, C); }
 
 extern "C" {
 
@@ -2069,6 +2114,19 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             for (int m = 0; m < M; ++m) xa.A[g][m] = (const unsigned char*)A[g * M + m];
         }
         return G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
+    }
+    if (!g_tune_no_xa) {
+        // r > 16: the same kernel with RP / 16 rank tiles, one launch per projection
+        for (int g = 0; g < G; ++g) {
+            XaArgs xa;
+            memset(&xa, 0, sizeof(xa));
+            xa.x = (const unsigned char*)x; xa.tok_mod = tok_mod; xa.T = T; xa.C = d_in; xa.r = r; xa.M = M;
+            for (int m = 0; m < M; ++m) { xa.s_mod[m] = a.s_mod[m]; xa.A[0][m] = (const unsigned char*)A[g * M + m]; }
+            xa.part[0] = part[g]; xa.drop[0] = a.drop[g];
+            rc = RP == 32 ? launch_xa_wide<32>(xa, (hipStream_t)stream) : launch_xa_wide<64>(xa, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+        return MOKA_OK;
     }
     for (int g = 0; g < G; ++g) {                      // r > 16 (or the no_xa diagnostic): one launch per projection
         ReduceArgs b = a;
@@ -2215,10 +2273,12 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         Cmax = d_out[g] > Cmax ? d_out[g] : Cmax;
     }
     int rc = MOKA_OK;
-    if (g_part && g_part[0] && RP == 16 && !g_tune_no_fused_gy) {
-        // r <= 16: ONE pass over gy produces the g slices (one per 512-column block) and, if requested, dB
+    if (g_part && g_part[0] && !g_tune_no_fused_gy) {
+        // ONE pass over gy produces the g slices (one per 512-column block) and, if requested, dB
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
-        const bool with_db = dB_acc && dB_acc[0];
+        // the dB half rides along only for r <= 16: with 32 / 64 ranks its atomics (64 x RP per wave and block) and the single
+        // resident block per CU cost more than the second read of gy (measured: 47 vs 45 us at RP = 32, 97 vs 79 us at RP = 64)
+        const bool with_db = dB_acc && dB_acc[0] && RP == 16;
         if (with_db && !hp_kmj) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without hp_kmj");
         GyBatch gb;
         memset(&gb, 0, sizeof(gb));
@@ -2230,9 +2290,9 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
             for (int m = 0; m < M; ++m) a.s_mod[m] = s_out[m];
             a.T = T; a.Tp = (T + 31) / 32 * 32; a.C = d_out[g]; a.r = r; a.M = M;
         }
-        return with_db ? launch_gy<true>(gb, G, Cmax, (hipStream_t)stream) : launch_gy<false>(gb, G, Cmax, (hipStream_t)stream);
-    }
-    if (g_part && g_part[0]) {
+        rc = with_db ? launch_gy<true>(gb, G, Cmax, RP, (hipStream_t)stream) : launch_gy<false>(gb, G, Cmax, RP, (hipStream_t)stream);
+        if (rc || with_db || !(dB_acc && dB_acc[0])) return rc;
+    } else if (g_part && g_part[0]) {
         // g = s_out[mod] * gy Bw: contraction over d_out with the transposed weight; one chain per tile
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
         ReduceArgs ra;

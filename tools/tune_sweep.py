@@ -21,7 +21,7 @@ DROP = 0.0
 def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    B, S, r, M = int(os.environ.get("B", 4)), 2048, 16, 3
+    B, S, r, M = int(os.environ.get("B", 4)), 2048, int(os.environ.get("R", 16)), 3
     global DROP
     DROP = float(os.environ.get("DROP", 0.0))
     T = B * S
@@ -38,7 +38,7 @@ def main():
     masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
     rt = MokaRouting.from_avt_masks(masks)
     bf, f32 = torch.bfloat16, torch.float32
-    RP, Tp = 16, _lib.tok_pad(T)
+    RP, Tp = _lib.rank_pad(r), _lib.tok_pad(T)
     NBUF = int(os.environ.get("NBUF", 6))      # rotate over distinct buffers so nothing stays in the 256 MiB Infinity Cache
 
     def shapes(d_in, d_out):
