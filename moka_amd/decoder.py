@@ -13,13 +13,22 @@ input and the same masks::
 the modules one by one (``tests/test_gpu_parity.py::test_group_*``), but x is read once by the G
 down-projections and once by the G dA kernels, and the G input gradients are added to dx in one pass
 (``include/moka_hip.h``: ``moka_*_group``).  ``MokaLlamaMLP`` / ``qkv_forward`` are the two call sites.
+
+``MokaLlamaAttention`` / ``MokaLlamaDecoderLayer`` / ``MokaLlamaStack`` are the rest of the forked block: they thread
+the masks to all seven projections and switch them off for cached decode steps (VT
+``modified_models/modeling_llama.py:294-358``, AVT ``models/modeling_llama.py:647-654,721-743``).  Everything that
+is not an adapted projection (RMSNorm, rotary embedding, causal attention, SwiGLU) is stock PyTorch-ROCm -- the
+frozen backbone is not part of the hand-written path.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
+from torch.nn import functional as TF
 
 from .functional import moka_linear_group
 
@@ -65,6 +74,131 @@ class MokaLlamaMLP(nn.Module):
         self.gate_proj, self.up_proj, self.down_proj = mlp.gate_proj, mlp.up_proj, mlp.down_proj
         self.act_fn = getattr(mlp, "act_fn", nn.SiLU())
 
-    def forward(self, x: torch.Tensor, *mask_args, **kwargs) -> torch.Tensor:
-        gate, up = forward_group([self.gate_proj, self.up_proj], x, *mask_args, **kwargs)
+    def forward(self, x: torch.Tensor, *mask_args, grouped: bool = True, **kwargs) -> torch.Tensor:
+        if grouped:
+            gate, up = forward_group([self.gate_proj, self.up_proj], x, *mask_args, **kwargs)
+        else:                       # the reference's call pattern: one module call per projection
+            gate, up = self.gate_proj(x, *mask_args, **kwargs), self.up_proj(x, *mask_args, **kwargs)
         return self.down_proj(self.act_fn(gate) * up, *mask_args, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------
+# the rest of the forked decoder block
+# ------------------------------------------------------------------------------------------
+@dataclass
+class LlamaDims:
+    """Shape of one Llama block (defaults: Llama-2-7B)."""
+    hidden: int = 4096
+    ff: int = 11008
+    n_heads: int = 32
+    n_kv_heads: int = 32
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.n_heads
+
+
+def rotary_tables(S: int, head_dim: int, theta: float, device, dtype, offset: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos / sin [S, head_dim] of the rotate-half convention, positions offset .. offset + S - 1."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, device=device, dtype=torch.float32) / head_dim))
+    ang = torch.arange(offset, offset + S, device=device, dtype=torch.float32)[:, None] * inv[None, :]
+    ang = torch.cat([ang, ang], dim=-1)
+    return ang.cos().to(dtype), ang.sin().to(dtype)
+
+
+def _rotate(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    h = x.shape[-1] // 2
+    return x * cos + torch.cat([-x[..., h:], x[..., :h]], dim=-1) * sin
+
+
+def _live_masks(mask_args: tuple, past_len: int) -> tuple:
+    """The forked decoders hand the masks to the projections for training and for the prefill, and ``None`` for
+    every cached decode step (VT ``modeling_llama.py:311-329``; AVT gates the list the same way, ``:647-654``)."""
+    if past_len == 0:
+        return mask_args
+    return tuple(None for _ in mask_args)
+
+
+class MokaLlamaAttention(nn.Module):
+    """Self-attention of the forked block.  ``make_proj(d_in, d_out)`` builds one (adapted) projection; q/k/v run as
+    one group on the same normalised hidden states, o_proj on the attention output, all four with the masks."""
+
+    def __init__(self, dims: LlamaDims, make_proj: Callable[[int, int], nn.Module]):
+        super().__init__()
+        self.dims = dims
+        hd = dims.head_dim
+        self.q_proj = make_proj(dims.hidden, dims.n_heads * hd)
+        self.k_proj = make_proj(dims.hidden, dims.n_kv_heads * hd)
+        self.v_proj = make_proj(dims.hidden, dims.n_kv_heads * hd)
+        self.o_proj = make_proj(dims.n_heads * hd, dims.hidden)
+
+    def forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *mask_args,
+                kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, grouped: bool = True):
+        B, S, _ = x.shape
+        d = self.dims
+        if grouped:
+            q, k, v = qkv_forward(self, x, *mask_args)
+        else:
+            q, k, v = self.q_proj(x, *mask_args), self.k_proj(x, *mask_args), self.v_proj(x, *mask_args)
+        q = q.view(B, S, d.n_heads, d.head_dim).transpose(1, 2)
+        k = k.view(B, S, d.n_kv_heads, d.head_dim).transpose(1, 2)
+        v = v.view(B, S, d.n_kv_heads, d.head_dim).transpose(1, 2)
+        q, k = _rotate(q, cos, sin), _rotate(k, cos, sin)
+        if kv_cache is not None:
+            k, v = torch.cat([kv_cache[0], k], dim=2), torch.cat([kv_cache[1], v], dim=2)
+        new_cache = (k, v)
+        if d.n_kv_heads != d.n_heads:
+            rep = d.n_heads // d.n_kv_heads
+            k, v = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
+        o = TF.scaled_dot_product_attention(q, k, v, is_causal=(kv_cache is None and S > 1))
+        o = o.transpose(1, 2).reshape(B, S, d.n_heads * d.head_dim)
+        return self.o_proj(o, *mask_args), new_cache
+
+
+class MokaLlamaDecoderLayer(nn.Module):
+    """pre-norm attention + SwiGLU block with all seven projections adapted and mask-threaded."""
+
+    def __init__(self, dims: LlamaDims, make_proj: Callable[[int, int], nn.Module]):
+        super().__init__()
+        self.dims = dims
+        self.input_layernorm = nn.RMSNorm(dims.hidden, eps=dims.rms_eps)
+        self.post_attention_layernorm = nn.RMSNorm(dims.hidden, eps=dims.rms_eps)
+        self.self_attn = MokaLlamaAttention(dims, make_proj)
+
+        from types import SimpleNamespace
+        self.mlp = MokaLlamaMLP(SimpleNamespace(gate_proj=make_proj(dims.hidden, dims.ff), up_proj=make_proj(dims.hidden, dims.ff),
+                                                down_proj=make_proj(dims.ff, dims.hidden), act_fn=nn.SiLU()))
+
+    def forward(self, h: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *mask_args,
+                kv_cache=None, grouped: bool = True):
+        past_len = 0 if kv_cache is None else kv_cache[0].shape[2]
+        masks = _live_masks(mask_args, past_len)
+        a, new_cache = self.self_attn(self.input_layernorm(h), cos, sin, *masks, kv_cache=kv_cache, grouped=grouped)
+        h = h + a
+        m = self.mlp(self.post_attention_layernorm(h), *masks, grouped=grouped)
+        return h + m, new_cache
+
+
+class MokaLlamaStack(nn.Module):
+    """L decoder layers on given input embeddings (embedding table, encoders and LM head are out of scope): the harness
+    ``bench.py --e2e`` and the layer tests drive.  ``forward`` returns the final hidden states (and the caches)."""
+
+    def __init__(self, dims: LlamaDims, n_layers: int, make_proj: Callable[[int, int], nn.Module]):
+        super().__init__()
+        self.dims = dims
+        self.layers = nn.ModuleList(MokaLlamaDecoderLayer(dims, make_proj) for _ in range(n_layers))
+
+    def forward(self, h: torch.Tensor, *mask_args, kv_caches: Optional[list] = None, grouped: bool = True,
+                on_layer: Optional[Callable[[int], None]] = None):
+        S = h.shape[1]
+        past = 0 if kv_caches is None else kv_caches[0][0].shape[2]
+        cos, sin = rotary_tables(S, self.dims.head_dim, self.dims.rope_theta, h.device, h.dtype, offset=past)
+        caches = []
+        for i, layer in enumerate(self.layers):
+            h, c = layer(h, cos, sin, *mask_args, kv_cache=None if kv_caches is None else kv_caches[i], grouped=grouped)
+            caches.append(c)
+            if on_layer is not None:
+                on_layer(i)
+        return h, caches
