@@ -337,6 +337,81 @@ def cpu_baseline(args):
                       f"{n} repeats, scaled x{LLAMA7B['layers']} layers"}
 
 
+def end_to_end(args, dev):
+    """Context, not the metric: fwd+bwd of the WHOLE decoder stack (frozen bf16 base on hipBLASLt, stock SDPA / RMSNorm /
+    rotary, the seven adapted projections of every layer on the HIP path through moka_amd/decoder.py) against the same
+    stack with plain frozen projections, same tokens per GPU.  Embedding table, encoders and LM head are out of scope."""
+    from moka_amd.decoder import LlamaDims, MokaLlamaStack
+    from moka_amd.peft_hyper import Linear
+    B, S, r, L = args.batch, args.seq, args.rank, args.layers
+    dims = LlamaDims(hidden=LLAMA7B["d"], ff=LLAMA7B["ff"], n_heads=32, n_kv_heads=32)
+    bf = torch.bfloat16
+    tok, q = synthetic_layout(S)
+    masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
+    masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
+    h = torch.randn(B, S, dims.hidden, device=dev, dtype=bf)
+    gout = torch.randn(B, S, dims.hidden, device=dev, dtype=bf)
+
+    class Plain(torch.nn.Linear):
+        def forward(self, x, *m):
+            return super().forward(x)
+
+    def adapted(d_in, d_out):
+        m = Linear(d_in, d_out, r=(r, r, r), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=args.dropout,
+                   loramethod="train", bias=False)
+        torch.nn.init.normal_(m.weight, std=0.02)
+        torch.nn.init.normal_(m.lora_B0.weight, std=0.02)
+        return m
+
+    def plain(d_in, d_out):
+        m = Plain(d_in, d_out, bias=False)
+        torch.nn.init.normal_(m.weight, std=0.02)
+        m.weight.requires_grad = False
+        return m
+
+    def timed(make, train_adapter):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(bf)
+        try:
+            with torch.device(dev):
+                st = MokaLlamaStack(dims, L, make)
+        finally:
+            torch.set_default_dtype(old)
+        st.train()
+        for n, p_ in st.named_parameters():
+            p_.requires_grad = train_adapter and "lora_" in n
+        params = [p_ for p_ in st.parameters() if p_.requires_grad]
+        opt = torch.optim.AdamW(params, lr=1e-4, fused=True) if params else None
+        x = h.clone().requires_grad_(True)            # dx reaches the embeddings / projector in the real model
+
+        def step():
+            out, _ = st(x, masks)
+            out.backward(gout)
+            if opt is not None:
+                opt.step()
+                opt.zero_grad(set_to_none=False)
+            x.grad = None
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        del st, opt, params
+        torch.cuda.empty_cache()
+        return ms
+
+    ms_base = timed(plain, False)
+    ms_moka = timed(adapted, True)
+    return {"what": "decoder stack fwd+bwd (+ fused AdamW on the adapter), %d layers, %d x %d tokens, bf16; NOT the metric" % (L, B, S),
+            "ms_per_step": round(ms_moka, 2), "tokens_per_s": round(B * S / (ms_moka * 1e-3), 1),
+            "frozen_base_only_ms_per_step": round(ms_base, 2), "adapter_share_of_step": round(1.0 - ms_base / ms_moka, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,6 +428,9 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--variant", choices=("avt", "vt"), default="avt",
                     help="avt: 3 modalities, the headline workload; vt: 2 modalities (BASELINE.json configs[1], 256 image tokens + text)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the whole decoder stack (frozen base + adapters) through moka_amd/decoder.py and report it as "
+                         "`end_to_end` (context only; the metric stays the adapter path)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -489,6 +567,10 @@ def main():
             "entry_point_ms_per_pass": {n: round(tot_x[n], 3) for n in ENTRY},
             "kernels": table,
         }
+        if world == 1 and args.e2e:
+            del wl, opt, records
+            torch.cuda.empty_cache()
+            out["end_to_end"] = end_to_end(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
