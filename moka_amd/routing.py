@@ -130,6 +130,80 @@ class MokaRouting:
             kpos = torch.full((B, 1), -1, dtype=torch.int32, device=dev)
         return cls(cls._pad_tok_mod(tok), kpos, klen.to(torch.int32).contiguous(), B, S, Lk, 2)
 
+    # ---- routing straight from what the data pipeline knows, masks never materialised per call
+    @classmethod
+    def from_vt_batch(cls, input_ids: torch.Tensor, labels: torch.Tensor, image_pad_id: int,
+                      attention_mask: Optional[torch.Tensor] = None) -> "MokaRouting":
+        """The visual-text recipe (``VisualText/train/train.py:206-231`` per sample, ``:258-318`` right-padding in
+        the collator) evaluated for the whole padded batch on the device: image = placeholder id, text = every other
+        real token, question = non-image tokens that are not supervised (label -100) and lie after the last image
+        token.  ``attention_mask`` marks the real tokens (the collator pads every mask with False); without it every
+        position counts as real, as for a batch of one."""
+        B, S = input_ids.shape
+        real = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.reshape(B, S).bool()
+        image = (input_ids == image_pad_id) & real
+        text = (input_ids != image_pad_id) & real
+        pos = torch.arange(S, device=input_ids.device).expand(B, S)
+        last_image = torch.where(image, pos, -1).max(dim=1, keepdim=True).values          # -1: no image token
+        after = (pos > last_image) & (last_image >= 0)
+        question = text & (labels.reshape(B, S) == -100) & after
+        return cls.from_vt_masks(text, image, question)
+
+    @classmethod
+    def from_segments(cls, segments: Sequence[Sequence[tuple]], S: int, device, variant: str = "avt",
+                      pad: str = "left") -> "MokaRouting":
+        """Routing from per-sample segment lists ``[(kind, n_tokens), ...]`` -- what the audio-visual-text embedding
+        assembly knows on the host while it concatenates text and feature segments (``AudioVisualText/models/
+        unified_arch.py:150-246``: the text run closed by ``<question_end>`` is the question, ``<video>`` / ``<image>`` /
+        ``<audio>`` placeholders become feature tokens; ``:306-324`` left-pads the batch).  kinds: ``t`` text, ``q``
+        question (text), ``v`` video / image, ``a`` audio, ``p`` explicit padding.  Built with host integers only: no
+        mask tensors, no device read-back, one upload.  ``variant='vt'`` maps ``v`` to the image adapter (M = 2) and skips
+        samples without image or question tokens, as ``from_vt_masks`` does."""
+        import numpy as np
+        if variant not in ("avt", "vt"):
+            raise ValueError(variant)
+        M = 3 if variant == "avt" else 2
+        B = len(segments)
+        code = {"t": 0, "q": 0, "v": 1, "a": 2, "p": MOD_NONE}
+        tok = np.full((B, S), MOD_NONE, dtype=np.uint8)
+        qpos: List[List[int]] = []
+        for b, segs in enumerate(segments):
+            n = sum(int(l) for _, l in segs)
+            if n > S:
+                raise ValueError(f"sample {b}: {n} tokens do not fit S = {S}")
+            at = S - n if pad == "left" else 0
+            qs: List[int] = []
+            has_image = False
+            for kind, l in segs:
+                l = int(l)
+                if kind not in code or (kind == "a" and variant == "vt"):
+                    raise ValueError(f"segment kind {kind!r} is not part of the {variant} layout")
+                tok[b, at:at + l] = code[kind]
+                if kind == "q":
+                    qs.extend(range(at, at + l))
+                has_image |= kind == "v" and l > 0
+                at += l
+            if variant == "avt" and not qs:
+                raise IndexError("index 0 is out of bounds for dimension 0 with size 0")     # lora.py:489-490
+            if variant == "vt" and not has_image:
+                qs = []                                                                        # layer.py:630-637
+            qpos.append(qs)
+        if variant == "avt":      # contiguous span first..last question token; only question tokens are live key rows
+            spans = [list(range(q[0], q[-1] + 1)) for q in qpos]
+            live = [set(q) for q in qpos]
+        else:
+            spans, live = qpos, [set(q) for q in qpos]
+        Lk = max((len(sp) for sp in spans), default=0)
+        kpos = np.full((B, max(Lk, 1)), -1, dtype=np.int32)
+        klen = np.zeros((B,), dtype=np.int32)
+        for b, sp in enumerate(spans):
+            klen[b] = len(sp)
+            for j, p_ in enumerate(sp):
+                kpos[b, j] = p_ if p_ in live[b] else -1
+        dev = torch.device(device)
+        return cls(cls._pad_tok_mod(torch.from_numpy(tok).to(dev)), torch.from_numpy(kpos).to(dev),
+                   torch.from_numpy(klen).to(dev), B, S, Lk, M)
+
     @classmethod
     def plain(cls, B: int, S: int, device, M: int = 1) -> "MokaRouting":
         """Masks None (decode step): every token goes through the text adapter, no interaction
