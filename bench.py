@@ -36,6 +36,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 LLAMA7B = dict(d=4096, ff=11008, layers=32)
+# --model: the headline is Llama-2-7B; 13b = BASELINE.json configs[3] widths (run it with --rank 64 --seq 4096 --batch 2)
+MODELS = {"7b": LLAMA7B, "13b": dict(d=5120, ff=13824, layers=40)}
 # the 7 adapted projections of one decoder layer in the reference's call order
 # (AudioVisualText/models/modeling_llama.py:326-328,384,222-224): name, d_in, d_out, input id
 PROJS = [("q_proj", "d", "d", "hid"), ("k_proj", "d", "d", "hid"), ("v_proj", "d", "d", "hid"),
@@ -126,7 +128,7 @@ def build_workload(args, dev, lib, bucket_factory):
     from moka_amd.routing import MokaRouting
     vt = args.variant == "vt"
     B, S, r, M = args.batch, args.seq, args.rank, (2 if vt else 3)
-    d, ff, L = LLAMA7B["d"], LLAMA7B["ff"], args.layers
+    d, ff, L = MODELS[args.model]["d"], MODELS[args.model]["ff"], args.layers
     T = B * S
     tok, q = synthetic_layout(S)
     if vt:
@@ -303,7 +305,7 @@ def cpu_baseline(args):
     from oracle import cases as C
     from oracle import moka_oracle as O
     S, r = args.seq, args.rank
-    d, ff = LLAMA7B["d"], LLAMA7B["ff"]
+    d, ff = MODELS[args.model]["d"], MODELS[args.model]["ff"]
     cores = usable_cpus()
     torch.set_num_threads(cores)
     tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
@@ -332,9 +334,9 @@ def cpu_baseline(args):
         if time.perf_counter() - t0 > args.cpu_seconds or n >= 50:
             break
     per_layer = (time.perf_counter() - t0) / n
-    return {"value": S / (per_layer * LLAMA7B["layers"]), "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"value": S / (per_layer * args.layers), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"oracle port (torch fp32), adapter fwd+bwd of 1 decoder layer x 7 projections, 1 sequence of {S} tokens, "
-                      f"{n} repeats, scaled x{LLAMA7B['layers']} layers"}
+                      f"{n} repeats, scaled x{args.layers} layers"}
 
 
 def end_to_end(args, dev):
@@ -344,7 +346,7 @@ def end_to_end(args, dev):
     from moka_amd.decoder import LlamaDims, MokaLlamaStack
     from moka_amd.peft_hyper import Linear
     B, S, r, L = args.batch, args.seq, args.rank, args.layers
-    dims = LlamaDims(hidden=LLAMA7B["d"], ff=LLAMA7B["ff"], n_heads=32, n_kv_heads=32)
+    dims = LlamaDims(hidden=MODELS[args.model]["d"], ff=MODELS[args.model]["ff"], n_heads=MODELS[args.model]["d"] // 128, n_kv_heads=MODELS[args.model]["d"] // 128)
     bf = torch.bfloat16
     tok, q = synthetic_layout(S)
     masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
@@ -420,7 +422,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="sequences per GPU (reference AVT micro-batch: ft_musicavqa.sh:12-13)")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--layers", type=int, default=LLAMA7B["layers"])
+    ap.add_argument("--model", choices=tuple(MODELS), default="7b", help="widths / depth of the decoder (the metric is quoted on 7b)")
+    ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=4, help="distinct activation buffer sets cycled over the layers")
     ap.add_argument("--dropout", type=float, default=0.05, help="lora_dropout (both reference scripts train with 0.05)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -434,6 +437,8 @@ def main():
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
+    if args.layers is None:
+        args.layers = MODELS[args.model]["layers"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -501,7 +506,7 @@ def main():
 
     out = None
     if rank == 0:
-        fwd_b, bwd_b = algorithmic_bytes_per_token(LLAMA7B["d"], LLAMA7B["ff"], args.rank, args.layers)
+        fwd_b, bwd_b = algorithmic_bytes_per_token(MODELS[args.model]["d"], MODELS[args.model]["ff"], args.rank, args.layers)
         algo_gbs = (fwd_b + bwd_b) * T / (ms_per_step * 1e-3) / 1e9
         # per-launch durations from the HIP events recorded on the launch stream inside the timed region
         def collect(items):
@@ -546,15 +551,17 @@ def main():
             if tr == tr:
                 traffic = round(tr / cnt[dom])
         out = {
-            "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline",
+            "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline" if (args.model, args.rank, args.seq) == ("7b", 16, 2048)
+                      else "tokens/sec/GPU Llama-2-%s MokA r=%d seq%d bf16; adapter HBM %%roofline" % (args.model.upper(), args.rank, args.seq),
             "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Llama-2-7B dims, MokA r=%d %s, adapter fwd+bwd of 7x%d projections, "
+            "config": {"workload": "Llama-2-%s dims, MokA r=%d %s, adapter fwd+bwd of 7x%d projections, "
                                    "seq=%d (%s), lora_dropout %g, batch %d seq/GPU, %s, "
                                    "+ DP grad all-reduce (RCCL) + fused AdamW on adapter params"
-                                   % (args.rank, "M=2 (VT semantics)" if args.variant == "vt" else "M=3 (AVT semantics)", args.layers, args.seq,
-                                      "256 image + 64 question + text" if args.variant == "vt" else "256 image + 128 audio + 64 question + text",
+                                   % (args.model.upper(), args.rank, "M=2 (VT semantics)" if args.variant == "vt" else "M=3 (AVT semantics)", args.layers, args.seq,
+                                      ("%d image + %d question + text" % (args.seq // 8, args.seq // 32)) if args.variant == "vt"
+                                      else ("%d image + %d audio + %d question + text" % (args.seq // 8, args.seq // 16, args.seq // 32)),
                                       args.dropout, args.batch,
                                       "one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points"),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
