@@ -79,7 +79,9 @@ typedef struct moka_routing {
                                  row that still enters the softmax (also for keys whose token has no modality) */
     const int32_t* klen;      /* [B] number of key slots (0: sample has no interaction) */
     const int32_t* kslot;     /* [T] key slot j with ktok[b][j] == t, -1 if token t is not a (non-zero) key row */
-    int32_t B, S, Lk_max, M;
+    int32_t B, S, Lk_max, M;  /* Lk_max = max_b klen[b].  Limits of the cross kernels (a sample's key rows live in LDS):
+                                 Lk_max <= 512 for r <= 32, <= 247 for r <= 64; beyond that MOKA_EINVAL (the reference has
+                                 no limit; its question spans are tens of tokens) */
 } moka_routing;
 
 int         moka_version(void);

@@ -1863,7 +1863,8 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
     const int Lk = rt->Lk_max;
     if (Lk < 0 || Lk > 512) return fail(MOKA_EINVAL, "%s: Lk_max=%d not in 0..512", fn, Lk);
     const int kch = Lk <= 64 ? 1 : (Lk <= 128 ? 2 : (Lk <= 256 ? 4 : 8));
-    if (kch * RP > 128) return fail(MOKA_EINVAL, "%s: Lk_max=%d with rank pad %d exceeds the register budget", fn, Lk, RP);
+    // (kch * RP > 128: the per-lane key-gradient arrays of the backward no longer fit the register file and live in scratch -- the
+    //  rare long-question case is correct but slow; rank pad 64 ends at the LDS bound below, Lk_max <= 247)
     for (int z = 0; z < nz; ++z) {
         CrossArgs& a = ab.z[z];
         if (a.ks < 1) return fail(MOKA_EINVAL, "%s: ks=%d", fn, a.ks);
@@ -1872,15 +1873,17 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
         a.r = r; a.M = rt->M;
         a.RB = cross_rows_per_block(RP, bwd);
     }
-    if ((size_t)(96 + 2 * ab.z[0].Lkp) * (RP + 1) * 4 > 150 * 1024) return fail(MOKA_EINVAL, "%s: key block does not fit LDS", fn);
+    if ((size_t)(96 + 2 * ab.z[0].Lkp) * (RP + 1) * 4 + (size_t)ab.z[0].Lkp * 4 > 150 * 1024)
+        return fail(MOKA_EINVAL, "%s: Lk_max=%d key rows of rank pad %d do not fit LDS (limits: 512 keys for r <= 32, 247 for r <= 64)", fn, Lk, RP);
     if (RP == 16) {
         if (kch == 1) launch_cross_t<16, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<16, 2>(bwd, ab, nz, st);
         else if (kch == 4) launch_cross_t<16, 4>(bwd, ab, nz, st); else launch_cross_t<16, 8>(bwd, ab, nz, st);
     } else if (RP == 32) {
         if (kch == 1) launch_cross_t<32, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<32, 2>(bwd, ab, nz, st);
-        else launch_cross_t<32, 4>(bwd, ab, nz, st);
+        else if (kch == 4) launch_cross_t<32, 4>(bwd, ab, nz, st); else launch_cross_t<32, 8>(bwd, ab, nz, st);
     } else {
-        if (kch == 1) launch_cross_t<64, 1>(bwd, ab, nz, st); else launch_cross_t<64, 2>(bwd, ab, nz, st);
+        if (kch == 1) launch_cross_t<64, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<64, 2>(bwd, ab, nz, st);
+        else launch_cross_t<64, 4>(bwd, ab, nz, st);
     }
     return check_launch(fn);
 }

@@ -309,9 +309,12 @@ def test_dropout_replays_exactly_through_the_mask(name, p):
 @pytest.mark.parametrize("seed", [3, 7, 11, 12, 14, 15])
 def test_dropout_replay_on_random_shapes(seed):
     cd = _random_case(seed)
-    if cd.case.r > 16:
-        pytest.skip("covered by the fixed r = 64 cases")
     _dropout_replay(cd, [0.05, 0.1, 0.3][seed % 3], strict_rate=False)
+
+
+@pytest.mark.parametrize("seed", [101, 104])
+def test_dropout_replay_on_random_shapes_wide_ranks(seed):
+    _dropout_replay(_random_case(seed, ranks=(24, 32, 48, 64)), 0.1, strict_rate=False)
 
 
 def _dropout_replay(cd, p, strict_rate=True):
@@ -632,7 +635,7 @@ def test_widths_with_a_half_filled_wave(C):
 # ------------------------------------------------------------------------------------------
 # randomised shapes / layouts: every C entry point against the fp64 oracle (same checks as the fixed cases)
 # ------------------------------------------------------------------------------------------
-def _random_case(seed):
+def _random_case(seed, ranks=(4, 8, 16, 16, 16, 32)):
     import random
     rnd = random.Random(seed)
     variant = rnd.choice(["avt", "vt"])
@@ -640,7 +643,7 @@ def _random_case(seed):
     S = rnd.choice([37, 64, 95, 130, 257, 333, 512, 700])
     d_in = 32 * rnd.choice([1, 2, 3, 5, 7, 16, 17, 33, 43])
     d_out = 32 * rnd.choice([1, 2, 3, 4, 9, 16, 31, 35])
-    r = rnd.choice([4, 8, 16, 16, 16, 32])
+    r = rnd.choice(list(ranks))
     layouts = []
     for b in range(B):
         # random spans: padding, text, image, (audio), question, text; lengths sum to S
@@ -659,3 +662,39 @@ def _random_case(seed):
 @pytest.mark.parametrize("seed", list(range(16)))
 def test_random_shapes_and_layouts(seed):
     _stage_check(_random_case(seed))
+
+
+@pytest.mark.parametrize("seed", list(range(100, 108)))
+def test_random_shapes_wide_ranks(seed):
+    """Ranks 17..64 (rank pads 32 and 64, including ranks that do not fill their pad) on the rank-templated xa / gy kernels."""
+    cd = _random_case(seed, ranks=(17, 24, 32, 40, 48, 64))
+    _, rt, _ = _spec_and_routing(cd, _dev())
+    if cd.case.r > 32 and rt.Lk_max > 247:       # documented LDS bound of the rank-pad-64 cross kernels: loud, not wrong
+        from moka_amd._lib import MokaError
+        with pytest.raises(MokaError, match="do not fit LDS"):
+            _stage_check(cd)
+        return
+    _stage_check(cd)
+
+
+def _long_question_case(name, variant, r, n_q, d_in=160, d_out=96, seed=90):
+    lay = [("t", 5), ("v", 70), ("t", 3)] + ([("a", 40)] if variant == "avt" else [("v", 9)]) + [("q", n_q), ("t", 11)]
+    S = sum(n for _, n in lay)
+    C._CASES[name] = dict(variant=variant, B=2, S=S, d_in=d_in, d_out=d_out, r=r, alpha=16.0, w=1.0 if variant == "avt" else 0.05,
+                          layouts=[lay, [("t", 9)] + lay[1:-1] + [("t", 7)]], seed=seed, big=True)
+    return C.make_case_data(name)
+
+
+@pytest.mark.parametrize("variant,r,n_q", [("avt", 16, 500), ("vt", 16, 300), ("avt", 32, 450), ("avt", 64, 200), ("vt", 48, 240)])
+def test_long_question_spans(variant, r, n_q):
+    """Key blocks beyond 64 keys (up to 512 for r <= 32, 247 for r <= 64): the multi-chunk cross kernels, for the wide ranks with
+    their per-lane key-gradient arrays in scratch."""
+    _stage_check(_long_question_case(f"longq_{variant}_{r}_{n_q}", variant, r, n_q))
+
+
+def test_question_span_beyond_the_limits_fails_loudly():
+    from moka_amd._lib import MokaError
+    with pytest.raises(MokaError, match="do not fit LDS"):
+        _stage_check(_long_question_case("longq_over_64", "avt", 64, 300))
+    with pytest.raises(MokaError, match="not in 0..512"):
+        _stage_check(_long_question_case("longq_over_16", "avt", 16, 600))
