@@ -632,6 +632,49 @@ def test_widths_with_a_half_filled_wave(C):
         assert rel(dB, gy.float().t() @ h_ref) < 5e-5
 
 
+def test_large_ragged_token_count_end_to_end():
+    """T = 5 x 13999 = 69995 tokens (not a multiple of 32; y and gy are 2.3 GB each, byte offsets beyond 2^31): the whole autograd node
+    with token routing against plain fp32 GEMMs per modality span; the interaction is switched off (w = 0) so that the
+    check is a size-independent linear identity (maximum-size edge case, no oracle at this size)."""
+    from moka_amd.functional import AdapterSpec, moka_linear
+    from moka_amd.routing import MokaRouting
+    dev = _dev()
+    bf = torch.bfloat16
+    B, S, C_in, C_out, r = 5, 13999, 4096, 16384 + 32, 16
+    T = B * S
+    g = torch.Generator(device=dev).manual_seed(5)
+    tok = torch.zeros(S, dtype=torch.long)
+    tok[100:5000] = 1
+    tok[5003:9000] = 2
+    q = torch.zeros(S, dtype=torch.int32)
+    q[9000:9040] = 1
+    masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)] + [q.reshape(1, S, 1).repeat(B, 1, 1).to(dev)]
+    rt = MokaRouting.from_avt_masks(masks)
+    x = torch.randn(B, S, C_in, device=dev, dtype=bf, generator=g).requires_grad_(True)
+    W = torch.zeros(C_out, C_in, device=dev, dtype=bf)                       # base output 0: y is the adapter alone
+    A = [(torch.randn(r, C_in, device=dev, generator=g) * 0.05).to(bf).requires_grad_(True) for _ in range(3)]
+    Bw = (torch.randn(C_out, r, device=dev, generator=g) * 0.05).to(bf).requires_grad_(True)
+    gy = torch.randn(B, S, C_out, device=dev, dtype=bf, generator=g)
+    y = moka_linear(x, W, None, Bw, A, rt, AdapterSpec(r, 1.0, [1.0] * 3, 0.0, 0.25))
+    y.backward(gy)
+    tokd = tok.to(dev).repeat(B)
+    x2, gy2 = x.detach().reshape(T, C_in).float(), gy.reshape(T, C_out).float()
+    h = torch.zeros(T, r, device=dev)
+    for m in range(3):
+        sel = tokd == m
+        h[sel] = x2[sel] @ A[m].detach().float().t()
+    assert rel(y.reshape(T, C_out), (h @ Bw.detach().float().t()).to(bf)) < TOL_BF16
+    gh = gy2 @ Bw.detach().float()
+    assert rel(Bw.grad, gy2.t() @ h) < 2e-3                                  # bf16 cast of the fp32 sum
+    dx_ref = torch.zeros(T, C_in, device=dev)
+    for m in range(3):
+        sel = tokd == m
+        assert rel(A[m].grad, gh[sel].t() @ x2[sel]) < 2e-3, m
+        dx_ref[sel] = gh[sel] @ A[m].detach().float()
+    assert rel(x.grad.reshape(T, C_in), dx_ref.to(bf)) < TOL_BF16
+    assert not torch.isnan(y).any() and not torch.isnan(x.grad).any()
+
+
 # ------------------------------------------------------------------------------------------
 # randomised shapes / layouts: every C entry point against the fp64 oracle (same checks as the fixed cases)
 # ------------------------------------------------------------------------------------------
