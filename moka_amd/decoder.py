@@ -113,12 +113,39 @@ def _rotate(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tens
     return x * cos + torch.cat([-x[..., h:], x[..., :h]], dim=-1) * sin
 
 
+def _project(proj: nn.Module, x: torch.Tensor, masks: tuple, merged: Optional[dict]):
+    """One adapted projection; with ``merged`` (see ``MokaLlamaStack.merge_for_decode``) a decode step is a single GEMM."""
+    if merged is not None:
+        Wd, bias = merged[id(proj)]
+        return TF.linear(x, Wd, bias)
+    return proj(x, *masks)
+
+
 def _live_masks(mask_args: tuple, past_len: int) -> tuple:
     """The forked decoders hand the masks to the projections for training and for the prefill, and ``None`` for
     every cached decode step (VT ``modeling_llama.py:311-329``; AVT gates the list the same way, ``:647-654``)."""
     if past_len == 0:
         return mask_args
     return tuple(None for _ in mask_args)
+
+
+def decode_weight(proj: nn.Module) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(weight, bias) of the ONE dense layer a cached decode step of an adapted projection amounts to:
+    without masks only the text adapter acts and there is no interaction, ``y = x W^T + s x A_text^T B^T`` (AVT
+    ``lora.py:373-381``, VT ``layer.py:672-678``), i.e. ``W + s B A_text``.  Not the reference's ``merge()``, which folds
+    every active adapter (``layer.py:425-546``) and is not equivalent to the masked forward."""
+    if hasattr(proj, "lora_A0"):                                   # AVT mirror (weight shared on the module itself)
+        W, A, Bw, s = proj.weight, proj.lora_A0.weight, proj.lora_B0.weight, proj.scaling[0]
+        if getattr(proj, "fan_in_fan_out", False):
+            W = W.T
+        bias = proj.bias
+    elif hasattr(proj, "lora_A") and "text" in getattr(proj, "lora_A", {}):     # VT mirror (wrapped base layer)
+        base = proj.get_base_layer()
+        W, A, Bw, s, bias = base.weight, proj.lora_A["text"].weight, proj.lora_B["text"].weight, proj.scaling["text"], base.bias
+    else:                                                          # a projection the adapter was not attached to
+        return proj.weight, getattr(proj, "bias", None)
+    Wd = (W.float() + s * (Bw.float() @ A.float())).to(W.dtype)
+    return Wd, bias
 
 
 class MokaLlamaAttention(nn.Module):
@@ -135,10 +162,12 @@ class MokaLlamaAttention(nn.Module):
         self.o_proj = make_proj(dims.n_heads * hd, dims.hidden)
 
     def forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *mask_args,
-                kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, grouped: bool = True):
+                kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, grouped: bool = True, merged: Optional[dict] = None):
         B, S, _ = x.shape
         d = self.dims
-        if grouped:
+        if merged is not None:
+            q, k, v = (_project(p_, x, mask_args, merged) for p_ in (self.q_proj, self.k_proj, self.v_proj))
+        elif grouped:
             q, k, v = qkv_forward(self, x, *mask_args)
         else:
             q, k, v = self.q_proj(x, *mask_args), self.k_proj(x, *mask_args), self.v_proj(x, *mask_args)
@@ -154,7 +183,7 @@ class MokaLlamaAttention(nn.Module):
             k, v = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
         o = TF.scaled_dot_product_attention(q, k, v, is_causal=(kv_cache is None and S > 1))
         o = o.transpose(1, 2).reshape(B, S, d.n_heads * d.head_dim)
-        return self.o_proj(o, *mask_args), new_cache
+        return _project(self.o_proj, o, mask_args, merged), new_cache
 
 
 class MokaLlamaDecoderLayer(nn.Module):
@@ -172,12 +201,19 @@ class MokaLlamaDecoderLayer(nn.Module):
                                                 down_proj=make_proj(dims.ff, dims.hidden), act_fn=nn.SiLU()))
 
     def forward(self, h: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *mask_args,
-                kv_cache=None, grouped: bool = True):
+                kv_cache=None, grouped: bool = True, merged: Optional[dict] = None):
         past_len = 0 if kv_cache is None else kv_cache[0].shape[2]
         masks = _live_masks(mask_args, past_len)
-        a, new_cache = self.self_attn(self.input_layernorm(h), cos, sin, *masks, kv_cache=kv_cache, grouped=grouped)
+        if past_len == 0:
+            merged = None                                   # the merged weights stand for the mask-free decode branch only
+        a, new_cache = self.self_attn(self.input_layernorm(h), cos, sin, *masks, kv_cache=kv_cache, grouped=grouped, merged=merged)
         h = h + a
-        m = self.mlp(self.post_attention_layernorm(h), *masks, grouped=grouped)
+        x = self.post_attention_layernorm(h)
+        if merged is not None:
+            mlp = self.mlp
+            m = _project(mlp.down_proj, mlp.act_fn(_project(mlp.gate_proj, x, masks, merged)) * _project(mlp.up_proj, x, masks, merged), masks, merged)
+        else:
+            m = self.mlp(x, *masks, grouped=grouped)
         return h + m, new_cache
 
 
@@ -190,6 +226,20 @@ class MokaLlamaStack(nn.Module):
         self.dims = dims
         self.layers = nn.ModuleList(MokaLlamaDecoderLayer(dims, make_proj) for _ in range(n_layers))
 
+    def merge_for_decode(self) -> None:
+        """Pre-compute ``decode_weight`` of all 7 x L projections (inference only; call again after the adapter changed).
+        Decode steps (``kv_caches`` given, past > 0) then run one GEMM per projection instead of base GEMM + three adapter
+        launches; prefill and training are unaffected."""
+        self._merged = {}
+        for layer in self.layers:
+            a, m = layer.self_attn, layer.mlp
+            for p_ in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, m.gate_proj, m.up_proj, m.down_proj):
+                with torch.no_grad():
+                    self._merged[id(p_)] = decode_weight(p_)
+
+    def unmerge(self) -> None:
+        self._merged = None
+
     def forward(self, h: torch.Tensor, *mask_args, kv_caches: Optional[list] = None, grouped: bool = True,
                 on_layer: Optional[Callable[[int], None]] = None):
         S = h.shape[1]
@@ -197,7 +247,8 @@ class MokaLlamaStack(nn.Module):
         cos, sin = rotary_tables(S, self.dims.head_dim, self.dims.rope_theta, h.device, h.dtype, offset=past)
         caches = []
         for i, layer in enumerate(self.layers):
-            h, c = layer(h, cos, sin, *mask_args, kv_cache=None if kv_caches is None else kv_caches[i], grouped=grouped)
+            h, c = layer(h, cos, sin, *mask_args, kv_cache=None if kv_caches is None else kv_caches[i], grouped=grouped,
+                         merged=getattr(self, "_merged", None))
             caches.append(c)
             if on_layer is not None:
                 on_layer(i)

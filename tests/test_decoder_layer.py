@@ -209,3 +209,59 @@ def test_prefill_with_masks_then_cached_decode_equals_full_forward():
         step, _ = st(h[:, S - 1:], masks_pre, kv_caches=caches)     # stale masks of the wrong length: must be ignored
     assert rel(pre, full[:, :S - 1]) < 2e-2
     assert rel(step, full[:, S - 1:]) < 2e-2
+
+
+def test_decode_weight_equals_the_text_adapter_branch_on_cpu():
+    """decode_weight(W + s B A_text) against the oracle's mask-free branch (plain LoRA with the text adapter), both mirrors'
+    parameter layouts emulated with bare modules (no GPU needed: pure tensor algebra)."""
+    from types import SimpleNamespace
+    from moka_amd.decoder import decode_weight
+    from oracle import moka_oracle as O
+    g = torch.Generator().manual_seed(3)
+    d_in, d_out, r, s_ = 48, 40, 8, 2.0
+    W, A, Bw = torch.randn(d_out, d_in, generator=g), torch.randn(r, d_in, generator=g), torch.randn(d_out, r, generator=g)
+    x = torch.randn(2, 1, d_in, generator=g)
+    y_ref = O.plain_lora_forward(x, torch.nn.functional.linear(x.double(), W.double()), A, Bw, s_)
+    avt = SimpleNamespace(weight=W, bias=None, lora_A0=SimpleNamespace(weight=A), lora_B0=SimpleNamespace(weight=Bw), scaling=[s_], fan_in_fan_out=False)
+    Wd, b = decode_weight(avt)
+    assert b is None and torch.allclose(torch.nn.functional.linear(x, Wd).double(), y_ref, atol=1e-4)
+    vt = SimpleNamespace(lora_A={"text": SimpleNamespace(weight=A), "image": SimpleNamespace(weight=A * 0)},
+                         lora_B={"text": SimpleNamespace(weight=Bw), "image": SimpleNamespace(weight=Bw * 0)}, scaling={"text": s_, "image": 9.0},
+                         get_base_layer=lambda: SimpleNamespace(weight=W, bias=None))
+    Wd2, _ = decode_weight(vt)
+    assert torch.equal(Wd, Wd2)
+    plain = torch.nn.Linear(d_in, d_out, bias=False)
+    assert decode_weight(plain)[0] is plain.weight
+
+
+@pytest.mark.gpu
+def test_merged_decode_steps_match_the_adapter_path():
+    dev = _dev()
+    torch.manual_seed(1)
+    from moka_amd.peft_hyper import Linear
+
+    def make(d_in, d_out):
+        m = Linear(d_in, d_out, r=(16, 16, 16), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.0,
+                   loramethod="test", bias=False)
+        torch.nn.init.normal_(m.lora_B0.weight, std=0.05)
+        return m
+
+    st = MokaLlamaStack(DIMS, 2, make).to(dev, torch.bfloat16).eval()
+    B, S = 2, 80
+    masks = _avt_masks(B, S, dev)
+    h = torch.randn(B, S + 3, DIMS.hidden, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        pre, caches = st(h[:, :S], masks)
+        outs = []
+        c = caches
+        for i in range(3):                                          # three decode steps on the HIP adapter path
+            o, c = st(h[:, S + i:S + i + 1], masks, kv_caches=c)
+            outs.append(o)
+        st.merge_for_decode()
+        pre2, caches2 = st(h[:, :S], masks)                         # prefill is untouched by the merge
+        assert torch.equal(pre, pre2)
+        c = caches2
+        for i in range(3):                                          # the same steps as one GEMM per projection
+            o, c = st(h[:, S + i:S + i + 1], masks, kv_caches=c)
+            assert rel(o, outs[i]) < 1e-2
+        st.unmerge()
