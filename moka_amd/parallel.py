@@ -19,6 +19,7 @@ tensors (tests/test_parallel_gloo.py).
 """
 from __future__ import annotations
 
+import math
 from typing import List, Optional, Sequence
 
 import torch
@@ -99,3 +100,98 @@ def bind_param_grads(params: Sequence[torch.nn.Parameter], bucket: FlatGradBucke
         if view.dtype != p.dtype:
             raise TypeError(f"flat bucket is {view.dtype} but parameter is {p.dtype}")
         p.grad = view
+
+
+class ShardedFrozenBase:
+    """Frozen base weights sharded 1/N per rank and gathered one decoder layer at a time.
+
+    The reference runs its 70B configuration under DeepSpeed ZeRO-3 (``VisualText/zero_stage3_config_70b.json:2-13``:
+    parameter partitioning with prefetch).  On MI355X the bf16 70B base (140 GB) fits one GPU's 288 GB, so replication is
+    the default; this store is for when the memory is wanted for activations instead.  One flat buffer per layer (its
+    frozen tensors back to back, padded to a multiple of the world size), each rank keeps its contiguous 1/N slice;
+    ``prefetch(l)`` starts ``all_gather_into_tensor`` of layer l into one of two full-size staging buffers on a side
+    stream (RCCL over xGMI; one large collective per layer, not one per tensor), ``layer(l)`` waits for it and returns
+    the tensors as views of the staging buffer.  Two buffers: layer l + 1 (forward) or l - 1 (backward) streams in while
+    layer l computes.  The adapter parameters are never sharded (they are small and live in ``FlatGradBucket``)."""
+
+    def __init__(self, layers: Sequence[Sequence[tuple]], device, process_group=None, dtype=torch.bfloat16):
+        """layers[l] = [(name, tensor), ...] full frozen tensors of layer l (consumed: only the local shard is kept)."""
+        self.group = process_group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if on else 1
+        self.rank = dist.get_rank(process_group) if on else 0
+        self.device = torch.device(device)
+        self.meta: List[List[tuple]] = []          # per layer: (name, offset, shape)
+        self.shards: List[torch.Tensor] = []
+        self.padded: List[int] = []
+        for tensors in layers:
+            off, meta = 0, []
+            for name, t in tensors:
+                meta.append((name, off, tuple(t.shape)))
+                off += t.numel()
+            pad = (off + self.world - 1) // self.world * self.world
+            flat = torch.zeros(pad, dtype=dtype, device=self.device)
+            for (name, o, shape), (_, t) in zip(meta, tensors):
+                flat[o:o + t.numel()].copy_(t.reshape(-1))
+            n = pad // self.world
+            self.shards.append(flat[self.rank * n:(self.rank + 1) * n].clone())
+            self.meta.append(meta)
+            self.padded.append(pad)
+        cap = max(self.padded) if self.padded else 0
+        self.stage = [torch.empty(cap, dtype=dtype, device=self.device) for _ in range(2)]
+        self.holds = [-1, -1]                      # layer held by each staging buffer
+        self.pending = [None, None]
+        self.is_cuda = self.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.is_cuda and self.world > 1) else None
+        self._turn = 0
+
+    def shard_bytes(self) -> int:
+        return sum(s.numel() * s.element_size() for s in self.shards)
+
+    def prefetch(self, l: int) -> None:
+        """Start gathering layer l (no-op if it is already staged or on its way)."""
+        if l < 0 or l >= len(self.shards) or l in self.holds:
+            return
+        slot = self._turn
+        self._turn ^= 1
+        if self.pending[slot] is not None:         # the buffer's previous gather must have landed before it is reused
+            self._wait(slot)
+        out = self.stage[slot][:self.padded[l]]
+        self.holds[slot] = l
+        if self.world == 1:
+            out.copy_(self.shards[l])
+            return
+        if self.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))      # the consumer of the buffer's previous content is enqueued
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.pending[slot] = dist.all_gather_into_tensor(out, self.shards[l], group=self.group, async_op=True)
+        else:
+            self.pending[slot] = dist.all_gather_into_tensor(out, self.shards[l], group=self.group, async_op=True)
+
+    def _wait(self, slot: int) -> None:
+        wk = self.pending[slot]
+        if wk is None:
+            return
+        if self.is_cuda:
+            done = torch.cuda.Event()
+            with torch.cuda.stream(self.comm_stream):
+                wk.wait()
+                done.record(self.comm_stream)
+            torch.cuda.current_stream(self.device).wait_event(done)
+        else:
+            wk.wait()
+        self.pending[slot] = None
+
+    def layer(self, l: int, prefetch_next: Optional[int] = None) -> dict:
+        """Full tensors of layer l (views of a staging buffer, valid until two more layers were requested)."""
+        if l not in self.holds:
+            self.prefetch(l)
+        slot = self.holds.index(l)
+        self._wait(slot)
+        if prefetch_next is not None:
+            self._turn = slot ^ 1                  # never overwrite the buffer that was just handed out
+            self.prefetch(prefetch_next)
+        buf = self.stage[slot]
+        return {name: buf[o:o + math.prod(shape)].view(shape) for name, o, shape in self.meta[l]}

@@ -73,3 +73,50 @@ def test_single_process_is_a_noop():
     p = torch.nn.Parameter(torch.zeros(2, 3))
     bind_param_grads([p], b, [4])
     assert p.grad.data_ptr() == b.flat[4:].data_ptr()
+
+
+def _shard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import ShardedFrozenBase
+    g = torch.Generator().manual_seed(7)           # same full weights on every rank before sharding
+    full = [[("q.weight", torch.randn(6, 5, generator=g)), ("mlp.weight", torch.randn(7, 3, generator=g))] for _ in range(5)]
+    ref = [[(n, t.clone()) for n, t in layer] for layer in full]
+    store = ShardedFrozenBase(full, "cpu", dtype=torch.float32)
+    total = sum(t.numel() for layer in ref for _, t in layer)
+    ok = store.shard_bytes() <= (total // world + world * len(ref)) * 4           # each rank keeps ~1/N
+    order = list(range(5)) + list(range(4, -1, -1))                                # forward, then backward
+    for i, l in enumerate(order):
+        nxt = order[i + 1] if i + 1 < len(order) else None
+        got = store.layer(l, prefetch_next=nxt)
+        for n, t in ref[l]:
+            ok = ok and torch.equal(got[n], t)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_frozen_base_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(2)]
+    assert all(ok for _, ok in res), res
+
+
+def test_sharded_frozen_base_single_process():
+    sys.path.insert(0, ROOT)
+    from moka_amd.parallel import ShardedFrozenBase
+    layers = [[("w", torch.arange(12.0).reshape(3, 4) + 100 * l)] for l in range(3)]
+    ref = [layer[0][1].clone() for layer in layers]
+    store = ShardedFrozenBase(layers, "cpu", dtype=torch.float32)
+    for l in (0, 1, 2, 1, 0):
+        assert torch.equal(store.layer(l, prefetch_next=None)["w"], ref[l])
