@@ -447,11 +447,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl" on ROCm).  MOKA_BENCH_BACKEND=gloo is a functional check of the N > 1 script path on a box with fewer
+        # GPUs than ranks (ranks share a device; gloo stages the gradient slices through the host) -- never a measurement.
+        backend = os.environ.get("MOKA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from moka_amd import _lib
     lib = _lib.load()
