@@ -701,9 +701,18 @@ __global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab
         for (int row = wave; row < nrow; row += NWV) {
             const int m = s_mod[row];
             if (m == 0 || m == MOKA_MOD_NONE) continue;
-            float q[RP], dO[RP];
+            // the query row and its upstream gradient: per-lane register copies for the narrow ranks; for rank pad 64 they stay
+            // in LDS and are read as broadcasts inside the k loops (two RP-long arrays less per lane: no scratch at KCH <= 2)
+            constexpr bool QLDS = (RP == 64);
+            const float* qrow = Hs + row * KP;
+            const float* grow = Gs + row * KP;
+            float q[QLDS ? 1 : RP], dO[QLDS ? 1 : RP];
+            if (!QLDS) {
 #pragma unroll
-            for (int k = 0; k < RP; ++k) { q[k] = Hs[row * KP + k]; dO[k] = a.w * Gs[row * KP + k]; }
+                for (int k = 0; k < RP; ++k) { q[k] = qrow[k]; dO[k] = a.w * grow[k]; }
+            }
+            auto Q = [&](int k) { return QLDS ? qrow[k] : q[k]; };
+            auto DO = [&](int k) { return QLDS ? a.w * grow[k] : dO[k]; };
             float p[KCH], dP[KCH];
             float mx = -INFINITY;
 #pragma unroll
@@ -713,7 +722,7 @@ __global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab
                 if (j < Lk) {
                     s = 0.f;
 #pragma unroll
-                    for (int k = 0; k < RP; ++k) { s = fmaf(q[k], Ks[j * KP + k], s); d = fmaf(dO[k], Ks[j * KP + k], d); }
+                    for (int k = 0; k < RP; ++k) { s = fmaf(Q(k), Ks[j * KP + k], s); d = fmaf(DO(k), Ks[j * KP + k], d); }
                     s *= a.c;
                 }
                 p[ch] = s; dP[ch] = d;
@@ -744,7 +753,7 @@ __global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab
 #pragma unroll
                     for (int k = 0; k < RP; ++k) {
                         dq[k] = fmaf(dS, Ks[j * KP + k], dq[k]);
-                        dK[ch][k] = fmaf(p[ch], dO[k], fmaf(dS, q[k], dK[ch][k]));
+                        dK[ch][k] = fmaf(p[ch], DO(k), fmaf(dS, Q(k), dK[ch][k]));
                     }
                 }
             }
