@@ -50,7 +50,7 @@ def forward_group(modules: Sequence[nn.Module], x: torch.Tensor, *mask_args, **k
     Falls back to the per-module calls whenever a module takes one of the reference's non-adapter
     branches (adapters disabled / merged, ``loramethod`` without train/test) or the modules disagree on
     rank, scaling, interaction weight or dropout."""
-    if len(modules) < 2 or len(modules) > 3 or not all(hasattr(m, "_plan") for m in modules):
+    if len(modules) < 2 or len(modules) > 3 or not all(hasattr(m, "_plan") for m in modules) or x.numel() == 0:
         return [m(x, *mask_args, **kwargs) for m in modules]
     plans = [m._plan(x, *mask_args, **kwargs) for m in modules]
     if any(p is None for p in plans) or not _compatible(plans):

@@ -195,6 +195,8 @@ class Linear(nn.Module, LoraLayer):
             raise NotImplementedError("moka_amd: per-sample `adapter_names` (mixed-batch LoRA) is outside the MokA path")
         if self.merged:
             return self.base_layer(x, *args, **kwargs)
+        if x.numel() == 0:                      # empty batch: the adapter adds nothing to an empty base output
+            return self.base_layer(x, *args, **kwargs)
         W, bias, Bw, A, rt, spec = self._plan(x, my_text_mask, my_image_mask, question_mask)
         return moka_linear(x, W, bias, Bw, A, rt, spec)
 

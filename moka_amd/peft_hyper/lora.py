@@ -103,6 +103,9 @@ class Linear(nn.Linear, LoraLayer):
         return None                      # the reference falls off the end of forward (lora.py:532)
 
     def forward(self, x: torch.Tensor, modality_mask: Optional[List[torch.Tensor]] = None):
+        if x.numel() == 0 and ("test" in (self.loramethod or "") or "train" in (self.loramethod or "")):
+            # empty batch: the reference's per-sample loops run zero times and the adapter adds nothing (lora.py:485,524)
+            return torch.nn.functional.linear(x, self.weight.T if self.fan_in_fan_out else self.weight, self.bias)
         plan = self._plan(x, modality_mask)
         if plan is None:
             return None

@@ -120,3 +120,18 @@ def test_vt_disabled_and_merged_paths_use_base_only():
     assert torch.equal(lin(x, None, None, None), lin.base_layer(x))
     lin.unmerge()
     assert torch.allclose(lin.base_layer.weight.float(), w0.float(), atol=1e-2)
+
+
+def test_empty_batch_returns_the_empty_base_output():
+    """B = 0: the reference's per-sample loops run zero times; nothing is launched, on any device."""
+    from moka_amd.peft_hyper import Linear as AvtLinear
+    from moka_amd.modified_peft import layer as vt_layer
+    a = AvtLinear(32, 64, r=(4, 4, 4), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.0,
+                  loramethod="train", bias=False)
+    y = a(torch.zeros(0, 5, 32), [torch.zeros(0, 5, 1, dtype=torch.int32)] * 4)
+    assert y.shape == (0, 5, 64)
+    v = vt_layer.Linear(torch.nn.Linear(32, 64, bias=False), "image", r=4, lora_alpha=16, lora_dropout=0.0, attn_weight=0.05)
+    v.update_layer("text", 4, lora_alpha=16, lora_dropout=0.0, init_lora_weights=True, use_rslora=False)
+    v.set_adapter(["image", "text"])
+    m = torch.zeros(0, 5, dtype=torch.bool)
+    assert v(torch.zeros(0, 5, 32, dtype=v.get_base_layer().weight.dtype), m, m, m).shape == (0, 5, 64)
