@@ -97,11 +97,10 @@ int moka_tune(const char* key, int value);
 int moka_rank_pad(int r);
 /* Token count rounded up to the pack granularity (32). */
 int moka_tok_pad(int T);
-/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C (r <= 16: one per 512 columns)
- * (moka_down_fwd: C = d_in).  `part` holds ks * T * RP floats. */
+/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C (one per 512 columns; C = d_in).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
- * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  r <= 16: one slice per 512-column block of gy. */
+ * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy. */
 int moka_ksplit_bwd(int T, int C, int r);
 
 /* ---- forward ----------------------------------------------------------------------- */
