@@ -814,22 +814,41 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossBat
     int* list = (int*)smem;                           // [nblk] indices of the blocks that wrote a partial
     __shared__ int s_n;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // Latency structure: the key token of my element is requested first (it does not depend on anything), the flags next;
+    // everything that depends on the token (owner check, routing byte, the row's own g slices) is requested together with
+    // the partials, so the kernel is two memory round trips deep instead of five.
+    const int e = blockIdx.y * 16 + (tid >> 4), sub = tid & 15;
+    const bool live = e < a.Lkp * RP;
+    const int j = e / RP, k = e % RP;
+    const int t = (live && sub == 0) ? a.ktok[b * a.Lkp + j] : -1;
     if (tid < 64) {                                   // wave 0 compacts the flag list
         int n = 0;
-        for (int base = 0; base < nblk; base += 64) {
-            const int blk = base + lane;
-            const bool f = blk < nblk && a.dk_flag[b * nblk + blk] != 0;
-            const unsigned long long mask = __ballot(f);
-            if (f) list[n + __popcll(mask & ((1ull << lane) - 1ull))] = blk;
-            n += __popcll(mask);
+        constexpr int FU = 8;                         // flags of 64 * FU blocks are requested together (one round trip, not one per 64)
+        for (int base0 = 0; base0 < nblk; base0 += 64 * FU) {
+            int fl[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) fl[u] = a.dk_flag[b * nblk + min(base0 + 64 * u + lane, nblk - 1)];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int blk = base0 + 64 * u + lane;
+                const bool f = blk < nblk && fl[u] != 0;
+                const unsigned long long mask = __ballot(f);
+                if (f) list[n + __popcll(mask & ((1ull << lane) - 1ull))] = blk;
+                n += __popcll(mask);
+            }
         }
         if (lane == 0) s_n = n;
     }
     __syncthreads();
     const int n = s_n;
+    int owner = -2, mod = MOKA_MOD_NONE;
+    float own = 0.f;
+    if (t >= 0) {                                     // (sub == 0 lanes of live elements with a real key token)
+        owner = a.kslot[t];
+        mod = a.tok_mod[t];
+        own = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
+    }
     // 16 lanes per (key slot, rank) element: each sums a strided share of the flagged partials
-    const int e = blockIdx.y * 16 + (tid >> 4), sub = tid & 15;
-    const bool live = e < a.Lkp * RP;
     float v = 0.f;
     if (live) {
         const float* src = a.dk_part + (size_t)b * nblk * a.Lkp * RP + e;
@@ -837,13 +856,10 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossBat
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (!live || sub != 0) return;
-    const int j = e / RP, k = e % RP;
-    const int t = a.ktok[b * a.Lkp + j];
-    if (t < 0 || a.kslot[t] != j) return;           // zero key row / not the owner of that token
-    v += sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
+    if (t < 0 || owner != j) return;                  // zero key row / not the owner of that token / helper lane
+    v += own;
     if (a.out_f32) a.out_f32[(size_t)t * RP + k] = v;
-    write_packs_bwd<RP>(a, t, k, a.tok_mod[t], v * a.s_mod[0]);
+    write_packs_bwd<RP>(a, t, k, mod, v * a.s_mod[0]);
 }
 
 // ------------------------------------------------------------------------------------------
