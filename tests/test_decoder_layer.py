@@ -265,3 +265,41 @@ def test_merged_decode_steps_match_the_adapter_path():
             o, c = st(h[:, S + i:S + i + 1], masks, kv_caches=c)
             assert rel(o, outs[i]) < 1e-2
         st.unmerge()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reentrant", [False, True])
+def test_activation_checkpointing_replays_the_dropout_masks(reentrant):
+    """The reference trains AVT with gradient checkpointing (ft_musicavqa.sh:41).  The per-call dropout seeds come from torch's
+    CPU generator, which checkpointing restores before the re-forward: gradients with and without checkpointing must agree
+    (up to the atomics' summation order), i.e. the recomputed masks are the ones the first forward used."""
+    from torch.utils.checkpoint import checkpoint
+    dev = _dev()
+    layer = _avt_layer(dev, p=0.1).train()
+    B, S = 2, 96
+    masks = _avt_masks(B, S, dev)
+    cos, sin = rotary_tables(S, DIMS.head_dim, DIMS.rope_theta, dev, torch.bfloat16)
+    h0 = torch.randn(B, S, DIMS.hidden, generator=torch.Generator().manual_seed(1)).to(dev, torch.bfloat16)
+
+    def run(ckpt):
+        torch.manual_seed(123)
+        for p_ in layer.parameters():
+            p_.grad = None
+        h = h0.clone().requires_grad_(True)
+        if ckpt:
+            out = checkpoint(lambda hh: layer(hh, cos, sin, masks)[0], h, use_reentrant=reentrant)
+        else:
+            out = layer(h, cos, sin, masks)[0]
+        out.float().square().mean().backward()
+        return out.detach(), h.grad, {n: p_.grad.clone() for n, p_ in layer.named_parameters() if p_.grad is not None}
+
+    o1, dh1, g1 = run(False)
+    o2, dh2, g2 = run(True)
+    assert torch.equal(o1, o2)
+    assert rel(dh2, dh1) < 1e-3
+    assert set(g1) == set(g2) and sum("lora_" in n for n in g1) == 7 * 4
+    for n in g1:
+        assert rel(g2[n], g1[n]) < 1e-3, n
+    torch.manual_seed(124)                     # another seed gives other masks (the check above is not vacuous)
+    h = h0.clone()
+    assert not torch.equal(layer(h, cos, sin, masks)[0], o1)
