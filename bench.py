@@ -434,6 +434,9 @@ def main():
     ap.add_argument("--e2e", action="store_true",
                     help="also time the whole decoder stack (frozen base + adapters) through moka_amd/decoder.py and report it as "
                          "`end_to_end` (context only; the metric stays the adapter path)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the 1024 launches of a step as one hipGraph (single GPU; not the default because the dominant kernel "
+                         "can then not be bracketed with HIP events inside the timed region -- `roofline` comes from the extra pass)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -479,9 +482,33 @@ def main():
     records = Recorder(only=LIVE)
     records.reserve(2 * len(wl["units"]) * args.steps + 16)
 
+    graph = None
+    if args.graph:
+        # the launch sequence of one micro-batch (1024 launches) as ONE hipGraph: the library only enqueues on the stream it is
+        # given (no allocation, no sync), so it captures as is.  Single GPU only: the bucketed all-reduce hooks stay outside.
+        assert world == 1, "--graph: single-GPU experiment"
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            spw = c_void_p(side.cuda_stream)
+            run_forward(lib, wl, spw)
+            run_backward(lib, wl, spw, L)                # warm-up on the capture stream (LDS attributes, lazy module load)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            spg = c_void_p(torch.cuda.current_stream().cuda_stream)
+            run_forward(lib, wl, spg)          # (event records captured as graph nodes cannot be timed on ROCm: no brackets in here)
+            run_backward(lib, wl, spg, L)
+
     def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
         bucket.zero_()                               # same stream as the previous optimizer step
+        if graph is not None:
+            graph.replay()
+            bucket.finish(average=True)
+            if opt is not None:
+                opt.step()
+                wl["work"].copy_(wl["master"])
+            return
         run_forward(lib, wl, sp, rec)
         run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
         bucket.finish(average=True)
@@ -536,7 +563,10 @@ def main():
         run_forward(lib, wl, sp_, extra)
         run_backward(lib, wl, sp_, L, None, extra)
         torch.cuda.synchronize()
-        tot_x, cnt_x, _, per_shape_x = collect(extra.items)
+        tot_x, cnt_x, byt_x, per_shape_x = collect(extra.items)
+        live_items = records.items
+        if not live_items:                               # --graph: nothing was bracketed inside the timed region
+            tot, cnt, byt, live_items = tot_x, cnt_x, byt_x, extra.items
         table = {}
         for (n, label, di, dos), (ms, c_, nb) in sorted(per_shape_x.items()):
             avg = ms / c_
@@ -551,7 +581,7 @@ def main():
         traffic = None
         if args.seq == 2048:
             tr = 0.0
-            for n, u, e0, e1 in records.items:
+            for n, u, e0, e1 in live_items:
                 if n == dom:
                     tr += sum(pmc_traffic_bytes(n, do, T) or float("nan") for do in u.d_outs)
             if tr == tr:
