@@ -225,8 +225,13 @@ class Recorder:
     """HIP-event brackets around launches on the launch stream.  `only` limits which entry points are
     bracketed (bracketing every launch of a step makes the host the bottleneck and distorts the headline)."""
 
-    def __init__(self, only=None):
-        self.only, self.items, self.pool = only, [], []
+    def __init__(self, only=None, every=1):
+        self.only, self.items, self.pool, self.every, self.seen = only, [], [], max(1, int(every)), 0
+
+    def skip(self):
+        """Bracket every `every`-th eligible launch (an event record is a packet of its own on the stream: ~2 us each)."""
+        self.seen += 1
+        return (self.seen % self.every) != 0
 
     def event(self):
         return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
@@ -238,7 +243,7 @@ class Recorder:
 def _call(lib, name, u, sp, rec):
     """Launch one entry point of unit `u`; bracket it with HIP events when the recorder asks for it."""
     sym, args = u.calls[name]
-    if rec is None or (rec.only is not None and name not in rec.only):
+    if rec is None or (rec.only is not None and name not in rec.only) or rec.skip():
         rc = getattr(lib, sym)(*args, sp)
     else:
         e0, e1 = rec.event(), rec.event()
@@ -257,10 +262,10 @@ def run_forward(lib, wl, sp, rec=None):
         _call(lib, "moka_up_fwd", u, sp, rec)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None):
-    """Reverse layer order; `on_layer_done(l)` fires after layer l's launches are enqueued."""
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0):
+    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued."""
     units, per = wl["units"], wl["units_per_layer"]
-    for l in range(n_layers - 1, -1, -1):
+    for l in range(n_layers - 1, lo - 1, -1):
         for u in reversed(units[l * per:(l + 1) * per]):
             _call(lib, "moka_up_bwd", u, sp, rec)
             _call(lib, "moka_cross_bwd", u, sp, rec)
@@ -434,9 +439,13 @@ def main():
     ap.add_argument("--e2e", action="store_true",
                     help="also time the whole decoder stack (frozen base + adapters) through moka_amd/decoder.py and report it as "
                          "`end_to_end` (context only; the metric stays the adapter path)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the 1024 launches of a step as one hipGraph (single GPU; not the default because the dominant kernel "
-                         "can then not be bracketed with HIP events inside the timed region -- `roofline` comes from the extra pass)")
+    ap.add_argument("--graph", choices=("off", "bwd", "all"), default="off",
+                    help="hipGraph replay: bwd = one graph per gradient bucket of the backward (forward live, brackets and DP hooks "
+                         "unchanged); all = the whole micro-batch as one graph (single GPU, no brackets in the timed region)")
+    ap.add_argument("--bracket-every", type=int, default=5,
+                    help="bracket every n-th launch of the dominant kernel with HIP events inside the timed region (an event record is a "
+                         "packet of its own: bracketing all 128 launches of a step costs 0.7 ms of it; 5 is coprime to the 4 unit shapes "
+                         "of a layer, so the sample covers them evenly)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -479,38 +488,59 @@ def main():
         opt = torch.optim.AdamW([mp], lr=1e-4, fused=True)
     L = args.layers
 
-    records = Recorder(only=LIVE)
+    records = Recorder(only=LIVE, every=args.bracket_every)
     records.reserve(2 * len(wl["units"]) * args.steps + 16)
 
-    graph = None
-    if args.graph:
-        # the launch sequence of one micro-batch (1024 launches) as ONE hipGraph: the library only enqueues on the stream it is
-        # given (no allocation, no sync), so it captures as is.  Single GPU only: the bucketed all-reduce hooks stay outside.
-        assert world == 1, "--graph: single-GPU experiment"
-        side = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(side):
-            spw = c_void_p(side.cuda_stream)
-            run_forward(lib, wl, spw)
-            run_backward(lib, wl, spw, L)                # warm-up on the capture stream (LDS attributes, lazy module load)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            spg = c_void_p(torch.cuda.current_stream().cuda_stream)
-            run_forward(lib, wl, spg)          # (event records captured as graph nodes cannot be timed on ROCm: no brackets in here)
-            run_backward(lib, wl, spg, L)
+    # hipGraphs (the library only enqueues on the stream it is given -- no allocation, no synchronisation -- so its launches
+    # capture unchanged).  "bwd": the backward launches of every gradient bucket (4 layers: 80 kernels) replay as one graph each;
+    # the forward stays live so that the dominant kernel is bracketed with HIP events inside the timed region, and the bucket
+    # hooks (RCCL all-reduce of a finished bucket) run between the graphs exactly as between live layers.  "all": the whole
+    # micro-batch as one graph (single GPU, no brackets: `roofline` then comes from the extra pass).
+    fwd_bwd_graph, bwd_graphs = None, None
+    if args.graph != "off":
+        try:
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                spw = c_void_p(side.cuda_stream)
+                run_forward(lib, wl, spw)
+                run_backward(lib, wl, spw, L)            # warm-up on the capture stream (LDS attributes, lazy module load)
+            torch.cuda.synchronize()
+            if args.graph == "all":
+                assert world == 1, "--graph all: single GPU only"
+                fwd_bwd_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fwd_bwd_graph, stream=side):
+                    spg = c_void_p(torch.cuda.current_stream().cuda_stream)
+                    run_forward(lib, wl, spg)
+                    run_backward(lib, wl, spg, L)
+            else:
+                lpb = bucket.layers_per_bucket
+                bwd_graphs = []
+                for hi in range(L, 0, -lpb):             # buckets are aligned groups of layers, walked last -> first
+                    lo = max(0, (hi - 1) // lpb * lpb)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        run_backward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), hi, lo=lo)
+                    bwd_graphs.append((g, lo, hi))
+            torch.cuda.synchronize()
+        except Exception as exc:                         # capture is an optimisation, never a requirement
+            print(f"bench: hipGraph capture failed ({exc!r}); launching live", file=sys.stderr)
+            fwd_bwd_graph, bwd_graphs = None, None
+            torch.cuda.synchronize()
 
     def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
         bucket.zero_()                               # same stream as the previous optimizer step
-        if graph is not None:
-            graph.replay()
-            bucket.finish(average=True)
-            if opt is not None:
-                opt.step()
-                wl["work"].copy_(wl["master"])
-            return
-        run_forward(lib, wl, sp, rec)
-        run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
+        if fwd_bwd_graph is not None:
+            fwd_bwd_graph.replay()
+        else:
+            run_forward(lib, wl, sp, rec)
+            if bwd_graphs is not None:
+                for g, lo, hi in bwd_graphs:
+                    g.replay()
+                    for l in range(hi - 1, lo - 1, -1):
+                        bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
+            else:
+                run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
         bucket.finish(average=True)
         if opt is not None:
             opt.step()
