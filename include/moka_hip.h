@@ -15,13 +15,13 @@
  *   - all work is enqueued on `stream` (the caller's current stream); no internal
  *     synchronisation, no default-stream use, no persistent device allocations: workspaces
  *     are owned by the caller.  Entry points are re-entrant and stateless (activation
- *     checkpointing re-runs the forward inside backward).
+ *     checkpointing re-runs the forward inside backward) and capture into hipGraphs as they are.
  *   - token-major layouts: T = B*S flattened tokens, row-major, contiguous.
  *       x  [T, d_in]  bf16      y / gy [T, d_out] bf16      dx [T, d_in] bf16
  *       A_m [r, d_in] bf16 (lora_A{m}.weight / lora_A[name].weight)
  *       Bw [d_out, r] bf16 (lora_B0.weight / lora_B['text'].weight)
  *   - rank space (RP = moka_rank_pad(r) in {16,32,64}, Tp = moka_tok_pad(T) = T rounded up to 32):
- *       part          [KS, T, RP] fp32   split-K partial sums written by the reduce kernel
+ *       part          [KS, T, RP] fp32   split-K partial sums written by moka_down_fwd / moka_up_bwd
  *       h, hp, dh     [T, RP]     fp32   rank-space activations / gradients
  *       *_tok  pack   [Tp, 2*RP]  bf16   token-major  [hi(RP) | lo(RP)]  of an fp32 row (hi+lo == value
  *                                        to 2^-17): the MFMA operand of the expand kernel
