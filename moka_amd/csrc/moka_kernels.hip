@@ -540,12 +540,30 @@ __global__ void __launch_bounds__(NTH) moka_cross_fwd_kernel(const CrossBatch ab
     }
     if (anyq) {
         // ---- batch 2: the sample's key rows (indices are in LDS by now)
-        for (int e = tid; e < Lk * RP; e += NTH) {
-            const int j = e / RP, k = e % RP;
-            const int t = Kt[j];
-            float v = 0.f;
-            if (t >= 0) v = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
-            Ks[j * KP + k] = v;
+        // two key elements per thread and round: their slice loads are in flight together (same sums, same order per element)
+        const int nk = Lk * RP;
+        const size_t sstride = (size_t)a.T * RP;
+        for (int e = tid; e < nk; e += 2 * NTH) {
+            const int e1 = e + NTH;
+            const int j0 = e / RP, k0 = e % RP;
+            const int j1 = min(e1, nk - 1) / RP, k1 = e1 % RP;
+            const int t0 = Kt[j0], t1 = Kt[j1];
+            const float* p0 = a.part + (size_t)max(t0, 0) * RP + k0;
+            const float* p1 = a.part + (size_t)max(t1, 0) * RP + k1;
+            float v0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < a.ks; s += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const size_t off = (size_t)min(s + q, a.ks - 1) * sstride;
+                    const float x0 = p0[off], x1 = p1[off];
+                    v0[q] += (s + q < a.ks) ? x0 : 0.f;
+                    v1[q] += (s + q < a.ks) ? x1 : 0.f;
+                }
+            }
+            const float r0 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
+            const float r1 = ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
+            Ks[j0 * KP + k0] = (t0 >= 0) ? r0 : 0.f;
+            if (e1 < nk) Ks[j1 * KP + k1] = (t1 >= 0) ? r1 : 0.f;
         }
         __syncthreads();
         for (int row = wave; row < nrow; row += NWV) {
