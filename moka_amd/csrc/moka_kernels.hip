@@ -704,11 +704,25 @@ __global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab
     }
     if (anyq) {
         // ---- batch 2: key rows of h
-        for (int e = tid; e < Lk * RP; e += NTH) {
-            const int j = e / RP, k = e % RP;
-            const int t = Kt[j];
-            Ks[j * KP + k] = (t >= 0) ? a.hfull[(size_t)t * RP + k] : 0.f;
-            dKs[j * KP + k] = 0.f;
+        // four elements per thread and round, loads unconditional (clamped): one memory round trip for the usual 64 keys x 16 ranks
+        const int nk = Lk * RP;
+        for (int e0 = tid; e0 < nk; e0 += 4 * NTH) {
+            float v[4];
+            int tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * NTH, nk - 1);
+                tt[u] = Kt[e / RP];
+                v[u] = a.hfull[(size_t)max(tt[u], 0) * RP + (e % RP)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * NTH;
+                if (e < nk) {
+                    Ks[(e / RP) * KP + (e % RP)] = (tt[u] >= 0) ? v[u] : 0.f;
+                    dKs[(e / RP) * KP + (e % RP)] = 0.f;
+                }
+            }
         }
         __syncthreads();
         float dK[KCH][RP];
