@@ -112,6 +112,11 @@ class Unit:
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
                                                       drop_p, sd, 0)),
+            # the two halves of moka_down_bwd on their own (--wgrad-stream: dA on a side stream, it feeds nothing downstream)
+            "moka_down_bwd_dx": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, None, dx.data_ptr(), T, self.d_in, r, M, G,
+                                                         drop_p, sd, 0)),
+            "moka_down_bwd_dA": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, None, T, self.d_in, r, M, G,
+                                                         drop_p, sd, 0)),
         }
         # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
         # per-projection definition: a group that reads x once is still credited G reads -- the roofline
@@ -165,9 +170,11 @@ def build_workload(args, dev, lib, bucket_factory):
     Tp = _lib.tok_pad(T)
     max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r), _lib.ksplit_bwd(T, ff, r))
     # scratch shared by all units (consumed before the next unit overwrites it), one slot per group member
-    scratch = [dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
-                    dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
-               for _ in range(3)]
+    # (two sets, alternated unit by unit: with --wgrad-stream the dA kernel of a unit still reads its dh pack while the next
+    #  unit's rank-space kernels run)
+    scratch2 = [[dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
+                      dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
+                 for _ in range(3)] for _ in range(2)]
 
     # units = maximal runs of projections with the same input (--no-group: every projection alone)
     unit_defs = []
@@ -204,7 +211,7 @@ def build_workload(args, dev, lib, bucket_factory):
                                 BwT=torch.empty(RP, d_out, dtype=bf, device=dev), AT=torch.empty(M, d_in, RP, dtype=bf, device=dev)))
         for src, pis in unit_defs:
             mem = [members[pi] for pi in pis]
-            units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch,
+            units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch2[len(units) % 2],
                               1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                               [1000003 * l + pi for pi in pis]))
         layer_end.append(off)
@@ -212,7 +219,7 @@ def build_workload(args, dev, lib, bucket_factory):
     work.copy_(master)
     assert layer_end == bucket.layer_end
     return dict(units=units, units_per_layer=len(unit_defs), rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T,
-                n_params=n_params, layer_end=layer_end, keep=(sets, masks, scratch))
+                n_params=n_params, layer_end=layer_end, keep=(sets, masks, scratch2))
 
 
 ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
@@ -262,16 +269,35 @@ def run_forward(lib, wl, sp, rec=None):
         _call(lib, "moka_up_fwd", u, sp, rec)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0):
-    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued."""
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, side=None):
+    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
+    side: a second stream for the dA half of moka_down_bwd (the weight gradients feed nothing downstream, so they may run
+    beside the next unit's latency-bound rank-space kernels); joined back into the launch stream after every layer."""
     units, per = wl["units"], wl["units_per_layer"]
+    main = torch.cuda.current_stream()
+    done = [None, None]                              # side-stream events of the last two units (their scratch set is reused two units on)
+    j = 0
     for l in range(n_layers - 1, lo - 1, -1):
         for u in reversed(units[l * per:(l + 1) * per]):
             _call(lib, "moka_up_bwd", u, sp, rec)
+            if side is not None and done[j % 2] is not None:
+                main.wait_event(done[j % 2])         # the dA kernel that read this scratch set has finished
             _call(lib, "moka_cross_bwd", u, sp, rec)
-            _call(lib, "moka_down_bwd", u, sp, rec)
+            if side is None:
+                _call(lib, "moka_down_bwd", u, sp, rec)
+            else:
+                side.wait_stream(main)
+                _call(lib, "moka_down_bwd_dA", u, c_void_p(side.cuda_stream), None)
+                done[j % 2] = torch.cuda.Event()
+                done[j % 2].record(side)
+                _call(lib, "moka_down_bwd_dx", u, sp, None)
+            j += 1
         if on_layer_done is not None:
+            if side is not None:
+                main.wait_stream(side)               # the bucket hook ships this layer's gradients
             on_layer_done(l)
+    if side is not None:
+        main.wait_stream(side)
 
 
 # HBM bytes per launch from the PMC counters of profiles/r01_v11_pmc_{fetch,write}_size.md (rocprofv3 --pmc FETCH_SIZE and
@@ -439,18 +465,24 @@ def main():
     ap.add_argument("--e2e", action="store_true",
                     help="also time the whole decoder stack (frozen base + adapters) through moka_amd/decoder.py and report it as "
                          "`end_to_end` (context only; the metric stays the adapter path)")
-    ap.add_argument("--graph", choices=("off", "bwd", "all"), default="off",
-                    help="hipGraph replay: bwd = one graph per gradient bucket of the backward (forward live, brackets and DP hooks "
-                         "unchanged); all = the whole micro-batch as one graph (single GPU, no brackets in the timed region)")
+    ap.add_argument("--graph", choices=("auto", "off", "bwd", "all"), default="auto",
+                    help="hipGraph replay (the library only enqueues on the stream it is given, so its launches capture unchanged): "
+                         "all = the whole micro-batch as one graph (single GPU; nothing can be bracketed inside a graph, so `roofline` comes "
+                         "from one extra, live, fully bracketed pass after the timed region); bwd = one graph per gradient bucket of the "
+                         "backward (forward live, DP hooks between the graphs); off = every launch live; auto = all on 1 GPU, bwd on N > 1")
     ap.add_argument("--bracket-every", type=int, default=5,
                     help="bracket every n-th launch of the dominant kernel with HIP events inside the timed region (an event record is a "
                          "packet of its own: bracketing all 128 launches of a step costs 0.7 ms of it; 5 is coprime to the 4 unit shapes "
                          "of a layer, so the sample covers them evenly)")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="run the dA half of moka_down_bwd on a second stream (it feeds nothing downstream), beside the next unit's kernels")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
     if args.layers is None:
         args.layers = MODELS[args.model]["layers"]
+    if args.graph == "auto":
+        args.graph = "all" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "bwd"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -483,9 +515,10 @@ def main():
     bucket = wl["bucket"]
     opt = None
     if not args.no_optimizer:
-        mp = torch.nn.Parameter(wl["master"])
-        mp.grad = bucket.flat
-        opt = torch.optim.AdamW([mp], lr=1e-4, fused=True)
+        # AdamW on the flat buffers as ONE kernel of the library (moka_adamw_flat): gradient averaging, update of the fp32 master,
+        # bf16 working copy for the next forward and zeroing of the gradient buffer in a single pass (34 B / parameter)
+        from moka_amd.parallel import FlatAdamW
+        opt = FlatAdamW(wl["master"], bucket.flat, wl["work"], lr=1e-4)
     L = args.layers
 
     records = Recorder(only=LIVE, every=args.bracket_every)
@@ -497,13 +530,14 @@ def main():
     # hooks (RCCL all-reduce of a finished bucket) run between the graphs exactly as between live layers.  "all": the whole
     # micro-batch as one graph (single GPU, no brackets: `roofline` then comes from the extra pass).
     fwd_bwd_graph, bwd_graphs = None, None
+    wside = torch.cuda.Stream(device=dev) if args.wgrad_stream else None
     if args.graph != "off":
         try:
             side = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(side):
                 spw = c_void_p(side.cuda_stream)
                 run_forward(lib, wl, spw)
-                run_backward(lib, wl, spw, L)            # warm-up on the capture stream (LDS attributes, lazy module load)
+                run_backward(lib, wl, spw, L, side=wside)   # warm-up on the capture stream (LDS attributes, lazy module load)
             torch.cuda.synchronize()
             if args.graph == "all":
                 assert world == 1, "--graph all: single GPU only"
@@ -511,7 +545,7 @@ def main():
                 with torch.cuda.graph(fwd_bwd_graph, stream=side):
                     spg = c_void_p(torch.cuda.current_stream().cuda_stream)
                     run_forward(lib, wl, spg)
-                    run_backward(lib, wl, spg, L)
+                    run_backward(lib, wl, spg, L, side=wside)
             else:
                 lpb = bucket.layers_per_bucket
                 bwd_graphs = []
@@ -519,7 +553,7 @@ def main():
                     lo = max(0, (hi - 1) // lpb * lpb)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
-                        run_backward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), hi, lo=lo)
+                        run_backward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), hi, lo=lo, side=wside)
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
@@ -529,7 +563,8 @@ def main():
 
     def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
-        bucket.zero_()                               # same stream as the previous optimizer step
+        if opt is None:
+            bucket.zero_()                           # (the optimizer kernel leaves the gradient buffer zeroed)
         if fwd_bwd_graph is not None:
             fwd_bwd_graph.replay()
         else:
@@ -540,11 +575,10 @@ def main():
                     for l in range(hi - 1, lo - 1, -1):
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
-                run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
-        bucket.finish(average=True)
+                run_backward(lib, wl, sp, L, bucket.layer_done, rec, side=wside)   # all-reduce of finished layer groups overlaps the rest
+        bucket.finish(average=opt is None)           # join the all-reduces; the optimizer kernel averages (grad_scale)
         if opt is not None:
-            opt.step()
-            wl["work"].copy_(wl["master"])           # bf16 working copy read by the next forward
+            opt.step(grad_scale=1.0 / world, zero_grad=True)
 
     for i in range(args.warmup):
         step(i)
@@ -586,17 +620,22 @@ def main():
                 a_, b_, _ = per_shape.get(key, (0.0, 0, 0))
                 per_shape[key] = (a_ + ms, b_ + 1, u.algo[n])
             return tot, cnt, byt, per_shape
-        tot, cnt, byt, per_shape = collect(records.items)         # live: the timed steps (LIVE entry points)
+        sp_ = c_void_p(torch.cuda.current_stream().cuda_stream)
+        if not records.items:
+            # graph replay: nothing can be bracketed inside the timed region -> the dominant entry point is bracketed (every n-th
+            # launch, as in the live mode) in extra live passes right behind it, same buffers, same kernel sequence
+            for _ in range(min(args.steps, 3)):
+                run_forward(lib, wl, sp_, records)
+                run_backward(lib, wl, sp_, L, None, None)
+            torch.cuda.synchronize()
+        tot, cnt, byt, per_shape = collect(records.items)         # the dominant entry point (LIVE)
         # every entry point, in one extra untimed pass (full bracketing would perturb the timed region)
         extra = Recorder()
-        sp_ = c_void_p(torch.cuda.current_stream().cuda_stream)
         run_forward(lib, wl, sp_, extra)
         run_backward(lib, wl, sp_, L, None, extra)
         torch.cuda.synchronize()
         tot_x, cnt_x, byt_x, per_shape_x = collect(extra.items)
         live_items = records.items
-        if not live_items:                               # --graph: nothing was bracketed inside the timed region
-            tot, cnt, byt, live_items = tot_x, cnt_x, byt_x, extra.items
         table = {}
         for (n, label, di, dos), (ms, c_, nb) in sorted(per_shape_x.items()):
             avg = ms / c_

@@ -57,7 +57,7 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      300            /* 0.3.0 */
+#define MOKA_VERSION      400            /* 0.4.0 */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
@@ -200,6 +200,21 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
  * checker replay a dropout run exactly.  moka_dropout_scale returns 1/(1-p') (see moka_down_fwd). */
 int   moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in, uint8_t* keep_out, moka_stream_t stream);
 float moka_dropout_scale(float dropout_p);
+
+/* ---- data-parallel step on the flat adapter buffers ---------------------------------- */
+
+/* One pass over the flat fp32 adapter buffers (moka_amd/parallel.py: the gradients every weight-gradient kernel
+ * accumulated into, after the RCCL all-reduce): decoupled-weight-decay Adam exactly as torch.optim.AdamW
+ *     g = grad_scale * grad            (grad_scale = 1 / world_size averages the all-reduced sum)
+ *     p *= 1 - lr * weight_decay;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2
+ *     p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * plus, in the same pass, the bf16 working copy the next forward reads (work_bf16, may be NULL) and the zeroing of
+ * the gradient buffer for the next accumulation (zero_grad != 0).  Replaces the optimizer step + gradient zeroing the
+ * reference leaves to DeepSpeed ZeRO-2 / HF Trainer (VisualText/zero_stage2_config.json:2-10,
+ * AudioVisualText/trainer.py) for the adapter parameters.  step counts from 1.  Buffers 16-byte aligned. */
+int moka_adamw_flat(float* master, void* work_bf16, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    int zero_grad, moka_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@
 //   * Token routing is a wave-uniform decision per 16-token tile: a tile of one modality costs one
 //     MFMA chain; tiles straddling a span boundary run one chain per modality present and select.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -35,6 +36,13 @@
 #include <type_traits>
 
 #include "moka_hip.h"
+
+#ifndef ABL_XA
+#define ABL_XA 0
+#endif
+#ifndef ABL_GY
+#define ABL_GY 0
+#endif
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -450,10 +458,6 @@ static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t
     }
 }
 
-// Forward.  Block = 8 waves, RB (<= 32) token rows of one sample.  Latency structure: ONE batch of
-// global loads at kernel start (routing bytes, key-token indices, the block's partial rows), one
-// dependent batch (the key rows), then LDS-only work: one wave per query row, one lane per key.
-// Every block also transposes a slice of Bw into BwT (weights do not change until the backward).
 // Weight shadows for the backward (the weights do not change before it runs), written by dedicated blocks of
 // the cross_fwd launch so that they run beside the row blocks instead of lengthening some of them:
 // BwT[k][c] = Bw[c][k]   and   AT[m][c][k] = A_m[k][c]
@@ -494,44 +498,95 @@ static __device__ __forceinline__ void cross_weight_shadows(const CrossArgs& a, 
     }
 }
 
-template <int RP, int KCH, int NTH>
-__global__ void __launch_bounds__(NTH) moka_cross_fwd_kernel(const CrossBatch ab) {
-    constexpr int NWV = NTH / 64;
+// ---- MFMA form of the rank-space attention (v_mfma_f32_16x16x4_f32: fp32 operands, exact products) ----
+// Operand maps (verified on hardware, tools/microbench/f32probe.hip): A[m][k]: lane (m = l % 16, k = l / 16); B[k][n]: lane
+// (n = l % 16, k = l / 16); D[m][n]: lane (n = l % 16), register reg <-> m = 4 (l / 16) + reg.
+// A wave owns 16 rows of the block (q = l % 16).  Scores are formed TRANSPOSED, S^T[key][q] = sum_k K[key][k] Q[q][k]
+// (A = key rows, B = query rows), so a lane holds, for ITS query q, the keys 16 t + 4 g + reg of key tile t: the softmax
+// statistics of a query row are a reduction over the lane's registers and over the four 16-lane rows of the wave
+// (two v_permlane swaps), and the probabilities are, as they stand, the B operand of O^T[rank][q] = sum_key K[key][rank] P^T[key][q]
+// (the contraction step s' takes register s' of every lane, i.e. keys {4 g + s'}, and the A operand is read from LDS to match).
+// Keys are processed in chunks of 64 with a running max / sum (no bound on the question length: only one chunk lives in LDS).
+#define MFMA4F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// combine a per-lane value over the four 16-lane rows of the wave (every lane gets the result of its column l % 16)
+static __device__ __forceinline__ float rows_max(float v) {
+    u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+    s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+static __device__ __forceinline__ float rows_sum(float v) {
+    u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+    s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
+// Sum of the split-K slices of four consecutive rank-space values (one 16-byte load per slice, four slices in flight,
+// indices clamped so that no load is conditional).  Rows and key rows of the forward are summed by the same function,
+// so a key row equals the h row of its token bit for bit.
+static __device__ __forceinline__ f32x4 sum_slices4(const float* p, size_t stride, int ks) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ks; s += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 x = *(const f32x4*)(p + (size_t)min(s + j, ks - 1) * stride);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v[j] += (s + j < ks) ? x : z;
+        }
+    }
+    return (v[0] + v[1]) + (v[2] + v[3]);
+}
+
+template <int RP>
+static __device__ __forceinline__ void write_pack_tok(unsigned short* pack_tok, int t, int k, float v_scaled) {
+    unsigned short hi, lo;
+    split_hi_lo(v_scaled, hi, lo);
+    pack_tok[(size_t)t * (2 * RP) + k] = hi;
+    pack_tok[(size_t)t * (2 * RP) + RP + k] = lo;
+}
+
+// Forward.  Block = NWV waves on RB = 16 NWV consecutive token rows of one sample.  Latency structure: ONE batch of global
+// loads (routing bytes, the rows' split-K slices), one dependent batch (key token indices -> key rows), then LDS / MFMA work.
+// The blocks behind the row blocks write the weight shadows (cross_weight_shadows).
+template <int RP, int NWV>
+__global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBatch ab) {
+    constexpr int NTH = NWV * 64, RB = NWV * 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KP = RP + 1;
-    float* Hs = (float*)smem;                  // [32][KP]  h rows
-    float* Hp = Hs + 32 * KP;                  // [32][KP]  hp rows
-    float* Ks = Hp + 32 * KP;                  // [Lkp][KP]
-    int* Kt = (int*)(Ks + (size_t)a.Lkp * KP); // [Lkp] flat key token indices
-    __shared__ int s_mod[32];
+    float* Hs = (float*)smem;                  // [RB][KP]  h rows
+    float* Hp = Hs + RB * KP;                  // [RB][KP]  hp rows
+    float* Ks = Hp + RB * KP;                  // [KC][KP]  one chunk of key rows
+    __shared__ int s_mod[RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrb = (a.S + a.RB - 1) / a.RB;            // row blocks; the blocks behind them only write the weight shadows
+    const int i = lane & 15, g = lane >> 4;
+    const int nrb = (a.S + RB - 1) / RB;                // row blocks; the blocks behind them only write the weight shadows
     if ((int)blockIdx.y >= nrb) {
         cross_weight_shadows<RP>(a, ((int)blockIdx.y - nrb) * gridDim.x + blockIdx.x, ((int)gridDim.y - nrb) * gridDim.x, tid, NTH);
         return;
     }
-    const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
-    const int nrow = min(a.RB, a.S - r0);
+    const int b = blockIdx.x, r0 = blockIdx.y * RB;
+    const int nrow = min(RB, a.S - r0);
+    const size_t sstride = (size_t)a.T * RP;
     // ---- batch 1: everything that does not depend on other loads
-    const int klen_b = a.klen[b];
+    const int Lk = a.klen[b];
     int my_mod = MOKA_MOD_NONE;
     if (tid < nrow) my_mod = a.tok_mod[b * a.S + r0 + tid];
-    for (int j = tid; j < a.Lkp; j += NTH) Kt[j] = a.ktok[b * a.Lkp + j];
-    for (int e = tid; e < 32 * RP; e += NTH) {
-        const int row = e / RP, k = e % RP;
-        float v = 0.f;
-        if (row < nrow) {
-            const int t = b * a.S + r0 + row;
-            v = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);     // garbage for tokens of no modality
-        }
-        Hs[row * KP + k] = v;
+    for (int e = tid; e < RB * R4; e += NTH) {
+        const int row = e / R4, k4 = e % R4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nrow) v = sum_slices4(a.part + ((size_t)(b * a.S + r0 + row)) * RP + 4 * k4, sstride, a.ks);   // garbage for tokens of no modality
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Hs[row * KP + 4 * k4 + c] = v[c];
     }
-    if (tid < 32) s_mod[tid] = my_mod;
-    const int Lk = min(klen_b, a.Lk_max);
+    if (tid < RB) s_mod[tid] = my_mod;
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     // tokens of no modality: h = 0 (their partial rows were never written)
-    for (int e = tid; e < 32 * RP; e += NTH) {
+    for (int e = tid; e < RB * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         float v = Hs[row * KP + k];
         if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;
@@ -539,80 +594,77 @@ __global__ void __launch_bounds__(NTH) moka_cross_fwd_kernel(const CrossBatch ab
         Hp[row * KP + k] = v;
     }
     if (anyq) {
-        // ---- batch 2: the sample's key rows (indices are in LDS by now)
-        // two key elements per thread and round: their slice loads are in flight together (same sums, same order per element)
-        const int nk = Lk * RP;
-        const size_t sstride = (size_t)a.T * RP;
-        for (int e = tid; e < nk; e += 2 * NTH) {
-            const int e1 = e + NTH;
-            const int j0 = e / RP, k0 = e % RP;
-            const int j1 = min(e1, nk - 1) / RP, k1 = e1 % RP;
-            const int t0 = Kt[j0], t1 = Kt[j1];
-            const float* p0 = a.part + (size_t)max(t0, 0) * RP + k0;
-            const float* p1 = a.part + (size_t)max(t1, 0) * RP + k1;
-            float v0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < a.ks; s += 8) {
+        const int qrow = wave * 16 + i;                           // the lane's query row inside the block
+        const int mq = s_mod[qrow];
+        const bool isq = (mq != 0 && mq != MOKA_MOD_NONE);
+        const bool wq = __any(isq);                               // this wave's 16 rows contain query rows
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4 O[NT];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const size_t off = (size_t)min(s + q, a.ks - 1) * sstride;
-                    const float x0 = p0[off], x1 = p1[off];
-                    v0[q] += (s + q < a.ks) ? x0 : 0.f;
-                    v1[q] += (s + q < a.ks) ? x1 : 0.f;
-                }
+        for (int nt = 0; nt < NT; ++nt) O[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float qf[KS4];
+        const int nch = (Lk + KC - 1) / KC;
+        for (int c = 0; c < nch; ++c) {
+            if (c) __syncthreads();                               // everybody is done with the previous chunk
+            // ---- batch 2: the chunk's key rows (token index, then its slices)
+            for (int e = tid; e < KC * R4; e += NTH) {
+                const int jj = e / R4, k4 = e % R4;
+                const int j = c * KC + jj;
+                const int t = (j < Lk) ? a.ktok[b * a.Lkp + j] : -1;
+                f32x4 v = sum_slices4(a.part + (size_t)max(t, 0) * RP + 4 * k4, sstride, a.ks);
+                if (t < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};       // zero key row (still enters the softmax when j < Lk)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) Ks[jj * KP + 4 * k4 + cc] = v[cc];
             }
-            const float r0 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
-            const float r1 = ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
-            Ks[j0 * KP + k0] = (t0 >= 0) ? r0 : 0.f;
-            if (e1 < nk) Ks[j1 * KP + k1] = (t1 >= 0) ? r1 : 0.f;
-        }
-        __syncthreads();
-        for (int row = wave; row < nrow; row += NWV) {
-            const int m = s_mod[row];
-            if (m == 0 || m == MOKA_MOD_NONE) continue;           // wave uniform
-            float q[RP];
+            __syncthreads();
+            if (!wq) continue;                                    // wave uniform
+            if (c == 0) {
 #pragma unroll
-            for (int k = 0; k < RP; ++k) q[k] = Hs[row * KP + k];
-            float sc[KCH];
+                for (int ks = 0; ks < KS4; ++ks) qf[ks] = Hs[qrow * KP + 4 * ks + g];
+            }
+            f32x4 st[4];
             float mx = -INFINITY;
 #pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = lane + 64 * ch;
-                float s = -INFINITY;
-                if (j < Lk) {
-                    s = 0.f;
+            for (int t = 0; t < 4; ++t) {
+                st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < RP; ++k) s = fmaf(q[k], Ks[j * KP + k], s);
-                    s *= a.c;
-                }
-                sc[ch] = s;
-                mx = fmaxf(mx, s);
-            }
-            mx = wave_max(mx);
-            float l = 0.f;
+                for (int ks = 0; ks < KS4; ++ks) st[t] = MFMA4F(Ks[(16 * t + i) * KP + 4 * ks + g], qf[ks], st[t]);
 #pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = lane + 64 * ch;
-                sc[ch] = (j < Lk) ? __expf(sc[ch] - mx) : 0.f;
-                l += sc[ch];
-            }
-            l = wave_sum(l);
-            float o[RP];
-#pragma unroll
-            for (int k = 0; k < RP; ++k) o[k] = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = lane + 64 * ch;
-                if (j < Lk) {
-#pragma unroll
-                    for (int k = 0; k < RP; ++k) o[k] = fmaf(sc[ch], Ks[j * KP + k], o[k]);
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float sv = (c * KC + 16 * t + 4 * g + reg < Lk) ? st[t][reg] * a.c : -INFINITY;
+                    st[t][reg] = sv;
+                    mx = fmaxf(mx, sv);
                 }
             }
-            wave_sum_vec<RP>(o);
-            const float wl = a.w / l;
-            if (lane == 0) {
+            mx = rows_max(mx);
+            const float m_new = fmaxf(m_run, mx);                 // finite: every chunk holds at least one key
+            const float alpha = __expf(m_run - m_new);            // 0 on the first chunk
+            float ls = 0.f;
 #pragma unroll
-                for (int k = 0; k < RP; ++k) Hp[row * KP + k] = q[k] + wl * o[k];
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { const float pv = __expf(st[t][reg] - m_new); st[t][reg] = pv; ls += pv; }
+            ls = rows_sum(ls);
+            l_run = fmaf(l_run, alpha, ls);
+            m_run = m_new;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                O[nt] *= alpha;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp) O[nt] = MFMA4F(Ks[(16 * t + 4 * g + sp) * KP + 16 * nt + i], st[t][sp], O[nt]);
             }
+        }
+        if (wq && isq) {
+            const float wl = a.w / l_run;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = 16 * nt + 4 * g + reg;
+                    Hp[qrow * KP + k] = fmaf(wl, O[nt][reg], Hs[qrow * KP + k]);
+                }
         }
     }
     __syncthreads();
@@ -622,7 +674,19 @@ __global__ void __launch_bounds__(NTH) moka_cross_fwd_kernel(const CrossBatch ab
         const float hv = Hs[row * KP + k], hpv = Hp[row * KP + k];
         a.out_f32[(size_t)t * RP + k] = hv;
         if (a.out_f32b) a.out_f32b[(size_t)t * RP + k] = hpv;
-        write_packs_fwd<RP>(a, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
+        write_pack_tok<RP>(a.pack_tok, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
+    }
+    // rank-major pack: consecutive lanes <-> consecutive tokens (positions permuted inside a group of 32): coalesced 2-byte stores
+    for (int e = tid; e < RP * RB; e += NTH) {
+        const int k = e / RB, row = e % RB;
+        if (row < nrow) {
+            const int t = b * a.S + r0 + row;
+            unsigned short hi, lo;
+            split_hi_lo(Hp[row * KP + k] * mod_scale(a.s_mod, s_mod[row]), hi, lo);
+            const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
+            a.pack_kmj[((size_t)0 * RP + k) * a.Tp + pos] = hi;
+            a.pack_kmj[((size_t)1 * RP + k) * a.Tp + pos] = lo;
+        }
     }
     // pack tail [T, Tp): zero (the weight-gradient kernel reads whole groups of 32 tokens)
     if (b == a.B - 1 && blockIdx.y == nrb - 1) {
@@ -630,72 +694,50 @@ __global__ void __launch_bounds__(NTH) moka_cross_fwd_kernel(const CrossBatch ab
     }
 }
 
-// Backward, part a.  Same block shape and latency structure.  Query rows: recompute the softmax, dq,
-// and per-lane key/value gradients; the block's dK is combined in LDS and written to the block's own
-// partial slot.  Rows that are themselves key rows are finished by part b (their dq, if any, joins
-// their dK slot).
-template <int RP, int KCH, int NTH>
-__global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab) {
-    constexpr int NWV = NTH / 64;
+// Backward, part a.  Same block shape and latency structure (keys: rows of the saved h).  Per 16-row tile with query rows:
+//   pass 1 (all key chunks): S^T and dP^T = K dO^T (dO = w g) share the key operand; running max / sum / sum(p dP) give the
+//           softmax statistics m, l and D = sum_j P_j dP_j of every query row
+//   pass 2 (all key chunks): P^T, dS^T = P^T (dP^T - D) c, dq^T += K^T dS^T; the key gradient contracts over the QUERIES, so the
+//           same scores are formed a second time un-transposed (operands swapped: lane <-> key, registers <-> queries; the
+//           statistics of queries 4 g + reg come through a 16-entry LDS table) and dK^T[rank][key] += Q^T dS + dO^T P
+// The block's dK of a chunk is combined in LDS (one wave at a time) and written to the block's own partial slot; rows that are
+// themselves key rows are finished by part b (their dq, if any, joins their dK slot).
+template <int RP, int NWV>
+__global__ void __launch_bounds__(NWV * 64) moka_cross_bwd_kernel(const CrossBatch ab) {
+    constexpr int NTH = NWV * 64, RB = NWV * 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KP = RP + 1;
-    float* Gs = (float*)smem;                  // [32][KP]  g rows
-    float* Dh = Gs + 32 * KP;                  // [32][KP]  dh rows
-    float* Hs = Dh + 32 * KP;                  // [32][KP]  h rows (queries)
-    float* Ks = Hs + 32 * KP;                  // [Lkp][KP]
-    float* dKs = Ks + (size_t)a.Lkp * KP;      // [Lkp][KP]
-    int* Kt = (int*)(dKs + (size_t)a.Lkp * KP);// [Lkp]
-    __shared__ int s_mod[32], s_slot[32];
+    float* Gs = (float*)smem;                  // [RB][KP]  g rows
+    float* Dh = Gs + RB * KP;                  // [RB][KP]  dh rows
+    float* Hs = Dh + RB * KP;                  // [RB][KP]  h rows (queries)
+    float* Ks = Hs + RB * KP;                  // [KC][KP]
+    float* dKs = Ks + KC * KP;                 // [KC][KP]
+    float* stat = dKs + KC * KP;               // [NWV][16][4]  m, 1/l, D, is-query of the wave's rows
+    __shared__ int s_mod[RB], s_slot[RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, r0 = blockIdx.y * a.RB;
-    const int nrow = min(a.RB, a.S - r0);
+    const int i = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x, r0 = blockIdx.y * RB;
+    const int nrow = min(RB, a.S - r0);
+    const size_t sstride = (size_t)a.T * RP;
 
     // ---- batch 1
-    const int klen_b = a.klen[b];
+    const int Lk = a.klen[b];
     int my_mod = MOKA_MOD_NONE, my_slot = -1;
     if (tid < nrow) { my_mod = a.tok_mod[b * a.S + r0 + tid]; my_slot = a.kslot[b * a.S + r0 + tid]; }
-    for (int j = tid; j < a.Lkp; j += NTH) Kt[j] = a.ktok[b * a.Lkp + j];
-    // g rows = sum of the split-K slices (up to 22 for a 11008-wide gy): all 512 threads take part, the slices of
-    // one element are dealt round-robin to 512 / (RB * RP) thread groups, partial sums meet in LDS (Dh as scratch)
-    const int NE = a.RB * RP;                              // elements of the block
-    const bool split = (NE <= 256);
-    if (split) {
-        const int nsg = NTH / NE, sg = tid / NE, el = tid - sg * NE;
-        if (sg < nsg) {
-            const int row = el / RP, k = el % RP;
-            float v = 0.f;
-            if (row < nrow) v = sum_slices(a.part + ((size_t)(b * a.S + r0 + row)) * RP + k, (size_t)a.T * RP, a.ks, sg, nsg);
-            Dh[sg * NE + el] = v;                          // NE * nsg <= 512 <= 32 * KP floats
-        }
-    }
-    for (int e = tid; e < 32 * RP; e += NTH) {
-        const int row = e / RP, k = e % RP;
-        float v = 0.f, hv = 0.f;
+    for (int e = tid; e < RB * R4; e += NTH) {
+        const int row = e / R4, k4 = e % R4;
+        f32x4 gv = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f};
         if (row < nrow) {
-            const int t = b * a.S + r0 + row;
-            if (!split) v = sum_slices(a.part + (size_t)t * RP + k, (size_t)a.T * RP, a.ks, 0, 1);
-            hv = a.hfull[(size_t)t * RP + k];
+            const size_t off = ((size_t)(b * a.S + r0 + row)) * RP + 4 * k4;
+            gv = sum_slices4(a.part + off, sstride, a.ks);
+            hv = *(const f32x4*)(a.hfull + off);
         }
-        if (!split) Gs[row * KP + k] = v;
-        Hs[row * KP + k] = hv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { Gs[row * KP + 4 * k4 + c] = gv[c]; Hs[row * KP + 4 * k4 + c] = hv[c]; }
     }
-    if (tid < 32) { s_mod[tid] = my_mod; s_slot[tid] = my_slot; }
-    const int Lk = min(klen_b, a.Lk_max);
+    if (tid < RB) { s_mod[tid] = my_mod; s_slot[tid] = my_slot; }
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
-    if (split) {
-        const int nsg = NTH / NE;
-        for (int e = tid; e < 32 * RP; e += NTH) {
-            const int row = e / RP, k = e % RP;
-            float v = 0.f;
-            if (row < a.RB) {
-                for (int q = 0; q < nsg; ++q) v += Dh[q * NE + row * RP + k];
-            }
-            Gs[row * KP + k] = v;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < 32 * RP; e += NTH) {
+    for (int e = tid; e < RB * RP; e += NTH) {
         const int row = e / RP, k = e % RP;
         float v = Gs[row * KP + k];
         if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;   // unwritten partial rows
@@ -703,122 +745,178 @@ __global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab
         Dh[row * KP + k] = v;
     }
     if (anyq) {
-        // ---- batch 2: key rows of h
-        // four elements per thread and round, loads unconditional (clamped): one memory round trip for the usual 64 keys x 16 ranks
-        const int nk = Lk * RP;
-        for (int e0 = tid; e0 < nk; e0 += 4 * NTH) {
-            float v[4];
-            int tt[4];
+        const int qrow = wave * 16 + i;
+        const int mq = s_mod[qrow];
+        const bool isq = (mq != 0 && mq != MOKA_MOD_NONE);
+        const bool wq = __any(isq);
+        const int nch = (Lk + KC - 1) / KC;
+        auto load_keys = [&](int c) {                             // key rows of chunk c: rows of the saved h
+            for (int e = tid; e < KC * R4; e += NTH) {
+                const int jj = e / R4, k4 = e % R4;
+                const int j = c * KC + jj;
+                const int t = (j < Lk) ? a.ktok[b * a.Lkp + j] : -1;
+                f32x4 v = *(const f32x4*)(a.hfull + (size_t)max(t, 0) * RP + 4 * k4);
+                if (t < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u * NTH, nk - 1);
-                tt[u] = Kt[e / RP];
-                v[u] = a.hfull[(size_t)max(tt[u], 0) * RP + (e % RP)];
+                for (int cc = 0; cc < 4; ++cc) { Ks[jj * KP + 4 * k4 + cc] = v[cc]; dKs[jj * KP + 4 * k4 + cc] = 0.f; }
             }
+        };
+        float qf[KS4], dof[KS4];                                  // query row / its upstream gradient, as MFMA fragments
+        f32x4 st[4], dpt[4];                                      // S^T (scaled, masked) and dP^T of the current chunk
+        auto scores = [&](int c) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * NTH;
-                if (e < nk) {
-                    Ks[(e / RP) * KP + (e % RP)] = (tt[u] >= 0) ? v[u] : 0.f;
-                    dKs[(e / RP) * KP + (e % RP)] = 0.f;
+            for (int t = 0; t < 4; ++t) {
+                st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS4; ++ks) {
+                    const float kf = Ks[(16 * t + i) * KP + 4 * ks + g];
+                    st[t] = MFMA4F(kf, qf[ks], st[t]);
+                    dpt[t] = MFMA4F(kf, dof[ks], dpt[t]);
                 }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    st[t][reg] = (c * KC + 16 * t + 4 * g + reg < Lk) ? st[t][reg] * a.c : -INFINITY;
             }
-        }
-        __syncthreads();
-        float dK[KCH][RP];
+        };
+        // ---- pass 1: softmax statistics of my query row
+        float m_run = -INFINITY, l_run = 0.f, n_run = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            if (c) __syncthreads();
+            load_keys(c);
+            __syncthreads();
+            if (!wq) continue;
+            if (c == 0) {
 #pragma unroll
-        for (int ch = 0; ch < KCH; ++ch)
-#pragma unroll
-            for (int k = 0; k < RP; ++k) dK[ch][k] = 0.f;
-        for (int row = wave; row < nrow; row += NWV) {
-            const int m = s_mod[row];
-            if (m == 0 || m == MOKA_MOD_NONE) continue;
-            // the query row and its upstream gradient: per-lane register copies for the narrow ranks; for rank pad 64 they stay
-            // in LDS and are read as broadcasts inside the k loops (two RP-long arrays less per lane: no scratch at KCH <= 2)
-            constexpr bool QLDS = (RP == 64);
-            const float* qrow = Hs + row * KP;
-            const float* grow = Gs + row * KP;
-            float q[QLDS ? 1 : RP], dO[QLDS ? 1 : RP];
-            if (!QLDS) {
-#pragma unroll
-                for (int k = 0; k < RP; ++k) { q[k] = qrow[k]; dO[k] = a.w * grow[k]; }
+                for (int ks = 0; ks < KS4; ++ks) { qf[ks] = Hs[qrow * KP + 4 * ks + g]; dof[ks] = a.w * Gs[qrow * KP + 4 * ks + g]; }
             }
-            auto Q = [&](int k) { return QLDS ? qrow[k] : q[k]; };
-            auto DO = [&](int k) { return QLDS ? a.w * grow[k] : dO[k]; };
-            float p[KCH], dP[KCH];
+            scores(c);
             float mx = -INFINITY;
 #pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = lane + 64 * ch;
-                float s = -INFINITY, d = 0.f;
-                if (j < Lk) {
-                    s = 0.f;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int k = 0; k < RP; ++k) { s = fmaf(Q(k), Ks[j * KP + k], s); d = fmaf(DO(k), Ks[j * KP + k], d); }
-                    s *= a.c;
-                }
-                p[ch] = s; dP[ch] = d;
-                mx = fmaxf(mx, s);
-            }
-            mx = wave_max(mx);
-            float l = 0.f;
+                for (int reg = 0; reg < 4; ++reg) mx = fmaxf(mx, st[t][reg]);
+            mx = rows_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float ls = 0.f, ns = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = lane + 64 * ch;
-                p[ch] = (j < Lk) ? __expf(p[ch] - mx) : 0.f;
-                l += p[ch];
-            }
-            l = wave_sum(l);
-            const float inv_l = 1.f / l;
-            float D = 0.f;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) { p[ch] *= inv_l; D = fmaf(p[ch], dP[ch], D); }
-            D = wave_sum(D);
-            float dq[RP];
-#pragma unroll
-            for (int k = 0; k < RP; ++k) dq[k] = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = lane + 64 * ch;
-                if (j < Lk) {
-                    const float dS = p[ch] * (dP[ch] - D) * a.c;     // c folded in: both uses carry it
-#pragma unroll
-                    for (int k = 0; k < RP; ++k) {
-                        dq[k] = fmaf(dS, Ks[j * KP + k], dq[k]);
-                        dK[ch][k] = fmaf(p[ch], DO(k), fmaf(dS, Q(k), dK[ch][k]));
-                    }
-                }
-            }
-            wave_sum_vec<RP>(dq);
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < RP; ++k) Dh[row * KP + k] = Gs[row * KP + k] + dq[k];
-            }
+                for (int reg = 0; reg < 4; ++reg) { const float pv = __expf(st[t][reg] - m_new); ls += pv; ns = fmaf(pv, dpt[t][reg], ns); }
+            ls = rows_sum(ls);
+            ns = rows_sum(ns);
+            l_run = fmaf(l_run, alpha, ls);
+            n_run = fmaf(n_run, alpha, ns);
+            m_run = m_new;
         }
-        // combine the 8 waves' key/value gradients: one wave at a time, plain LDS read-modify-write
-        // (measured: LDS fp32 atomics cost ~700 cycles per wave instruction under 8-wave contention)
-        for (int w = 0; w < NWV; ++w) {
-            if (wave == w) {
+        const float inv_l = 1.f / l_run, Dq = n_run * inv_l;
+        if (wq && g == 0) {
+            float* sp = stat + (wave * 16 + i) * 4;
+            sp[0] = m_run; sp[1] = inv_l; sp[2] = Dq; sp[3] = isq ? 1.f : 0.f;
+        }
+        // ---- pass 2: dq, dK chunk by chunk
+        f32x4 dq[NT];
 #pragma unroll
-                for (int ch = 0; ch < KCH; ++ch) {
-                    const int j = lane + 64 * ch;
-                    if (j < Lk) {
+        for (int nt = 0; nt < NT; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nch; ++c) {
+            if (nch > 1) {                                        // (one chunk: keys, scores and dP^T are still in place)
+                __syncthreads();
+                load_keys(c);
+                __syncthreads();
+                if (wq) scores(c);
+            }
+            f32x4 dK[NT][4];
+            if (wq) {
+                // P^T and dS^T (in place of S^T / dP^T); rows of the tile that are no query rows contribute nothing
 #pragma unroll
-                        for (int k = 0; k < RP; ++k) dKs[j * KP + k] += dK[ch][k];
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float pv = isq ? __expf(st[t][reg] - m_run) * inv_l : 0.f;
+                        dpt[t][reg] = pv * (dpt[t][reg] - Dq) * a.c;          // c folded in: both uses carry it
+                        st[t][reg] = pv;
                     }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int sp = 0; sp < 4; ++sp) dq[nt] = MFMA4F(Ks[(16 * t + 4 * g + sp) * KP + 16 * nt + i], dpt[t][sp], dq[nt]);
+                // the same quantities with lane <-> key (16 t + i), registers <-> queries 4 g + reg
+                float mS[4], ilS[4], dS_[4], qS[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float* sp = stat + (wave * 16 + 4 * g + reg) * 4;     // written by this wave (program order + lgkmcnt)
+                    mS[reg] = sp[0]; ilS[reg] = sp[1]; dS_[reg] = sp[2]; qS[reg] = sp[3];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dK[nt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 sq = {0.f, 0.f, 0.f, 0.f}, dpq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS4; ++ks) {
+                        const float kf = Ks[(16 * t + i) * KP + 4 * ks + g];
+                        sq = MFMA4F(qf[ks], kf, sq);
+                        dpq = MFMA4F(dof[ks], kf, dpq);
+                    }
+                    const bool kvalid = c * KC + 16 * t + i < Lk;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float pv = (kvalid && qS[reg] != 0.f) ? __expf(sq[reg] * a.c - mS[reg]) * ilS[reg] : 0.f;
+                        dpq[reg] = pv * (dpq[reg] - dS_[reg]) * a.c;
+                        sq[reg] = pv;
+                    }
+                    // dK^T[rank][key] += sum_q Q[q][rank] dS[q][key] + dO[q][rank] P[q][key]   (contraction step s' <-> queries 4 g + s')
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int sp = 0; sp < 4; ++sp) {
+                            const int qr = (wave * 16 + 4 * g + sp) * KP + 16 * nt + i;
+                            dK[nt][t] = MFMA4F(Hs[qr], dpq[sp], dK[nt][t]);
+                            dK[nt][t] = MFMA4F(a.w * Gs[qr], sq[sp], dK[nt][t]);
+                        }
                 }
             }
-            __syncthreads();
+            // combine the waves' key gradients of this chunk: one wave at a time, plain LDS read-modify-write
+            // (D^T tile: lane <-> key 16 t + i, registers <-> ranks 16 nt + 4 g + reg)
+            for (int w = 0; w < NWV; ++w) {
+                if (wave == w && wq) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) dKs[(16 * t + i) * KP + 16 * nt + 4 * g + reg] += dK[nt][t][reg];
+                }
+                __syncthreads();
+            }
+            const int nk = min(KC, Lk - c * KC);
+            float* dst = a.dk_part + (((size_t)b * gridDim.y + blockIdx.y) * a.Lkp + (size_t)c * KC) * RP;
+            for (int e = tid; e < nk * RP; e += NTH) dst[e] = dKs[(e / RP) * KP + (e % RP)];
         }
-        // a key row that is also a query row (masks may overlap in VT): its dq joins its own dK slot
+        if (wq && isq) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = 16 * nt + 4 * g + reg;
+                    Dh[qrow * KP + k] = Gs[qrow * KP + k] + dq[nt][reg];
+                }
+        }
+        __syncthreads();
+        // a key row that is also a query row (masks may overlap in VT): its dq joins its own dK slot (this block's partial)
         for (int e = tid; e < nrow * RP; e += NTH) {
             const int row = e / RP, k = e % RP;
             const int slot = s_slot[row];
-            if (slot >= 0) dKs[slot * KP + k] += Dh[row * KP + k] - Gs[row * KP + k];
+            if (slot >= 0 && slot < Lk) {
+                float* dst = a.dk_part + (((size_t)b * gridDim.y + blockIdx.y) * a.Lkp + slot) * RP + k;
+                *dst += Dh[row * KP + k] - Gs[row * KP + k];
+            }
         }
-        __syncthreads();
-        float* dst = a.dk_part + ((size_t)b * gridDim.y + blockIdx.y) * a.Lkp * RP;
-        for (int e = tid; e < Lk * RP; e += NTH) dst[e] = dKs[(e / RP) * KP + (e % RP)];
     } else {
         __syncthreads();
     }
@@ -830,7 +928,25 @@ __global__ void __launch_bounds__(NTH) moka_cross_bwd_kernel(const CrossBatch ab
         const int m = s_mod[row];
         const float dv = Dh[row * KP + k];
         if (a.out_f32) a.out_f32[(size_t)t * RP + k] = dv;
-        write_packs_bwd<RP>(a, t, k, m, (m == MOKA_MOD_NONE) ? 0.f : dv * a.s_mod[0]);
+        write_pack_tok<RP>(a.pack_tok, t, k, (m == MOKA_MOD_NONE) ? 0.f : dv * a.s_mod[0]);
+    }
+    // rank-major masked planes: consecutive lanes <-> consecutive tokens
+    for (int e = tid; e < RP * RB; e += NTH) {
+        const int k = e / RB, row = e % RB;
+        if (row < nrow && s_slot[row] < 0) {
+            const int t = b * a.S + r0 + row;
+            const int m = s_mod[row];
+            unsigned short hi, lo;
+            split_hi_lo((m == MOKA_MOD_NONE) ? 0.f : Dh[row * KP + k] * a.s_mod[0], hi, lo);
+            const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
+#pragma unroll
+            for (int mm = 0; mm < MOKA_MAX_MOD; ++mm) {
+                if (mm < a.M) {
+                    a.pack_kmj[(((size_t)mm * 2 + 0) * RP + k) * a.Tp + pos] = (mm == m) ? hi : (unsigned short)0;
+                    a.pack_kmj[(((size_t)mm * 2 + 1) * RP + k) * a.Tp + pos] = (mm == m) ? lo : (unsigned short)0;
+                }
+            }
+        }
     }
     if (b == a.B - 1 && blockIdx.y == gridDim.y - 1) {
         for (int e = tid; e < (a.Tp - a.T) * RP; e += NTH) write_packs_bwd<RP>(a, a.T + e / RP, e % RP, MOKA_MOD_NONE, 0.f);
@@ -1326,6 +1442,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     const int per_wave = (grp_end - grp_begin + NW - 1) / NW;
     int grp = grp_begin + wave * per_wave;
     const int wend = min(grp_end, grp + per_wave);
+    const int wlast = max(wend - 1, grp);             // the prefetch behind my last group re-requests that group (L2 hit), not the next wave's first
     auto routing_of = [&](int gq) -> int {                       // tok_mod is padded past T: the load itself is unconditional
         const int v = a.tok_mod[(min(gq, grp_last + 1) << 5) + (lane & 31)];
         return (gq < wend) ? v : MOKA_MOD_NONE;
@@ -1342,14 +1459,14 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
         int mym_nn = routing_of(grp + 2);
         unsigned pres_nxt = present_of(mym_nxt);
         second_pack(grp, pres_cur);
-        issue(ldB, bhB, blB, grp + 1, pres_nxt);
+        issue(ldB, bhB, blB, min(grp + 1, wlast), pres_nxt);
         if (pres_cur) compute(ldA, bhA, blA, bhx, blx, grp, pres_cur);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
         if (grp >= wend) break;
         mym_nn = routing_of(grp + 2);
         pres_nxt = present_of(mym_nxt);
         second_pack(grp, pres_cur);
-        issue(ldA, bhA, blA, grp + 1, pres_nxt);
+        issue(ldA, bhA, blA, min(grp + 1, wlast), pres_nxt);
         if (pres_cur) compute(ldB, bhB, blB, bhx, blx, grp, pres_cur);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
     }
@@ -1472,8 +1589,10 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
 
     const int grp_last = ngroups - 1;
     // F[st][kk]: rows 16st + i of the group, columns c0 + 32kk + 8g .. +7   (unconditional, clamped)
+    // (the prefetch behind the block's last group is clamped to that group: its lines were requested a moment ago, so the
+    //  unconditional load costs an L2 hit -- not a second HBM read of the NEXT block's first group, which was 1/NG of the traffic)
     auto issue = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp_) {
-        const int grp = min(grp_, grp_last);
+        const int grp = min(min(grp_, grp0 + NG - 1), grp_last);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const size_t rowoff = (size_t)min((grp << 5) + 16 * st + i, a.T - 1) * a.C;
@@ -1498,6 +1617,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) accW[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float abl_sink = 0.f;
     auto compute = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int gi) {
         const int grp = grp0 + gi;
         const bool live = wactive && grp < ngroups;      // wave uniform
@@ -1513,12 +1633,16 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
                     accR = MFMA16(F[st][0], bwt[0][nt], accR);
                     accR = MFMA16((c0 + 32 < a.C) ? F[st][1] : z8r, bwt[1][nt], accR);   // branch-free, see moka_xa_kernel
                 }
+#if ABL_GY & 2
+                abl_sink += accR[0] + accR[1] + accR[2] + accR[3];
+#else
                 MFMA_SETTLE(accR);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = accR[reg];
+#endif
             }
         // ---- dB: transposed tile through the wave-private LDS region
-        if (WITH_DB && live) {
+        if (WITH_DB && live && !(ABL_GY & 4)) {
             const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -1541,6 +1665,9 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     };
     // sum the eight waves' slots of one phase (PH groups) and write the split-K slice rows
     auto reduce_phase = [&](int phase) {
+#if ABL_GY & 1
+        return;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int e = tid; e < PH * RSLOT; e += 512) {
             float sum = 0.f;
@@ -1568,7 +1695,10 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
         else reduce_phase(gi / 2);
     }
 
-    if (WITH_DB) {
+#if ABL_GY
+    if (abl_sink == 1234.5f) slice[tid] = abl_sink;
+#endif
+    if (WITH_DB && !(ABL_GY & 8)) {
         // dB leaves as [column][rank] rows: wave w's accumulators hold columns cb0 + 64w .. of it, the destination rows of the waves
         // are disjoint, so there is no cross-wave sum -- only a wave-private transposition through LDS (own tile region for RP = 16,
         // own slot area -- free after the last reduce_phase barrier -- for the wider ranks, CTB column tiles at a time)
@@ -1644,7 +1774,7 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
 
     const int grp_last = ngroups - 1;
     auto issue = [&](bf16x8 (&F)[2][2], int (&mr)[2], int grp_) {
-        const int grp = min(grp_, grp_last);
+        const int grp = min(min(grp_, grp0 + NG - 1), grp_last);     // never the next block's data (see moka_gy_kernel)
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int t = (grp << 5) + 16 * st + i;
@@ -1657,8 +1787,13 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
             }
         }
     };
+    float abl_sink = 0.f;
     auto compute = [&](bf16x8 (&F)[2][2], int (&mr)[2], int gi_, int ph_) {
         const int grp = grp0 + gi_;
+#if ABL_XA >= 3
+        { union { bf16x8 b; float f[4]; } u0, u1, u2, u3; u0.b = F[0][0]; u1.b = F[0][1]; u2.b = F[1][0]; u3.b = F[1][1];
+          abl_sink += u0.f[0] + u0.f[3] + u1.f[0] + u1.f[3] + u2.f[0] + u2.f[3] + u3.f[0] + u3.f[3] + (float)mr[0] + (float)mr[1]; return; }
+#endif
         const bool live = wactive && grp < ngroups;
         const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1700,14 +1835,21 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+#if ABL_XA >= 2
+                    abl_sink += acc[nt][0] + acc[nt][1] + acc[nt][2] + acc[nt][3];
+#else
                     MFMA_SETTLE(acc[nt]);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = acc[nt][reg];
+#endif
                 }
             }
         }
     };
     auto reduce_phase = [&](int phase) {
+#if ABL_XA >= 1
+        return;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
@@ -1741,6 +1883,9 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
         compute(FB, mrB, gi_ + 1, 1);
         reduce_phase(gi_ / 2);
     }
+#if ABL_XA >= 1
+    if (abl_sink == 1234.5f) a.part[0][tid] = abl_sink;
+#endif
 }
 
 // Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
@@ -1750,6 +1895,56 @@ __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int 
         const KeepMask keep = drop_keep8(d, (unsigned)idx);
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[idx * 8 + e] = drop_kept(keep, e) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// O: the data-parallel step on the flat adapter buffers (moka_amd/parallel.py): one pass does what the reference's
+// ZeRO-2 step spreads over several (gradient averaging, AdamW, bf16 working copy, gradient zeroing)
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float* master; unsigned short* work; float* grad; float* m; float* v;
+    size_t n;
+    float lr, beta1, beta2, eps, decay;      // decay = 1 - lr * weight_decay
+    float step_size, inv_bc2_sqrt;           // lr / (1 - beta1^t),  1 / sqrt(1 - beta2^t)
+    float grad_scale;
+    int zero_grad;
+};
+
+// 34 bytes of HBM traffic per parameter (p, g, m, v read; p, m, v, bf16 copy, zeroed g written), 16 bytes per lane and access.
+__global__ void __launch_bounds__(256) moka_adamw_kernel(const AdamArgs a) {
+    const size_t n4 = a.n >> 2;
+    const size_t stride = (size_t)gridDim.x * 256;
+    auto upd = [&](float p, float g, float& m, float& v) -> float {
+        g *= a.grad_scale;
+        p *= a.decay;
+        m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
+        v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+        const float denom = fmaf(sqrtf(v), a.inv_bc2_sqrt, a.eps);
+        return p - a.step_size * (m / denom);
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 p = ((const f32x4*)a.master)[i], g = ((const f32x4*)a.grad)[i];
+        f32x4 m = ((const f32x4*)a.m)[i], v = ((const f32x4*)a.v)[i], q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float me = m[e], ve = v[e];
+            q[e] = upd(p[e], g[e], me, ve);
+            m[e] = me; v[e] = ve;
+        }
+        ((f32x4*)a.master)[i] = q;
+        ((f32x4*)a.m)[i] = m;
+        ((f32x4*)a.v)[i] = v;
+        if (a.work) ((uint2*)a.work)[i] = make_uint2(f2bf_pk(q[0], q[1]), f2bf_pk(q[2], q[3]));
+        if (a.zero_grad) ((f32x4*)a.grad)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {       // tail of a length that is not a multiple of 4
+        const size_t i = (n4 << 2) + threadIdx.x;
+        float m = a.m[i], v = a.v[i];
+        const float q = upd(a.master[i], a.grad[i], m, v);
+        a.master[i] = q; a.m[i] = m; a.v[i] = v;
+        if (a.work) a.work[i] = f2bf(q);
+        if (a.zero_grad) a.grad[i] = 0.f;
     }
 }
 
@@ -1837,13 +2032,6 @@ static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs*
     return MOKA_OK;
 }
 
-// rows per block (measured at T = 8192, Lk = 64): 8 for r <= 16; the wider ranks re-sum the sample's key rows from the split-K
-// slices in every block, so longer blocks pay (RP = 64 forward 33 -> 26 us, RP = 32 backward 29 -> 23 us)
-static int cross_rows_per_block(int RP, bool bwd) {
-    if (g_tune_cross_rows >= 8 && g_tune_cross_rows <= 32) return g_tune_cross_rows;
-    return ((RP == 64 && !bwd) || (RP == 32 && bwd)) ? 16 : 8;
-}
-
 static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     if (dtype != MOKA_BF16) return fail(MOKA_EDTYPE, "%s: only bf16 storage is implemented (dtype=%d)", fn, dtype);
     if (T < 1) return fail(MOKA_EINVAL, "%s: T=%d", fn, T);
@@ -1878,35 +2066,28 @@ static int launch_reduce(const ReduceArgs& a, int RP, int /*G*/, int nz, hipStre
     return check_launch("moka_reduce_kernel");
 }
 
-template <int RP, int KCH, int NTH>
-static void launch_cross_t2(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
+template <int RP>
+static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
+    constexpr int NWV = 4, RB = 16 * NWV, KC = 64, KP = RP + 1;
     const CrossArgs& a = ab.z[0];
-    dim3 grid(a.B, (a.S + a.RB - 1) / a.RB, nz), block(NTH);
+    dim3 grid(a.B, (a.S + RB - 1) / RB, nz), block(NWV * 64);
     if (!bwd) {
-        const size_t lds = (size_t)(64 + a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
-        ensure_lds((const void*)moka_cross_fwd_kernel<RP, KCH, NTH>, lds);
+        const size_t lds = (size_t)(2 * RB + KC) * KP * 4;
+        ensure_lds((const void*)moka_cross_fwd_kernel<RP, NWV>, lds);
         // + blocks that write the weight shadows (one thread per BwT column / AT row)
         long items = 0;
         for (int z = 0; z < nz; ++z) {
             const long it = (ab.z[z].BwT ? ab.z[z].C : 0) > (ab.z[z].AT ? (long)ab.z[z].M * ab.z[z].Cin : 0) ? ab.z[z].C : (ab.z[z].AT ? (long)ab.z[z].M * ab.z[z].Cin : 0);
             items = it > items ? it : items;
         }
-        dim3 gridf(grid.x, grid.y + (unsigned)((items + (long)NTH * a.B - 1) / ((long)NTH * a.B)), nz);
-        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, KCH, NTH>), gridf, block, lds, st, ab);
+        dim3 gridf(grid.x, grid.y + (unsigned)((items + (long)block.x * a.B - 1) / ((long)block.x * a.B)), nz);
+        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, NWV>), gridf, block, lds, st, ab);
     } else {
-        const size_t lds = (size_t)(96 + 2 * a.Lkp) * (RP + 1) * 4 + (size_t)a.Lkp * 4;
-        ensure_lds((const void*)moka_cross_bwd_kernel<RP, KCH, NTH>, lds);
-        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, KCH, NTH>), grid, block, lds, st, ab);
+        const size_t lds = (size_t)(3 * RB + 2 * KC) * KP * 4 + (size_t)NWV * 16 * 4 * 4;
+        ensure_lds((const void*)moka_cross_bwd_kernel<RP, NWV>, lds);
+        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, NWV>), grid, block, lds, st, ab);
         hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16, nz), dim3(256), (size_t)grid.y * 4, st, ab, (int)grid.y);
     }
-}
-
-// 4-wave blocks: the blocks are latency- not throughput-bound, so twice as many of them per CU halve the number of
-// rounds (the common r <= 16 / Lk <= 64 case; the wider variants keep 8 waves for their register budget)
-template <int RP, int KCH>
-static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
-    if (RP == 16 && KCH == 1 && g_tune_cross_nth != 512 && (bwd || nz > 1 || g_tune_cross_nth == 256)) launch_cross_t2<RP, KCH, (RP == 16 && KCH == 1) ? 256 : 512>(bwd, ab, nz, st);
-    else launch_cross_t2<RP, KCH, 512>(bwd, ab, nz, st);
 }
 
 // fills the routing fields of every problem and launches the batch
@@ -1918,30 +2099,21 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
     if (rt->B < 1 || rt->S < 1) return fail(MOKA_EINVAL, "%s: B=%d S=%d", fn, rt->B, rt->S);
     if (!rt->tok_mod || !rt->klen || !rt->ktok || !rt->kslot) return fail(MOKA_EINVAL, "%s: null routing pointer", fn);
     const int Lk = rt->Lk_max;
-    if (Lk < 0 || Lk > 512) return fail(MOKA_EINVAL, "%s: Lk_max=%d not in 0..512", fn, Lk);
-    const int kch = Lk <= 64 ? 1 : (Lk <= 128 ? 2 : (Lk <= 256 ? 4 : 8));
-    // (kch * RP > 128: the per-lane key-gradient arrays of the backward no longer fit the register file and live in scratch -- the
-    //  rare long-question case is correct but slow; rank pad 64 ends at the LDS bound below, Lk_max <= 247)
+    if (Lk < 0) return fail(MOKA_EINVAL, "%s: Lk_max=%d", fn, Lk);
     for (int z = 0; z < nz; ++z) {
         CrossArgs& a = ab.z[z];
         if (a.ks < 1) return fail(MOKA_EINVAL, "%s: ks=%d", fn, a.ks);
+        if (((uintptr_t)a.part | (uintptr_t)a.hfull) & 15) return fail(MOKA_EINVAL, "%s: rank-space buffers must be 16-byte aligned", fn);
         a.tok_mod = rt->tok_mod; a.ktok = rt->ktok; a.klen = rt->klen; a.kslot = rt->kslot;
         a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
         a.r = r; a.M = rt->M;
-        a.RB = cross_rows_per_block(RP, bwd);
+        a.RB = 64;
     }
-    if ((size_t)(96 + 2 * ab.z[0].Lkp) * (RP + 1) * 4 + (size_t)ab.z[0].Lkp * 4 > 150 * 1024)
-        return fail(MOKA_EINVAL, "%s: Lk_max=%d key rows of rank pad %d do not fit LDS (limits: 512 keys for r <= 32, 247 for r <= 64)", fn, Lk, RP);
-    if (RP == 16) {
-        if (kch == 1) launch_cross_t<16, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<16, 2>(bwd, ab, nz, st);
-        else if (kch == 4) launch_cross_t<16, 4>(bwd, ab, nz, st); else launch_cross_t<16, 8>(bwd, ab, nz, st);
-    } else if (RP == 32) {
-        if (kch == 1) launch_cross_t<32, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<32, 2>(bwd, ab, nz, st);
-        else if (kch == 4) launch_cross_t<32, 4>(bwd, ab, nz, st); else launch_cross_t<32, 8>(bwd, ab, nz, st);
-    } else {
-        if (kch == 1) launch_cross_t<64, 1>(bwd, ab, nz, st); else if (kch == 2) launch_cross_t<64, 2>(bwd, ab, nz, st);
-        else launch_cross_t<64, 4>(bwd, ab, nz, st);
-    }
+    // (the question span is unbounded, as in the reference -- layer.py:640-653, lora.py:489-499: keys are streamed through LDS in
+    //  chunks of 64 with a running softmax; only the caller's workspace grows with Lk_max, moka_cross_ws_bytes)
+    if (RP == 16) launch_cross_t<16>(bwd, ab, nz, st);
+    else if (RP == 32) launch_cross_t<32>(bwd, ab, nz, st);
+    else launch_cross_t<64>(bwd, ab, nz, st);
     return check_launch(fn);
 }
 
@@ -2469,6 +2641,29 @@ int moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in,
     if (!drop.thr) return (hipMemsetAsync(keep_out, 1, (size_t)T * d_in, (hipStream_t)stream) == hipSuccess) ? MOKA_OK : fail(MOKA_ELAUNCH, "memset");
     hipLaunchKernelGGL(moka_dropout_mask_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, drop, T, d_in, keep_out);
     return check_launch("moka_dropout_mask_kernel");
+}
+
+int moka_adamw_flat(float* master, void* work_bf16, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    int zero_grad, moka_stream_t stream) {
+    if (!master || !grad || !exp_avg || !exp_avg_sq) return fail(MOKA_EINVAL, "moka_adamw_flat: null pointer");
+    if (n == 0) return MOKA_OK;
+    if (step < 1) return fail(MOKA_EINVAL, "moka_adamw_flat: step=%d (the first step is 1)", step);
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) return fail(MOKA_EINVAL, "moka_adamw_flat: betas (%g, %g) not in [0, 1)", (double)beta1, (double)beta2);
+    if ((((uintptr_t)master | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) || ((uintptr_t)work_bf16 & 7))
+        return fail(MOKA_EINVAL, "moka_adamw_flat: buffers must be 16-byte aligned (bf16 copy: 8)");
+    AdamArgs a;
+    a.master = master; a.work = (unsigned short*)work_bf16; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.decay = 1.f - lr * weight_decay;
+    a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+    size_t blocks = ((n >> 2) + 255) / 256;
+    const size_t cap = (size_t)num_cu() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(moka_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("moka_adamw_kernel");
 }
 
 float moka_dropout_scale(float dropout_p) {
