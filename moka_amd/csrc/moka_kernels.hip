@@ -428,6 +428,7 @@ struct CrossArgs {
     float s_mod[4];                 // fwd: s_out per modality; bwd: s_in for every modality
     int ks, B, S, T, Tp, Lk_max, Lkp, r, C, M, RB;
     float w, c;
+    int abl;                        // diagnostics (moka_tune cross_abl): truncate the kernel after a phase
 };
 // blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems on the same routing (batched launch)
 struct CrossBatch { CrossArgs z[MOKA_MAX_GROUP]; };
@@ -524,22 +525,46 @@ static __device__ __forceinline__ float rows_sum(float v) {
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-// Sum of the split-K slices of four consecutive rank-space values (one 16-byte load per slice, four slices in flight,
-// indices clamped so that no load is conditional).  Rows and key rows of the forward are summed by the same function,
-// so a key row equals the h row of its token bit for bit.
+// Sum of the split-K slices of four consecutive rank-space values (one 16-byte load per slice, eight slices in flight,
+// indices clamped so that no load is conditional), in slice order -- the order every sum of slices in the cross kernels uses,
+// so a key row of the forward equals the h row of its token bit for bit.
 static __device__ __forceinline__ f32x4 sum_slices4(const float* p, size_t stride, int ks) {
-    f32x4 v[4];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ks; s += 8) {
+        f32x4 x[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ks; s += 4) {
+        for (int j = 0; j < 8; ++j) x[j] = *(const f32x4*)(p + (size_t)min(s + j, ks - 1) * stride);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 x = *(const f32x4*)(p + (size_t)min(s + j, ks - 1) * stride);
+        for (int j = 0; j < 8; ++j) acc += (s + j < ks) ? x[j] : z;
+    }
+    return acc;
+}
+
+// The block's first memory phase: the split-K slices of its RB rows AND of the first key chunk in ONE stream of loads.  A thread
+// owns IPT float4 elements of each array; per batch SB slices of both arrays are requested before anything is consumed
+// (16 loads of 16 bytes in flight per thread), so a 4096-wide input (8 slices) costs one memory round trip instead of the
+// five a load-wait-load-wait sequence took, a 11008-wide one three instead of thirteen.  Sums run in slice order.
+template <int IPT, int SB>
+static __device__ __forceinline__ void sum_rows_and_keys(const float* part, size_t sstride, int ks, const size_t (&offR)[IPT], const size_t (&offK)[IPT],
+                                                         f32x4 (&accR)[IPT], f32x4 (&accK)[IPT]) {
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) { accR[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; accK[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int s0 = 0; s0 < ks; s0 += SB) {
+        f32x4 xr[IPT][SB], xk[IPT][SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+            const size_t so = (size_t)min(s0 + q, ks - 1) * sstride;
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) { xr[u][q] = *(const f32x4*)(part + offR[u] + so); xk[u][q] = *(const f32x4*)(part + offK[u] + so); }
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            v[j] += (s + j < ks) ? x : z;
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) { accR[u] += (s0 + q < ks) ? xr[u][q] : z; accK[u] += (s0 + q < ks) ? xk[u][q] : z; }
         }
     }
-    return (v[0] + v[1]) + (v[2] + v[3]);
 }
 
 template <int RP>
@@ -565,6 +590,7 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int nrb = (a.S + RB - 1) / RB;                // row blocks; the blocks behind them only write the weight shadows
+    if (a.abl == 4) return;
     if ((int)blockIdx.y >= nrb) {
         cross_weight_shadows<RP>(a, ((int)blockIdx.y - nrb) * gridDim.x + blockIdx.x, ((int)gridDim.y - nrb) * gridDim.x, tid, NTH);
         return;
@@ -572,27 +598,49 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     const int b = blockIdx.x, r0 = blockIdx.y * RB;
     const int nrow = min(RB, a.S - r0);
     const size_t sstride = (size_t)a.T * RP;
-    // ---- batch 1: everything that does not depend on other loads
+    if (a.abl == 1) return;
+    // ---- round trip 1: routing (sample's key count, my row's modality, the key tokens of the first chunk)
+    constexpr int IPT = (RB * R4) / NTH, SB = (8 / IPT) < 2 ? 2 : 8 / IPT;
+    static_assert(RB * R4 == KC * R4 && (RB * R4) % NTH == 0, "one element of each array per thread and round");
     const int Lk = a.klen[b];
     int my_mod = MOKA_MOD_NONE;
     if (tid < nrow) my_mod = a.tok_mod[b * a.S + r0 + tid];
-    for (int e = tid; e < RB * R4; e += NTH) {
-        const int row = e / R4, k4 = e % R4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < nrow) v = sum_slices4(a.part + ((size_t)(b * a.S + r0 + row)) * RP + 4 * k4, sstride, a.ks);   // garbage for tokens of no modality
+    int tk[IPT], rmod[IPT];                                       // key token / modality of the row of my u-th element
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Hs[row * KP + 4 * k4 + c] = v[c];
+    for (int u = 0; u < IPT; ++u) {
+        const int row = (tid + u * NTH) / R4;
+        tk[u] = a.ktok[b * a.Lkp + min(row, a.Lkp - 1)];
+        rmod[u] = a.tok_mod[b * a.S + r0 + min(row, nrow - 1)];
+    }
+    // ---- round trip 2 (.. 1 + ks / SB): the rows' and the first chunk's key rows' split-K slices, all in flight together
+    {
+        size_t offR[IPT], offK[IPT];
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
+            if (row >= Lk) tk[u] = -1;                            // (row = key slot of the first chunk)
+            if (row >= nrow) rmod[u] = MOKA_MOD_NONE;
+            offR[u] = ((size_t)(b * a.S + r0 + min(row, nrow - 1))) * RP + 4 * k4;
+            offK[u] = (size_t)max(tk[u], 0) * RP + 4 * k4;
+        }
+        f32x4 accR[IPT], accK[IPT];
+        sum_rows_and_keys<IPT, SB>(a.part, sstride, a.ks, offR, offK, accR, accK);
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // tokens of no modality (their partial rows were never written) and rows behind the sample: h = 0
+                const float hv = (rmod[u] == MOKA_MOD_NONE) ? 0.f : accR[u][c];
+                Hs[row * KP + 4 * k4 + c] = hv;
+                Hp[row * KP + 4 * k4 + c] = hv;
+                Ks[row * KP + 4 * k4 + c] = (tk[u] < 0) ? 0.f : accK[u][c];   // zero key row (still enters the softmax when slot < Lk)
+            }
+        }
     }
     if (tid < RB) s_mod[tid] = my_mod;
+    if (a.abl == 2) { if (Hs[tid] == 1234.5f) a.out_f32[tid] = Ks[tid]; return; }
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
-    // tokens of no modality: h = 0 (their partial rows were never written)
-    for (int e = tid; e < RB * RP; e += NTH) {
-        const int row = e / RP, k = e % RP;
-        float v = Hs[row * KP + k];
-        if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;
-        Hs[row * KP + k] = v;
-        Hp[row * KP + k] = v;
-    }
     if (anyq) {
         const int qrow = wave * 16 + i;                           // the lane's query row inside the block
         const int mq = s_mod[qrow];
@@ -605,18 +653,19 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
         float qf[KS4];
         const int nch = (Lk + KC - 1) / KC;
         for (int c = 0; c < nch; ++c) {
-            if (c) __syncthreads();                               // everybody is done with the previous chunk
-            // ---- batch 2: the chunk's key rows (token index, then its slices)
-            for (int e = tid; e < KC * R4; e += NTH) {
-                const int jj = e / R4, k4 = e % R4;
-                const int j = c * KC + jj;
-                const int t = (j < Lk) ? a.ktok[b * a.Lkp + j] : -1;
-                f32x4 v = sum_slices4(a.part + (size_t)max(t, 0) * RP + 4 * k4, sstride, a.ks);
-                if (t < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};       // zero key row (still enters the softmax when j < Lk)
+            if (c) {                                              // further chunks of a long question (the first one is in place)
+                __syncthreads();                                  // everybody is done with the previous chunk
+                for (int e = tid; e < KC * R4; e += NTH) {
+                    const int jj = e / R4, k4 = e % R4;
+                    const int j = c * KC + jj;
+                    const int t = (j < Lk) ? a.ktok[b * a.Lkp + j] : -1;
+                    f32x4 v = sum_slices4(a.part + (size_t)max(t, 0) * RP + 4 * k4, sstride, a.ks);
+                    if (t < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) Ks[jj * KP + 4 * k4 + cc] = v[cc];
+                    for (int cc = 0; cc < 4; ++cc) Ks[jj * KP + 4 * k4 + cc] = v[cc];
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (!wq) continue;                                    // wave uniform
             if (c == 0) {
 #pragma unroll
@@ -668,24 +717,58 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
         }
     }
     __syncthreads();
-    for (int e = tid; e < nrow * RP; e += NTH) {
-        const int row = e / RP, k = e % RP;
-        const int t = b * a.S + r0 + row;
-        const float hv = Hs[row * KP + k], hpv = Hp[row * KP + k];
-        a.out_f32[(size_t)t * RP + k] = hv;
-        if (a.out_f32b) a.out_f32b[(size_t)t * RP + k] = hpv;
-        write_pack_tok<RP>(a.pack_tok, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
-    }
-    // rank-major pack: consecutive lanes <-> consecutive tokens (positions permuted inside a group of 32): coalesced 2-byte stores
-    for (int e = tid; e < RP * RB; e += NTH) {
-        const int k = e / RB, row = e % RB;
-        if (row < nrow) {
+    if (a.abl == 3) { if (Hp[tid] == 1234.5f) a.out_f32[tid] = Hs[tid]; return; }
+    if ((((b * a.S + r0) | nrow) & 3) == 0) {
+        // wide stores (block uniform: the block's rows come in aligned groups of four): per (row, 4 ranks) one 16-byte store of
+        // h and two 8-byte stores of the token-major pack; per (rank, 4 tokens) two 8-byte stores of the rank-major pack
+        // (four consecutive tokens of a group of 32 sit at four consecutive positions, see kmj_pos)
+        for (int e = tid; e < nrow * R4; e += NTH) {
+            const int row = e / R4, k4 = e % R4;
             const int t = b * a.S + r0 + row;
-            unsigned short hi, lo;
-            split_hi_lo(Hp[row * KP + k] * mod_scale(a.s_mod, s_mod[row]), hi, lo);
+            const float sc = mod_scale(a.s_mod, s_mod[row]);
+            f32x4 hv, hpv;
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                hv[c] = Hs[row * KP + 4 * k4 + c];
+                hpv[c] = Hp[row * KP + 4 * k4 + c];
+                split_hi_lo(hpv[c] * sc, hi[c], lo[c]);
+            }
+            *(f32x4*)(a.out_f32 + (size_t)t * RP + 4 * k4) = hv;
+            if (a.out_f32b) *(f32x4*)(a.out_f32b + (size_t)t * RP + 4 * k4) = hpv;
+            *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + 4 * k4) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+            *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + RP + 4 * k4) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+        }
+        for (int e = tid; e < RP * (nrow >> 2); e += NTH) {
+            const int k = e / (nrow >> 2), row = (e % (nrow >> 2)) << 2;
+            const int t = b * a.S + r0 + row;
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split_hi_lo(Hp[(row + c) * KP + k] * mod_scale(a.s_mod, s_mod[row + c]), hi[c], lo[c]);
             const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
-            a.pack_kmj[((size_t)0 * RP + k) * a.Tp + pos] = hi;
-            a.pack_kmj[((size_t)1 * RP + k) * a.Tp + pos] = lo;
+            *(uint2*)(a.pack_kmj + ((size_t)0 * RP + k) * a.Tp + pos) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+            *(uint2*)(a.pack_kmj + ((size_t)1 * RP + k) * a.Tp + pos) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+        }
+    } else {
+        for (int e = tid; e < nrow * RP; e += NTH) {
+            const int row = e / RP, k = e % RP;
+            const int t = b * a.S + r0 + row;
+            const float hv = Hs[row * KP + k], hpv = Hp[row * KP + k];
+            a.out_f32[(size_t)t * RP + k] = hv;
+            if (a.out_f32b) a.out_f32b[(size_t)t * RP + k] = hpv;
+            write_pack_tok<RP>(a.pack_tok, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
+        }
+        // rank-major pack: consecutive lanes <-> consecutive tokens (positions permuted inside a group of 32)
+        for (int e = tid; e < RP * RB; e += NTH) {
+            const int k = e / RB, row = e % RB;
+            if (row < nrow) {
+                const int t = b * a.S + r0 + row;
+                unsigned short hi, lo;
+                split_hi_lo(Hp[row * KP + k] * mod_scale(a.s_mod, s_mod[row]), hi, lo);
+                const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
+                a.pack_kmj[((size_t)0 * RP + k) * a.Tp + pos] = hi;
+                a.pack_kmj[((size_t)1 * RP + k) * a.Tp + pos] = lo;
+            }
         }
     }
     // pack tail [T, Tp): zero (the weight-gradient kernel reads whole groups of 32 tokens)
@@ -694,61 +777,98 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     }
 }
 
-// Backward, part a.  Same block shape and latency structure (keys: rows of the saved h).  Per 16-row tile with query rows:
-//   pass 1 (all key chunks): S^T and dP^T = K dO^T (dO = w g) share the key operand; running max / sum / sum(p dP) give the
-//           softmax statistics m, l and D = sum_j P_j dP_j of every query row
-//   pass 2 (all key chunks): P^T, dS^T = P^T (dP^T - D) c, dq^T += K^T dS^T; the key gradient contracts over the QUERIES, so the
-//           same scores are formed a second time un-transposed (operands swapped: lane <-> key, registers <-> queries; the
-//           statistics of queries 4 g + reg come through a 16-entry LDS table) and dK^T[rank][key] += Q^T dS + dO^T P
-// The block's dK of a chunk is combined in LDS (one wave at a time) and written to the block's own partial slot; rows that are
-// themselves key rows are finished by part b (their dq, if any, joins their dK slot).
-template <int RP, int NWV>
-__global__ void __launch_bounds__(NWV * 64) moka_cross_bwd_kernel(const CrossBatch ab) {
-    constexpr int NTH = NWV * 64, RB = NWV * 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
+// Backward, part a.  Block = 4 waves on ONE tile of 16 consecutive token rows; the four waves split the KEYS of a chunk
+// (wave w <-> key tile w, keys 16 w .. 16 w + 15), so the MFMA chain of a query tile is a quarter as long and runs on all four
+// SIMDs of the CU (the blocks are latency-, not throughput-bound: only ~1/5 of the tiles hold query rows).  Per tile with queries:
+//   pass 1 (all key chunks): S^T and dP^T = K dO^T (dO = w g) share the key operand; every wave keeps a running (max, sum,
+//           sum(p dP)) over ITS keys; one LDS exchange merges the four into the statistics m, l, D = sum_j P_j dP_j of each query row
+//   pass 2 (all key chunks): P^T, dS^T = P^T (dP^T - D) c and the wave's share of dq^T += K^T dS^T (summed over the waves through
+//           LDS at the end); the key gradient contracts over the QUERIES, so the same scores are formed a second time
+//           un-transposed (operands swapped: lane <-> key, registers <-> queries; their statistics come from a wave-private LDS
+//           table) and dK^T[rank][key] = Q^T dS + dO^T P is complete inside the wave: it goes straight to the block's partial slot.
+// Rows that are themselves key rows are finished by part b (their dq, if any, joins their dK slot).
+template <int RP>
+__global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab) {
+    constexpr int NTH = 256, NWV = 4, RB = 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
+    constexpr int RI = RB * R4;                // float4 elements of the block's rows (64 / 128 / 256)
+    constexpr int SG = NTH / RI;               // thread groups that share the slices of one element (4 / 2 / 1)
+    constexpr int KI = (KC * R4) / NTH;        // key-row float4 elements per thread (1 / 2 / 4)
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Gs = (float*)smem;                  // [RB][KP]  g rows
     float* Dh = Gs + RB * KP;                  // [RB][KP]  dh rows
     float* Hs = Dh + RB * KP;                  // [RB][KP]  h rows (queries)
     float* Ks = Hs + RB * KP;                  // [KC][KP]
-    float* dKs = Ks + KC * KP;                 // [KC][KP]
-    float* stat = dKs + KC * KP;               // [NWV][16][4]  m, 1/l, D, is-query of the wave's rows
+    float* Ps = Ks + KC * KP;                  // [NWV][RB][KP]  slice-group partial sums of g, later the waves' shares of dq
+    float* red = Ps + NWV * RB * KP;           // [NWV][16][4]   per-wave (max, sum, sum p dP) of the rows
+    float* stat = red + NWV * 16 * 4;          // [NWV][16][4]   per wave: m, 1/l, D, is-query of the rows
     __shared__ int s_mod[RB], s_slot[RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.x, r0 = blockIdx.y * RB;
     const int nrow = min(RB, a.S - r0);
     const size_t sstride = (size_t)a.T * RP;
+    if (a.abl == 1) return;
 
-    // ---- batch 1
+    // ---- round trip 1: routing (key count, the rows' modality / key slot, the key tokens of the first chunk)
     const int Lk = a.klen[b];
+    const int ritem = tid % RI, sgrp = tid / RI;
+    const int rrow = ritem / R4, rk4 = ritem % R4;
     int my_mod = MOKA_MOD_NONE, my_slot = -1;
     if (tid < nrow) { my_mod = a.tok_mod[b * a.S + r0 + tid]; my_slot = a.kslot[b * a.S + r0 + tid]; }
-    for (int e = tid; e < RB * R4; e += NTH) {
-        const int row = e / R4, k4 = e % R4;
-        f32x4 gv = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f};
-        if (row < nrow) {
-            const size_t off = ((size_t)(b * a.S + r0 + row)) * RP + 4 * k4;
-            gv = sum_slices4(a.part + off, sstride, a.ks);
-            hv = *(const f32x4*)(a.hfull + off);
+    int rmod = a.tok_mod[b * a.S + r0 + min(rrow, nrow - 1)];
+    int tk[KI];
+#pragma unroll
+    for (int u = 0; u < KI; ++u) tk[u] = a.ktok[b * a.Lkp + min((tid + u * NTH) / R4, a.Lkp - 1)];
+    // ---- round trip 2: the rows' g slices (dealt to SG thread groups, up to 8 loads in flight per thread), their h rows and
+    //      the first chunk's key rows of h
+    {
+        const size_t off = ((size_t)(b * a.S + r0 + min(rrow, nrow - 1))) * RP + 4 * rk4;
+        const f32x4 hv = *(const f32x4*)(a.hfull + off);
+        f32x4 kv[KI];
+#pragma unroll
+        for (int u = 0; u < KI; ++u) {
+            const int e = tid + u * NTH, jj = e / R4, k4 = e % R4;
+            if (jj >= Lk) tk[u] = -1;
+            kv[u] = *(const f32x4*)(a.hfull + (size_t)max(tk[u], 0) * RP + 4 * k4);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = sgrp; s0 < a.ks; s0 += 8 * SG) {
+            f32x4 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = *(const f32x4*)(a.part + off + (size_t)min(s0 + q * SG, a.ks - 1) * sstride);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += (s0 + q * SG < a.ks) ? x[q] : z;
+        }
+        if (rrow >= nrow) rmod = MOKA_MOD_NONE;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Ps[(sgrp * RB + rrow) * KP + 4 * rk4 + c] = (rmod == MOKA_MOD_NONE) ? 0.f : acc[c];   // rows of no modality: unwritten partial rows
+            if (sgrp == 0) Hs[rrow * KP + 4 * rk4 + c] = (rrow < nrow) ? hv[c] : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { Gs[row * KP + 4 * k4 + c] = gv[c]; Hs[row * KP + 4 * k4 + c] = hv[c]; }
+        for (int u = 0; u < KI; ++u) {
+            const int e = tid + u * NTH, jj = e / R4, k4 = e % R4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Ks[jj * KP + 4 * k4 + c] = (tk[u] < 0) ? 0.f : kv[u][c];
+        }
     }
     if (tid < RB) { s_mod[tid] = my_mod; s_slot[tid] = my_slot; }
+    if (a.abl == 2) { if (Hs[tid] == 1234.5f) a.pack_tok[tid] = (unsigned short)Ks[tid]; return; }
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
-    for (int e = tid; e < RB * RP; e += NTH) {
+    for (int e = tid; e < RB * RP; e += NTH) {                    // g = sum of the slice groups (fixed order)
         const int row = e / RP, k = e % RP;
-        float v = Gs[row * KP + k];
-        if (row >= nrow || s_mod[row] == MOKA_MOD_NONE) v = 0.f;   // unwritten partial rows
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < SG; ++q) v += Ps[(q * RB + row) * KP + k];
         Gs[row * KP + k] = v;
         Dh[row * KP + k] = v;
     }
+    __syncthreads();
     if (anyq) {
-        const int qrow = wave * 16 + i;
-        const int mq = s_mod[qrow];
-        const bool isq = (mq != 0 && mq != MOKA_MOD_NONE);
-        const bool wq = __any(isq);
+        const int mq = s_mod[i];
+        const bool isq = (mq != 0 && mq != MOKA_MOD_NONE);        // (lane <-> row i of the tile)
         const int nch = (Lk + KC - 1) / KC;
         auto load_keys = [&](int c) {                             // key rows of chunk c: rows of the saved h
             for (int e = tid; e < KC * R4; e += NTH) {
@@ -758,194 +878,183 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_bwd_kernel(const CrossBat
                 f32x4 v = *(const f32x4*)(a.hfull + (size_t)max(t, 0) * RP + 4 * k4);
                 if (t < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { Ks[jj * KP + 4 * k4 + cc] = v[cc]; dKs[jj * KP + 4 * k4 + cc] = 0.f; }
+                for (int cc = 0; cc < 4; ++cc) Ks[jj * KP + 4 * k4 + cc] = v[cc];
             }
         };
-        float qf[KS4], dof[KS4];                                  // query row / its upstream gradient, as MFMA fragments
-        f32x4 st[4], dpt[4];                                      // S^T (scaled, masked) and dP^T of the current chunk
+        float qf[KS4], dof[KS4];                                  // query rows / their upstream gradient, as MFMA fragments
+#pragma unroll
+        for (int ks = 0; ks < KS4; ++ks) { qf[ks] = Hs[i * KP + 4 * ks + g]; dof[ks] = a.w * Gs[i * KP + 4 * ks + g]; }
+        f32x4 st, dpt;                                            // S^T (scaled, masked) and dP^T of my key tile of the current chunk
         auto scores = [&](int c) {
+            st = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dpt = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS4; ++ks) {
-                    const float kf = Ks[(16 * t + i) * KP + 4 * ks + g];
-                    st[t] = MFMA4F(kf, qf[ks], st[t]);
-                    dpt[t] = MFMA4F(kf, dof[ks], dpt[t]);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    st[t][reg] = (c * KC + 16 * t + 4 * g + reg < Lk) ? st[t][reg] * a.c : -INFINITY;
+            for (int ks = 0; ks < KS4; ++ks) {
+                const float kf = Ks[(16 * wave + i) * KP + 4 * ks + g];
+                st = MFMA4F(kf, qf[ks], st);
+                dpt = MFMA4F(kf, dof[ks], dpt);
             }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                st[reg] = (c * KC + 16 * wave + 4 * g + reg < Lk) ? st[reg] * a.c : -INFINITY;
         };
-        // ---- pass 1: softmax statistics of my query row
-        float m_run = -INFINITY, l_run = 0.f, n_run = 0.f;
+        // ---- pass 1: (max, sum, sum p dP) over my keys, merged over the waves
+        float m_w = -INFINITY, l_w = 0.f, n_w = 0.f;
         for (int c = 0; c < nch; ++c) {
-            if (c) __syncthreads();
-            load_keys(c);
-            __syncthreads();
-            if (!wq) continue;
-            if (c == 0) {
-#pragma unroll
-                for (int ks = 0; ks < KS4; ++ks) { qf[ks] = Hs[qrow * KP + 4 * ks + g]; dof[ks] = a.w * Gs[qrow * KP + 4 * ks + g]; }
-            }
+            if (c) { __syncthreads(); load_keys(c); __syncthreads(); }     // (the first chunk is in place)
             scores(c);
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) mx = fmaxf(mx, st[t][reg]);
+            float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
             mx = rows_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
-            float ls = 0.f, ns = 0.f;
+            const float m_new = fmaxf(m_w, mx);
+            if (m_new > -INFINITY) {                              // (a wave may have no key at all: short questions)
+                const float alpha = __expf(m_w - m_new);
+                float ls = 0.f, ns = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int reg = 0; reg < 4; ++reg) { const float pv = __expf(st[reg] - m_new); ls += pv; ns = fmaf(pv, dpt[reg], ns); }
+                ls = rows_sum(ls);
+                ns = rows_sum(ns);
+                l_w = fmaf(l_w, alpha, ls);
+                n_w = fmaf(n_w, alpha, ns);
+                m_w = m_new;
+            }
+        }
+        if (g == 0) { float* rp = red + (wave * 16 + i) * 4; rp[0] = m_w; rp[1] = l_w; rp[2] = n_w; }
+        __syncthreads();
+        float m_run = -INFINITY, l_run = 0.f, n_run = 0.f;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { const float pv = __expf(st[t][reg] - m_new); ls += pv; ns = fmaf(pv, dpt[t][reg], ns); }
-            ls = rows_sum(ls);
-            ns = rows_sum(ns);
-            l_run = fmaf(l_run, alpha, ls);
-            n_run = fmaf(n_run, alpha, ns);
-            m_run = m_new;
+        for (int w = 0; w < NWV; ++w) m_run = fmaxf(m_run, red[(w * 16 + i) * 4]);
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {                           // fixed order: every wave gets the same bits
+            const float* rp = red + (w * 16 + i) * 4;
+            const float sc = (rp[0] > -INFINITY) ? __expf(rp[0] - m_run) : 0.f;
+            l_run = fmaf(rp[1], sc, l_run);
+            n_run = fmaf(rp[2], sc, n_run);
         }
         const float inv_l = 1.f / l_run, Dq = n_run * inv_l;
-        if (wq && g == 0) {
-            float* sp = stat + (wave * 16 + i) * 4;
-            sp[0] = m_run; sp[1] = inv_l; sp[2] = Dq; sp[3] = isq ? 1.f : 0.f;
-        }
-        // ---- pass 2: dq, dK chunk by chunk
+        if (g == 0) { float* sp = stat + (wave * 16 + i) * 4; sp[0] = m_run; sp[1] = inv_l; sp[2] = Dq; sp[3] = isq ? 1.f : 0.f; }
+        // ---- pass 2: my share of dq, and dK of my keys, chunk by chunk
         f32x4 dq[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nch; ++c) {
-            if (nch > 1) {                                        // (one chunk: keys, scores and dP^T are still in place)
-                __syncthreads();
-                load_keys(c);
-                __syncthreads();
-                if (wq) scores(c);
-            }
-            f32x4 dK[NT][4];
-            if (wq) {
-                // P^T and dS^T (in place of S^T / dP^T); rows of the tile that are no query rows contribute nothing
+        float mS[4], ilS[4], dS_[4], qS[4];                       // statistics of queries 4 g + reg (this wave's own table)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const float pv = isq ? __expf(st[t][reg] - m_run) * inv_l : 0.f;
-                        dpt[t][reg] = pv * (dpt[t][reg] - Dq) * a.c;          // c folded in: both uses carry it
-                        st[t][reg] = pv;
-                    }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int sp = 0; sp < 4; ++sp) dq[nt] = MFMA4F(Ks[(16 * t + 4 * g + sp) * KP + 16 * nt + i], dpt[t][sp], dq[nt]);
-                // the same quantities with lane <-> key (16 t + i), registers <-> queries 4 g + reg
-                float mS[4], ilS[4], dS_[4], qS[4];
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float* sp = stat + (wave * 16 + 4 * g + reg) * 4;     // written by this wave (program order + lgkmcnt)
-                    mS[reg] = sp[0]; ilS[reg] = sp[1]; dS_[reg] = sp[2]; qS[reg] = sp[3];
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dK[nt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    f32x4 sq = {0.f, 0.f, 0.f, 0.f}, dpq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < KS4; ++ks) {
-                        const float kf = Ks[(16 * t + i) * KP + 4 * ks + g];
-                        sq = MFMA4F(qf[ks], kf, sq);
-                        dpq = MFMA4F(dof[ks], kf, dpq);
-                    }
-                    const bool kvalid = c * KC + 16 * t + i < Lk;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const float pv = (kvalid && qS[reg] != 0.f) ? __expf(sq[reg] * a.c - mS[reg]) * ilS[reg] : 0.f;
-                        dpq[reg] = pv * (dpq[reg] - dS_[reg]) * a.c;
-                        sq[reg] = pv;
-                    }
-                    // dK^T[rank][key] += sum_q Q[q][rank] dS[q][key] + dO[q][rank] P[q][key]   (contraction step s' <-> queries 4 g + s')
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int sp = 0; sp < 4; ++sp) {
-                            const int qr = (wave * 16 + 4 * g + sp) * KP + 16 * nt + i;
-                            dK[nt][t] = MFMA4F(Hs[qr], dpq[sp], dK[nt][t]);
-                            dK[nt][t] = MFMA4F(a.w * Gs[qr], sq[sp], dK[nt][t]);
-                        }
-                }
-            }
-            // combine the waves' key gradients of this chunk: one wave at a time, plain LDS read-modify-write
-            // (D^T tile: lane <-> key 16 t + i, registers <-> ranks 16 nt + 4 g + reg)
-            for (int w = 0; w < NWV; ++w) {
-                if (wave == w && wq) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) dKs[(16 * t + i) * KP + 16 * nt + 4 * g + reg] += dK[nt][t][reg];
-                }
-                __syncthreads();
-            }
-            const int nk = min(KC, Lk - c * KC);
-            float* dst = a.dk_part + (((size_t)b * gridDim.y + blockIdx.y) * a.Lkp + (size_t)c * KC) * RP;
-            for (int e = tid; e < nk * RP; e += NTH) dst[e] = dKs[(e / RP) * KP + (e % RP)];
+        for (int reg = 0; reg < 4; ++reg) {
+            const float* sp = stat + (wave * 16 + 4 * g + reg) * 4;
+            mS[reg] = sp[0]; ilS[reg] = sp[1]; dS_[reg] = sp[2]; qS[reg] = sp[3];
         }
-        if (wq && isq) {
+        float* dkdst = a.dk_part + ((size_t)b * gridDim.y + blockIdx.y) * a.Lkp * RP;
+        for (int c = 0; c < nch; ++c) {
+            if (nch > 1) { __syncthreads(); load_keys(c); __syncthreads(); scores(c); }   // (one chunk: keys, S^T and dP^T are still in place)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {                   // P^T, dS^T in place; rows of the tile that are no query rows contribute nothing
+                const float pv = isq ? __expf(st[reg] - m_run) * inv_l : 0.f;
+                dpt[reg] = pv * (dpt[reg] - Dq) * a.c;            // c folded in: both uses carry it
+                st[reg] = pv;
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int k = 16 * nt + 4 * g + reg;
-                    Dh[qrow * KP + k] = Gs[qrow * KP + k] + dq[nt][reg];
+                for (int sp = 0; sp < 4; ++sp) dq[nt] = MFMA4F(Ks[(16 * wave + 4 * g + sp) * KP + 16 * nt + i], dpt[sp], dq[nt]);
+            // un-transposed: lane <-> key 16 wave + i, registers <-> queries 4 g + reg
+            f32x4 sq = {0.f, 0.f, 0.f, 0.f}, dpq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS4; ++ks) {
+                const float kf = Ks[(16 * wave + i) * KP + 4 * ks + g];
+                sq = MFMA4F(qf[ks], kf, sq);
+                dpq = MFMA4F(dof[ks], kf, dpq);
+            }
+            const int jkey = c * KC + 16 * wave + i;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float pv = (jkey < Lk && qS[reg] != 0.f) ? __expf(sq[reg] * a.c - mS[reg]) * ilS[reg] : 0.f;
+                dpq[reg] = pv * (dpq[reg] - dS_[reg]) * a.c;
+                sq[reg] = pv;
+            }
+            // dK^T[rank][key] = sum_q Q[q][rank] dS[q][key] + dO[q][rank] P[q][key]   (contraction step s' <-> queries 4 g + s')
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 dK = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {
+                    const int qr = (4 * g + sp) * KP + 16 * nt + i;
+                    dK = MFMA4F(Hs[qr], dpq[sp], dK);
+                    dK = MFMA4F(a.w * Gs[qr], sq[sp], dK);
                 }
+                if (jkey < Lk) *(f32x4*)(dkdst + (size_t)jkey * RP + 16 * nt + 4 * g) = dK;      // lane <-> key, registers <-> ranks 4 g + reg
+            }
+        }
+        // the waves' shares of dq meet in LDS
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ps[(wave * RB + i) * KP + 16 * nt + 4 * g + reg] = dq[nt][reg];
+        __syncthreads();
+        for (int e = tid; e < RB * RP; e += NTH) {
+            const int row = e / RP, k = e % RP;
+            const int m = s_mod[row];
+            if (m != 0 && m != MOKA_MOD_NONE) {
+                float v = Gs[row * KP + k];
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) v += Ps[(w * RB + row) * KP + k];
+                Dh[row * KP + k] = v;
+            }
         }
         __syncthreads();
         // a key row that is also a query row (masks may overlap in VT): its dq joins its own dK slot (this block's partial)
         for (int e = tid; e < nrow * RP; e += NTH) {
             const int row = e / RP, k = e % RP;
             const int slot = s_slot[row];
-            if (slot >= 0 && slot < Lk) {
-                float* dst = a.dk_part + (((size_t)b * gridDim.y + blockIdx.y) * a.Lkp + slot) * RP + k;
-                *dst += Dh[row * KP + k] - Gs[row * KP + k];
-            }
+            if (slot >= 0 && slot < Lk) dkdst[(size_t)slot * RP + k] += Dh[row * KP + k] - Gs[row * KP + k];
         }
-    } else {
-        __syncthreads();
     }
     if (tid == 0) a.dk_flag[b * gridDim.y + blockIdx.y] = anyq ? 1 : 0;
-    for (int e = tid; e < nrow * RP; e += NTH) {
-        const int row = e / RP, k = e % RP;
-        if (s_slot[row] >= 0) continue;                   // key row: finished by part b
-        const int t = b * a.S + r0 + row;
-        const int m = s_mod[row];
-        const float dv = Dh[row * KP + k];
-        if (a.out_f32) a.out_f32[(size_t)t * RP + k] = dv;
-        write_pack_tok<RP>(a.pack_tok, t, k, (m == MOKA_MOD_NONE) ? 0.f : dv * a.s_mod[0]);
-    }
-    // rank-major masked planes: consecutive lanes <-> consecutive tokens
-    for (int e = tid; e < RP * RB; e += NTH) {
-        const int k = e / RB, row = e % RB;
-        if (row < nrow && s_slot[row] < 0) {
+    if (a.abl == 3) { if (Dh[tid] == 1234.5f) a.pack_tok[tid] = (unsigned short)Gs[tid]; return; }
+    if ((((b * a.S + r0) | nrow) & 3) == 0) {
+        // wide stores, as in the forward.  Key rows get provisional values here: part b (the next launch) rewrites every
+        // entry of a key row with the final ones.
+        for (int e = tid; e < nrow * R4; e += NTH) {
+            const int row = e / R4, k4 = e % R4;
             const int t = b * a.S + r0 + row;
-            const int m = s_mod[row];
-            unsigned short hi, lo;
-            split_hi_lo((m == MOKA_MOD_NONE) ? 0.f : Dh[row * KP + k] * a.s_mod[0], hi, lo);
+            const float sc = (s_mod[row] == MOKA_MOD_NONE) ? 0.f : a.s_mod[0];
+            f32x4 dv;
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dv[c] = Dh[row * KP + 4 * k4 + c]; split_hi_lo(dv[c] * sc, hi[c], lo[c]); }
+            if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)t * RP + 4 * k4) = dv;
+            *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + 4 * k4) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+            *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + RP + 4 * k4) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+        }
+        for (int e = tid; e < RP * (nrow >> 2); e += NTH) {
+            const int k = e / (nrow >> 2), row = (e % (nrow >> 2)) << 2;
+            const int t = b * a.S + r0 + row;
+            unsigned short hi[4], lo[4];
+            int mm4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mm4[c] = s_mod[row + c];
+                split_hi_lo((mm4[c] == MOKA_MOD_NONE) ? 0.f : Dh[(row + c) * KP + k] * a.s_mod[0], hi[c], lo[c]);
+            }
             const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
 #pragma unroll
             for (int mm = 0; mm < MOKA_MAX_MOD; ++mm) {
                 if (mm < a.M) {
-                    a.pack_kmj[(((size_t)mm * 2 + 0) * RP + k) * a.Tp + pos] = (mm == m) ? hi : (unsigned short)0;
-                    a.pack_kmj[(((size_t)mm * 2 + 1) * RP + k) * a.Tp + pos] = (mm == m) ? lo : (unsigned short)0;
+                    unsigned short h4[4], l4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { h4[c] = (mm4[c] == mm) ? hi[c] : (unsigned short)0; l4[c] = (mm4[c] == mm) ? lo[c] : (unsigned short)0; }
+                    *(uint2*)(a.pack_kmj + (((size_t)mm * 2 + 0) * RP + k) * a.Tp + pos) = make_uint2(h4[0] | ((unsigned)h4[1] << 16), h4[2] | ((unsigned)h4[3] << 16));
+                    *(uint2*)(a.pack_kmj + (((size_t)mm * 2 + 1) * RP + k) * a.Tp + pos) = make_uint2(l4[0] | ((unsigned)l4[1] << 16), l4[2] | ((unsigned)l4[3] << 16));
                 }
             }
+        }
+    } else {
+        for (int e = tid; e < nrow * RP; e += NTH) {
+            const int row = e / RP, k = e % RP;
+            if (s_slot[row] >= 0) continue;                   // key row: finished by part b
+            const int t = b * a.S + r0 + row;
+            const int m = s_mod[row];
+            const float dv = Dh[row * KP + k];
+            if (a.out_f32) a.out_f32[(size_t)t * RP + k] = dv;
+            write_packs_bwd<RP>(a, t, k, m, (m == MOKA_MOD_NONE) ? 0.f : dv * a.s_mod[0]);
         }
     }
     if (b == a.B - 1 && blockIdx.y == gridDim.y - 1) {
@@ -1986,7 +2095,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
 static int g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
-           g_tune_cross_rows = 0;
+           g_tune_cross_rows = 0, g_tune_cross_abl = 0;
 
 static int num_cu() {
     static int n = 0;
@@ -2066,11 +2175,25 @@ static int launch_reduce(const ReduceArgs& a, int RP, int /*G*/, int nz, hipStre
     return check_launch("moka_reduce_kernel");
 }
 
+__global__ void moka_nop_kernel(int x) { if (x == 12345) __builtin_trap(); }
+struct BigArg { char pad[720]; };
+__global__ void moka_nop_big_kernel(BigArg x) { if (x.pad[3] == 123) __builtin_trap(); }
+
 template <int RP>
 static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
     constexpr int NWV = 4, RB = 16 * NWV, KC = 64, KP = RP + 1;
     const CrossArgs& a = ab.z[0];
     dim3 grid(a.B, (a.S + RB - 1) / RB, nz), block(NWV * 64);
+    if (!bwd && g_tune_cross_abl >= 9) {                  // diagnostics: (abl - 8) extra trivial launches in front of the real one
+        for (int q = 8; q < g_tune_cross_abl; ++q) hipLaunchKernelGGL(moka_nop_kernel, dim3(1), dim3(64), 0, st, 0);
+    } else
+    if (!bwd && g_tune_cross_abl >= 5) {                  // diagnostics: a trivial kernel in place of the forward cross kernel
+        if (g_tune_cross_abl == 5) hipLaunchKernelGGL(moka_nop_kernel, grid, block, 0, st, 0);
+        else if (g_tune_cross_abl == 6) hipLaunchKernelGGL(moka_nop_kernel, dim3(1), dim3(64), 0, st, 0);
+        else if (g_tune_cross_abl == 7) { BigArg ba; memset(&ba, 0, sizeof(ba)); hipLaunchKernelGGL(moka_nop_big_kernel, grid, block, 0, st, ba); }
+        else hipLaunchKernelGGL(moka_nop_kernel, grid, block, 13056, st, 0);
+        return;
+    }
     if (!bwd) {
         const size_t lds = (size_t)(2 * RB + KC) * KP * 4;
         ensure_lds((const void*)moka_cross_fwd_kernel<RP, NWV>, lds);
@@ -2083,10 +2206,11 @@ static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t s
         dim3 gridf(grid.x, grid.y + (unsigned)((items + (long)block.x * a.B - 1) / ((long)block.x * a.B)), nz);
         hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, NWV>), gridf, block, lds, st, ab);
     } else {
-        const size_t lds = (size_t)(3 * RB + 2 * KC) * KP * 4 + (size_t)NWV * 16 * 4 * 4;
-        ensure_lds((const void*)moka_cross_bwd_kernel<RP, NWV>, lds);
-        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP, NWV>), grid, block, lds, st, ab);
-        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16, nz), dim3(256), (size_t)grid.y * 4, st, ab, (int)grid.y);
+        const dim3 gridb(a.B, (a.S + 15) / 16, nz);           // one 16-row tile per block, the four waves split the keys
+        const size_t lds = (size_t)((3 + NWV) * 16 + KC) * KP * 4 + (size_t)2 * NWV * 16 * 4 * 4;
+        ensure_lds((const void*)moka_cross_bwd_kernel<RP>, lds);
+        hipLaunchKernelGGL((moka_cross_bwd_kernel<RP>), gridb, block, lds, st, ab);
+        hipLaunchKernelGGL((moka_cross_bwd_keys_kernel<RP>), dim3(a.B, (a.Lkp * RP + 15) / 16, nz), dim3(256), (size_t)gridb.y * 4, st, ab, (int)gridb.y);
     }
 }
 
@@ -2108,6 +2232,7 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
         a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
         a.r = r; a.M = rt->M;
         a.RB = 64;
+        a.abl = g_tune_cross_abl >= 9 ? 0 : g_tune_cross_abl;
     }
     // (the question span is unbounded, as in the reference -- layer.py:640-653, lora.py:489-499: keys are streamed through LDS in
     //  chunks of 64 with a running softmax; only the caller's workspace grows with Lk_max, moka_cross_ws_bytes)
@@ -2290,6 +2415,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
     else if (!strcmp(key, "wgrad_bpc")) g_tune_wgrad_bpc = value;
     else if (!strcmp(key, "cross_rows")) g_tune_cross_rows = value;
+    else if (!strcmp(key, "cross_abl")) g_tune_cross_abl = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 }
