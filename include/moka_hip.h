@@ -79,9 +79,9 @@ typedef struct moka_routing {
                                  row that still enters the softmax (also for keys whose token has no modality) */
     const int32_t* klen;      /* [B] number of key slots (0: sample has no interaction) */
     const int32_t* kslot;     /* [T] key slot j with ktok[b][j] == t, -1 if token t is not a (non-zero) key row */
-    int32_t B, S, Lk_max, M;  /* Lk_max = max_b klen[b].  Limits of the cross kernels (a sample's key rows live in LDS):
-                                 Lk_max <= 512 for r <= 32, <= 247 for r <= 64; beyond that MOKA_EINVAL (the reference has
-                                 no limit; its question spans are tens of tokens) */
+    int32_t B, S, Lk_max, M;  /* Lk_max = max_b klen[b] (= row length of ktok).  Unbounded, as in the reference
+                                 (layer.py:640-653, lora.py:489-499): the cross kernels stream the keys through LDS in
+                                 chunks of 64 with a running softmax; only moka_cross_ws_bytes() grows with it */
 } moka_routing;
 
 int         moka_version(void);
@@ -89,8 +89,8 @@ const char* moka_last_error(void);
 /* 0 when a gfx950 device is current, MOKA_ENODEV otherwise. */
 int         moka_device_check(void);
 
-/* Diagnostic: override a launch heuristic ("reduce_nw", "reduce_u", "reduce_ks", "expand_bpc", "wgrad_ct",
- * "wgrad_bpc", "cross_rows", "no_fused_gy", "gy_ng", "expand_depth", "no_xa", "cross_nth", "xa_ng"; value 0 restores the default).  Results never depend on it. */
+/* Diagnostic: override a launch heuristic ("expand_bpc", "expand_depth", "expand_nq", "wgrad_nw", "wgrad_ct", "wgrad_bpc",
+ * "gy_ng", "xa_ng"; value 0 restores the default).  Results never depend on it. */
 int moka_tune(const char* key, int value);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */

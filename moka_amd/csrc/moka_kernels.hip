@@ -2,25 +2,26 @@
 //
 // Kernels (formulation and buffer formats: include/moka_hip.h):
 //
-//   reduce  (R)  in[T,C] bf16 -> part[KS,T,RP] fp32             F1: x.A_m^T          B1: gy.Bw
-//   cross   (X)  rank-r cross-modal softmax interaction, fwd and bwd (fp32), + operand packs
-//   expand  (E)  out[T,C] bf16 += pack[T,:] . W^T                F2: y += hp.Bw^T     B3: dx += dh.A_m
-//   wgrad   (G)  acc[C,r] fp32 += sum_t in[t,c] * pack[k,t]      B1: dB               B3: dA_m
+//   xa      (F)  x[T,C] bf16 -> part[KS,T,RP] fp32 (split-K slices)   F1: x.A_m^T  (weights of all modalities / projections resident)
+//   gy      (Y)  gy[T,C] bf16 -> g_part[KS,T,RP] fp32 + dB            B1: gy.Bw and dB in one pass over gy
+//   cross   (X)  rank-r cross-modal softmax interaction, fwd and bwd: fp32 MFMA (16x16x4), keys streamed in chunks, + operand packs
+//   expand  (E)  out[T,C] bf16 += pack[T,:] . W^T                     F2: y += hp.Bw^T     B3: dx += dh.A_m
+//   wgrad   (G)  acc[C,r] fp32 += sum_t in[t,c] * pack[k,t]           B1: dB (r > 16)      B3: dA_m
+//   adamw   (O)  AdamW + gradient averaging + bf16 working copy + gradient zeroing on the flat adapter buffers
 //
 // Design (numbers measured on MI355X; profiles/ and tools/microbench/):
 //   * The big operands (x, y, gy, dx) are streamed exactly once per kernel, HBM -> VGPR in
-//     MFMA-fragment shape (16 rows x 64 B per wave instruction streams at 6.2-6.8 TB/s, the same as
-//     lane-linear loads), and never take an LDS round trip in R and E.
-//   * Every contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Rank-space
-//     tensors stay fp32 in HBM; the tiny cross kernels also emit them as bf16 hi+lo "packs" laid out
+//     MFMA-fragment shape (16 rows x 64 B per wave instruction streams as fast as lane-linear loads:
+//     6.0-6.4 TB/s read-only, 4.4-4.8 TB/s read-modify-write at 2 GiB working sets), and never take an
+//     LDS round trip in F and E.
+//   * The streaming contractions run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Rank-space
+//     tensors stay fp32 in HBM; the small cross kernels also emit them as bf16 hi+lo "packs" laid out
 //     exactly as the MFMA operands of E and G want them, so the streaming kernels do no conversion
 //     work.  For r = 16 the hi/lo pair fills the otherwise idle half of K = 32.
-//   * R: one block per 32-token tile, the block's 16 waves split the contraction dimension, weight
-//     fragments come straight from L2 (A_m is 393 KB), partial 16x16 tiles are summed through LDS.
-//     No weight staging, no barriers in the stream, one barrier at the end.
-//   * E: each wave keeps the weight fragments of its 128 output columns in registers (transposed via
-//     ds_read_b64_tr_b16 once per block for the A_m case) and walks over token tiles; per tile one
-//     16-byte pack load feeds 8 MFMAs and 4 x 16-byte read-modify-writes of the in/out tensor.
+//   * F / Y: block = 8 waves on a [NG*32 tokens x 512 columns] tile, wave = 64 columns with resident weight
+//     fragments; the [32 x RP] partials of the eight waves meet in LDS and leave as one split-K slice.
+//   * E: each wave keeps the weight fragments of its 128 output columns in registers and walks over token
+//     tiles; per tile one 16-byte pack load feeds 8 MFMAs and 4 x 16-byte read-modify-writes of the in/out tensor.
 //   * G: tokens are the MFMA K dimension, so the streamed tile must be K-major: each wave copies its
 //     own 32-token x 64-column tile to a private LDS region and reads it back transposed with
 //     ds_read_b64_tr_b16 -- no block barrier in the stream.  A block owns 64 columns for a long run
@@ -37,12 +38,6 @@
 
 #include "moka_hip.h"
 
-#ifndef ABL_XA
-#define ABL_XA 0
-#endif
-#ifndef ABL_GY
-#define ABL_GY 0
-#endif
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -178,233 +173,6 @@ static __device__ __forceinline__ float mod_scale(const float* s_mod, int m) {
 }
 
 // ------------------------------------------------------------------------------------------
-// R: reduce  in[T,C] -> part[KS,T,RP]      W_m is [r rows][C] row-major (A_m or BwT)
-// ------------------------------------------------------------------------------------------
-struct ReduceArgs {
-    const unsigned char* in[MOKA_MAX_GROUP];                 // [z]  [T][C[z]] bf16   (shared-input group: in[0])
-    const unsigned char* W[MOKA_MAX_GROUP][MOKA_MAX_MOD];    // [g or z][m]
-    const unsigned char* tok_mod;   // padded with MOKA_MOD_NONE
-    float* out[MOKA_MAX_GROUP];     // [g or z]  [KS][T][RP]
-    float s_mod[4];                 // scale per modality id
-    int C[MOKA_MAX_GROUP];          // [z]
-    int T, r, M, ks;
-    int shared_w;                   // 1: W[.][0] serves every modality (gy.Bw); routing only picks the scale
-    DropArgs drop[MOKA_MAX_GROUP];  // [g]  thr == 0: no dropout
-};
-
-// One block per (32-token tile, K slice).  The NW waves of the block split the slice's K steps;
-// every wave keeps TWO batches of U steps in flight (x: HBM, 16 rows x 64 B per instruction; W: L2):
-// batch i+1 (x and the weight fragments of the tile's first modality) is issued before batch i is
-// consumed, so the memory pipe never waits for the MFMA / weight round trip.  At the end the 16x16
-// partial tiles are summed through LDS.
-//   G == 1: blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems (batched launch).
-//   G  > 1: G projections share the input (q/k/v, gate/up): every x fragment is loaded once and
-//           multiplied with the G weight sets (each with its own dropout mask).
-//   MIX == false: shared weights (gy.Bw) -- a tile never needs more than one weight set, so the
-//           two-modality paths (and their registers) are compiled out.
-template <int RP, int NW, int U, int G, bool MIX>
-__global__ void __launch_bounds__(NW * 64) moka_reduce_kernel(const ReduceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = RP / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 15, g = lane >> 4;
-    const int z = (G == 1) ? blockIdx.z : 0;
-    const int C = a.C[z];
-    const unsigned char* in = a.in[z];
-    const int t0 = blockIdx.x << 5;
-    const int nst = C >> 5;                               // K steps of 32 columns (C % 32 == 0)
-    const int S0 = (int)(((long)blockIdx.y * nst) / a.ks), S1 = (int)(((long)(blockIdx.y + 1) * nst) / a.ks);
-    const int s_begin = S0 + (int)(((long)wave * (S1 - S0)) / NW), s_end = S0 + (int)(((long)(wave + 1) * (S1 - S0)) / NW);
-
-    const unsigned char* xrow[2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-        xrow[st] = in + ((size_t)min(t0 + 16 * st + i, a.T - 1) * C + 8 * g) * 2;
-    unsigned pres[2] = {1u, 1u};                          // bit m: modality m present in sub-tile (block uniform)
-    auto issue_x = [&](bf16x8 (&xb)[U][2], int s) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (s + u < s_end) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-                    if (pres[st]) xb[u][st] = *(const bf16x8*)(xrow[st] + (size_t)(s + u) * 64);
-            }
-        }
-    };
-    // The x stream does not depend on the routing: issue the first batch right away, the tok_mod
-    // bytes (which only select the weight rows / the skip) arrive underneath it.
-    bf16x8 xA[U][2], xB[U][2];
-    issue_x(xA, s_begin);
-    int mrow2[2];
-    unsigned mods4[2];                                    // modalities of my 4 result rows
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        mrow2[st] = a.tok_mod[t0 + 16 * st + i];
-        mods4[st] = *(const unsigned*)(a.tok_mod + t0 + 16 * st + 4 * g);
-    }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        unsigned p = 0;
-#pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow2[st] == m)) p |= 1u << m;
-        if (a.shared_w && p) p = 1u;                      // one chain, scale selected per row
-        pres[st] = p;
-    }
-    const unsigned pany = pres[0] | pres[1];
-    if (pany == 0) return;                                // padding tile (its speculative first batch is the only waste)
-
-    // ONE accumulator per sub-tile: MFMA rows are tokens, so in a sub-tile that straddles a span
-    // boundary the chain of modality m runs with the rows of the other modalities zeroed in the x
-    // operand and every result row only ever receives its own modality's product.
-    f32x4 acc[G][2][NT];
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[gi][st][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto mfma_step = [&](int gi, int st, int s1, bf16x8 xg, const bf16x8 (&w)[NT], int m, bool mask_rows) {
-        if (a.drop[gi].thr) {                                     // wave uniform; every projection has its own mask
-            const unsigned trow = (unsigned)min(t0 + 16 * st + i, a.T - 1);
-            xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(C >> 3) + (unsigned)(s1 * 4 + g)));
-        }
-        if (mask_rows) {                                          // mixed sub-tile: my row (token i) only counts in its own chain
-            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-            xg = (mrow2[st] == m) ? xg : z8;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[gi][st][nt] = MFMA16(xg, w[nt], acc[gi][st][nt]);
-    };
-
-    // The software-pipelined stream over this wave's K steps for a tile with NS (1 or 2) modalities.
-    // Two batches in flight: x (HBM latency) and, travelling with it, the weight fragments of all NS
-    // modalities (L2; measured: issuing them only one batch ahead exposes the loaded L2 latency and costs
-    // 15-40 %).  Every load of the loop is unconditional: a conditionally issued load
-    // makes the compiler's vmcnt bookkeeping conservative and serialises the batches -- and the kernel
-    // ends with its slowest block, i.e. with the tiles that straddle a span boundary.  One code path per
-    // NS keeps the common single-modality loop small (instruction cache).
-    auto stream = [&](auto ns_tag) {
-        constexpr int NS = decltype(ns_tag)::value;
-        int mods[NS];
-        mods[0] = __builtin_ctz(pany);
-        if (NS > 1) mods[NS - 1] = __builtin_ctz(pany & (pany - 1));
-        const unsigned char* wp[NS][G][NT];                       // per-lane fragment addresses
-        bf16x8 wA[NS][G][U][NT], wB[NS][G][U][NT];
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)   // rank rows >= r do not exist: clamp the row, its products are zeroed at the end
-                    wp[k][gi][nt] = a.W[G == 1 ? z : gi][mods[k]] + ((size_t)min(nt * 16 + i, a.r - 1) * C + 8 * g) * 2;
-        auto issue_w = [&](bf16x8 (&w)[NS][G][U][NT], int s) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-#pragma unroll
-                for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (s + u < s_end) {
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) w[k][gi][u][nt] = *(const bf16x8*)(wp[k][gi][nt] + (size_t)(s + u) * 64);
-                        }
-                    }
-        };
-        auto consume = [&](bf16x8 (&xb)[U][2], bf16x8 (&w)[NS][G][U][NT], int s) {
-#pragma unroll
-            for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (s + u < s_end) {
-#pragma unroll
-                        for (int st = 0; st < 2; ++st)
-#pragma unroll
-                            for (int k = 0; k < NS; ++k) {
-                                const unsigned bit = 1u << mods[k];
-                                if (pres[st] & bit) mfma_step(gi, st, s + u, xb[u][st], w[k][gi][u], mods[k], NS > 1 && pres[st] != bit);
-                            }
-                    }
-                }
-        };
-        issue_w(wA, s_begin);
-        for (int s = s_begin; s < s_end;) {
-            if (s + U < s_end) { issue_x(xB, s + U); issue_w(wB, s + U); }
-            consume(xA, wA, s);
-            s += U;
-            if (s >= s_end) break;
-            if (s + U < s_end) { issue_x(xA, s + U); issue_w(wA, s + U); }
-            consume(xB, wB, s);
-            s += U;
-        }
-    };
-
-    const int nmods = __builtin_popcount(pany);
-    if (!MIX || nmods == 1) {
-        stream(std::integral_constant<int, 1>{});
-    } else if (nmods == 2) {
-        stream(std::integral_constant<int, 2>{});
-    } else {
-        // three modalities inside one 32-token tile (needs two spans shorter than 32 tokens): plain loop
-#pragma unroll 1
-        for (int s = s_begin; s < s_end; ++s) {
-            bf16x8 x2[2];
-#pragma unroll
-            for (int st = 0; st < 2; ++st) x2[st] = (s == s_begin) ? xA[0][st] : *(const bf16x8*)(xrow[st] + (size_t)s * 64);
-#pragma unroll 1
-            for (int gi = 0; gi < G; ++gi) {
-#pragma unroll 1
-                for (int m = 0; m < a.M; ++m) {
-                    bf16x8 w[NT];
-                    const unsigned char* W = a.W[G == 1 ? z : gi][m];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        w[nt] = *(const bf16x8*)(W + ((size_t)min(nt * 16 + i, a.r - 1) * C + 8 * g) * 2 + (size_t)s * 64);
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-                        if (pres[st] & (1u << m)) {
-#pragma unroll
-                            for (int gj = 0; gj < G; ++gj)        // gi is a run-time index here
-                                if (gj == gi) mfma_step(gj, st, s, x2[st], w, m, pres[st] != (1u << m));
-                        }
-                }
-            }
-        }
-    }
-
-    // select per row, scale, and reduce the NW partial tiles through LDS
-    constexpr int REDSZ = NW * 2 * NT * 256;
-    float* red = (float*)smem;                            // [G][NW][2][NT][16 rows][16 cols]
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int mr = (mods4[st] >> (8 * reg)) & 255;
-                    float v = acc[gi][st][nt][reg] * mod_scale(a.s_mod, mr);        // 0 for rows of no modality
-                    if (mr >= a.M || nt * 16 + i >= a.r) v = 0.f;                   // padding rows, padded rank columns
-                    red[gi * REDSZ + (((wave * 2 + st) * NT + nt) << 8) + ((4 * g + reg) << 4) + i] = v;
-                }
-    __syncthreads();
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-        float* outp = a.out[G == 1 ? z : gi] + (size_t)blockIdx.y * a.T * RP;
-        for (int e = tid; e < 32 * RP; e += NW * 64) {
-            const int row = e / RP, k = e % RP;
-            const int st = row >> 4, r16 = row & 15, nt = k >> 4, kk = k & 15;
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) sum += red[gi * REDSZ + (((w * 2 + st) * NT + nt) << 8) + (r16 << 4) + kk];
-            const int t = t0 + row;
-            if (t < a.T) outp[(size_t)t * RP + k] = sum;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // X: rank-r cross-modal interaction
 // ------------------------------------------------------------------------------------------
 struct CrossArgs {
@@ -428,7 +196,6 @@ struct CrossArgs {
     float s_mod[4];                 // fwd: s_out per modality; bwd: s_in for every modality
     int ks, B, S, T, Tp, Lk_max, Lkp, r, C, M, RB;
     float w, c;
-    int abl;                        // diagnostics (moka_tune cross_abl): truncate the kernel after a phase
 };
 // blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems on the same routing (batched launch)
 struct CrossBatch { CrossArgs z[MOKA_MAX_GROUP]; };
@@ -590,7 +357,6 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int nrb = (a.S + RB - 1) / RB;                // row blocks; the blocks behind them only write the weight shadows
-    if (a.abl == 4) return;
     if ((int)blockIdx.y >= nrb) {
         cross_weight_shadows<RP>(a, ((int)blockIdx.y - nrb) * gridDim.x + blockIdx.x, ((int)gridDim.y - nrb) * gridDim.x, tid, NTH);
         return;
@@ -598,7 +364,6 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     const int b = blockIdx.x, r0 = blockIdx.y * RB;
     const int nrow = min(RB, a.S - r0);
     const size_t sstride = (size_t)a.T * RP;
-    if (a.abl == 1) return;
     // ---- round trip 1: routing (sample's key count, my row's modality, the key tokens of the first chunk)
     constexpr int IPT = (RB * R4) / NTH, SB = (8 / IPT) < 2 ? 2 : 8 / IPT;
     static_assert(RB * R4 == KC * R4 && (RB * R4) % NTH == 0, "one element of each array per thread and round");
@@ -639,7 +404,6 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
         }
     }
     if (tid < RB) s_mod[tid] = my_mod;
-    if (a.abl == 2) { if (Hs[tid] == 1234.5f) a.out_f32[tid] = Ks[tid]; return; }
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     if (anyq) {
         const int qrow = wave * 16 + i;                           // the lane's query row inside the block
@@ -717,7 +481,6 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
         }
     }
     __syncthreads();
-    if (a.abl == 3) { if (Hp[tid] == 1234.5f) a.out_f32[tid] = Hs[tid]; return; }
     if ((((b * a.S + r0) | nrow) & 3) == 0) {
         // wide stores (block uniform: the block's rows come in aligned groups of four): per (row, 4 ranks) one 16-byte store of
         // h and two 8-byte stores of the token-major pack; per (rank, 4 tokens) two 8-byte stores of the rank-major pack
@@ -808,7 +571,6 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab
     const int b = blockIdx.x, r0 = blockIdx.y * RB;
     const int nrow = min(RB, a.S - r0);
     const size_t sstride = (size_t)a.T * RP;
-    if (a.abl == 1) return;
 
     // ---- round trip 1: routing (key count, the rows' modality / key slot, the key tokens of the first chunk)
     const int Lk = a.klen[b];
@@ -855,7 +617,6 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab
         }
     }
     if (tid < RB) { s_mod[tid] = my_mod; s_slot[tid] = my_slot; }
-    if (a.abl == 2) { if (Hs[tid] == 1234.5f) a.pack_tok[tid] = (unsigned short)Ks[tid]; return; }
     const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     for (int e = tid; e < RB * RP; e += NTH) {                    // g = sum of the slice groups (fixed order)
         const int row = e / RP, k = e % RP;
@@ -1008,7 +769,6 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab
         }
     }
     if (tid == 0) a.dk_flag[b * gridDim.y + blockIdx.y] = anyq ? 1 : 0;
-    if (a.abl == 3) { if (Dh[tid] == 1234.5f) a.pack_tok[tid] = (unsigned short)Gs[tid]; return; }
     if ((((b * a.S + r0) | nrow) & 3) == 0) {
         // wide stores, as in the forward.  Key rows get provisional values here: part b (the next launch) rewrites every
         // entry of a key row with the final ones.
@@ -1726,7 +1486,6 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) accW[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float abl_sink = 0.f;
     auto compute = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int gi) {
         const int grp = grp0 + gi;
         const bool live = wactive && grp < ngroups;      // wave uniform
@@ -1742,16 +1501,12 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
                     accR = MFMA16(F[st][0], bwt[0][nt], accR);
                     accR = MFMA16((c0 + 32 < a.C) ? F[st][1] : z8r, bwt[1][nt], accR);   // branch-free, see moka_xa_kernel
                 }
-#if ABL_GY & 2
-                abl_sink += accR[0] + accR[1] + accR[2] + accR[3];
-#else
                 MFMA_SETTLE(accR);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = accR[reg];
-#endif
             }
         // ---- dB: transposed tile through the wave-private LDS region
-        if (WITH_DB && live && !(ABL_GY & 4)) {
+        if (WITH_DB && live) {
             const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -1774,9 +1529,6 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     };
     // sum the eight waves' slots of one phase (PH groups) and write the split-K slice rows
     auto reduce_phase = [&](int phase) {
-#if ABL_GY & 1
-        return;
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int e = tid; e < PH * RSLOT; e += 512) {
             float sum = 0.f;
@@ -1804,10 +1556,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
         else reduce_phase(gi / 2);
     }
 
-#if ABL_GY
-    if (abl_sink == 1234.5f) slice[tid] = abl_sink;
-#endif
-    if (WITH_DB && !(ABL_GY & 8)) {
+    if (WITH_DB) {
         // dB leaves as [column][rank] rows: wave w's accumulators hold columns cb0 + 64w .. of it, the destination rows of the waves
         // are disjoint, so there is no cross-wave sum -- only a wave-private transposition through LDS (own tile region for RP = 16,
         // own slot area -- free after the last reduce_phase barrier -- for the wider ranks, CTB column tiles at a time)
@@ -1896,13 +1645,8 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
             }
         }
     };
-    float abl_sink = 0.f;
     auto compute = [&](bf16x8 (&F)[2][2], int (&mr)[2], int gi_, int ph_) {
         const int grp = grp0 + gi_;
-#if ABL_XA >= 3
-        { union { bf16x8 b; float f[4]; } u0, u1, u2, u3; u0.b = F[0][0]; u1.b = F[0][1]; u2.b = F[1][0]; u3.b = F[1][1];
-          abl_sink += u0.f[0] + u0.f[3] + u1.f[0] + u1.f[3] + u2.f[0] + u2.f[3] + u3.f[0] + u3.f[3] + (float)mr[0] + (float)mr[1]; return; }
-#endif
         const bool live = wactive && grp < ngroups;
         const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1944,21 +1688,14 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-#if ABL_XA >= 2
-                    abl_sink += acc[nt][0] + acc[nt][1] + acc[nt][2] + acc[nt][3];
-#else
                     MFMA_SETTLE(acc[nt]);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) slot[(16 * st + 4 * g + reg) * RP + nt * 16 + i] = acc[nt][reg];
-#endif
                 }
             }
         }
     };
     auto reduce_phase = [&](int phase) {
-#if ABL_XA >= 1
-        return;
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
@@ -1992,9 +1729,6 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
         compute(FB, mrB, gi_ + 1, 1);
         reduce_phase(gi_ / 2);
     }
-#if ABL_XA >= 1
-    if (abl_sink == 1234.5f) a.part[0][tid] = abl_sink;
-#endif
 }
 
 // Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
@@ -2076,13 +1810,21 @@ static int check_launch(const char* what) {
     return MOKA_OK;
 }
 
-// Raise the dynamic-LDS cap of a kernel once (host-side cost only; cached per kernel pointer).
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+
+// Raise the dynamic-LDS cap of a kernel once per (device, kernel): hipFuncSetAttribute applies to the CURRENT device only, and a
+// process may drive several GPUs (device maps, model-parallel threads).  Host-side cost only; the table is thread-local.
 static void ensure_lds(const void* kernel, size_t lds) {
-    struct Slot { const void* k; size_t granted; };
-    static thread_local Slot slots[96];
+    struct Slot { const void* k; int dev; size_t granted; };
+    static thread_local Slot slots[160];
     static thread_local int nslots = 0;
+    const int dev = current_device();
     for (int s = 0; s < nslots; ++s)
-        if (slots[s].k == kernel) {
+        if (slots[s].k == kernel && slots[s].dev == dev) {
             if (lds <= slots[s].granted) return;
             (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             slots[s].granted = lds;
@@ -2090,20 +1832,21 @@ static void ensure_lds(const void* kernel, size_t lds) {
         }
     const size_t want = lds > 65536 ? lds : 65536;
     (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-    if (nslots < 96) { slots[nslots].k = kernel; slots[nslots].granted = want; ++nslots; }
+    if (nslots < 160) { slots[nslots].k = kernel; slots[nslots].dev = dev; slots[nslots].granted = want; ++nslots; }
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_cross_nth = 0, g_tune_no_xa = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_no_fused_gy = 0, g_tune_wgrad_nw = 0, g_tune_reduce_nw = 0, g_tune_reduce_u = 0, g_tune_reduce_ks = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0,
-           g_tune_cross_rows = 0, g_tune_cross_abl = 0;
+static int g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
 
-static int num_cu() {
-    static int n = 0;
+static int num_cu() {                                    // per device (a process may drive several GPUs)
+    static thread_local int cached[16] = {0};
+    const int dev = current_device();
+    int n = (dev < 16) ? cached[dev] : 0;
     if (n == 0) {
-        int dev = 0;
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n <= 0) n = 256;
+        if (dev < 16) cached[dev] = n;
     }
     return n;
 }
@@ -2111,18 +1854,6 @@ static int num_cu() {
 static int rank_pad(int r) {
     if (r < 1 || r > 64) return MOKA_EINVAL;
     return r <= 16 ? 16 : (r <= 32 ? 32 : 64);
-}
-
-// split-K factor of the reduce kernel: aim at ~2 blocks per CU, keep at least 16 K steps per slice
-static int reduce_ks(int T, int C) {
-    const int ntile = (T + 31) / 32;
-    int ks = (2 * num_cu() + ntile - 1) / ntile;
-    const int max_ks = (C / 32) / 16 > 0 ? (C / 32) / 16 : 1;
-    if (ks > max_ks) ks = max_ks;
-    if (ks > 8) ks = 8;
-    if (ks < 1) ks = 1;
-    if (g_tune_reduce_ks > 0 && g_tune_reduce_ks <= max_ks && g_tune_reduce_ks <= 8) ks = g_tune_reduce_ks;
-    return ks;
 }
 
 static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs* d) {
@@ -2150,50 +1881,11 @@ static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
     return MOKA_OK;
 }
 
-template <int RP, int NW, int U, int G, bool MIX>
-static void launch_reduce_t(const ReduceArgs& a, int nz, hipStream_t st) {
-    const size_t lds = (size_t)G * NW * 2 * (RP / 16) * 256 * 4;
-    dim3 grid((a.T + 31) / 32, a.ks, nz), block(NW * 64);
-    ensure_lds((const void*)moka_reduce_kernel<RP, NW, U, G, MIX>, lds);
-    hipLaunchKernelGGL((moka_reduce_kernel<RP, NW, U, G, MIX>), grid, block, lds, st, a);
-}
-
-// nz batched problems (grid z).  The kernel's G > 1 mode (shared input) is kept in the source but no longer
-// instantiated: for r <= 16 moka_xa_kernel does that job, wider ranks run one launch per projection.
-static int launch_reduce(const ReduceArgs& a, int RP, int /*G*/, int nz, hipStream_t st) {
-    if (RP == 16) {
-        const int nw = g_tune_reduce_nw == 8 ? 8 : 4, u = g_tune_reduce_u == 4 ? 4 : 2;
-        if (a.shared_w) {
-            if (nw == 4) { if (u == 4) launch_reduce_t<16, 4, 4, 1, false>(a, nz, st); else launch_reduce_t<16, 4, 2, 1, false>(a, nz, st); }
-            else { if (u == 4) launch_reduce_t<16, 8, 4, 1, false>(a, nz, st); else launch_reduce_t<16, 8, 2, 1, false>(a, nz, st); }
-        } else {
-            if (nw == 4) launch_reduce_t<16, 4, 2, 1, true>(a, nz, st); else launch_reduce_t<16, 8, 2, 1, true>(a, nz, st);
-        }
-    }
-    else if (RP == 32) { if (a.shared_w) launch_reduce_t<32, 8, 2, 1, false>(a, nz, st); else launch_reduce_t<32, 8, 2, 1, true>(a, nz, st); }
-    else { if (a.shared_w) launch_reduce_t<64, 8, 1, 1, false>(a, nz, st); else launch_reduce_t<64, 8, 1, 1, true>(a, nz, st); }
-    return check_launch("moka_reduce_kernel");
-}
-
-__global__ void moka_nop_kernel(int x) { if (x == 12345) __builtin_trap(); }
-struct BigArg { char pad[720]; };
-__global__ void moka_nop_big_kernel(BigArg x) { if (x.pad[3] == 123) __builtin_trap(); }
-
 template <int RP>
 static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
     constexpr int NWV = 4, RB = 16 * NWV, KC = 64, KP = RP + 1;
     const CrossArgs& a = ab.z[0];
     dim3 grid(a.B, (a.S + RB - 1) / RB, nz), block(NWV * 64);
-    if (!bwd && g_tune_cross_abl >= 9) {                  // diagnostics: (abl - 8) extra trivial launches in front of the real one
-        for (int q = 8; q < g_tune_cross_abl; ++q) hipLaunchKernelGGL(moka_nop_kernel, dim3(1), dim3(64), 0, st, 0);
-    } else
-    if (!bwd && g_tune_cross_abl >= 5) {                  // diagnostics: a trivial kernel in place of the forward cross kernel
-        if (g_tune_cross_abl == 5) hipLaunchKernelGGL(moka_nop_kernel, grid, block, 0, st, 0);
-        else if (g_tune_cross_abl == 6) hipLaunchKernelGGL(moka_nop_kernel, dim3(1), dim3(64), 0, st, 0);
-        else if (g_tune_cross_abl == 7) { BigArg ba; memset(&ba, 0, sizeof(ba)); hipLaunchKernelGGL(moka_nop_big_kernel, grid, block, 0, st, ba); }
-        else hipLaunchKernelGGL(moka_nop_kernel, grid, block, 13056, st, 0);
-        return;
-    }
     if (!bwd) {
         const size_t lds = (size_t)(2 * RB + KC) * KP * 4;
         ensure_lds((const void*)moka_cross_fwd_kernel<RP, NWV>, lds);
@@ -2232,7 +1924,6 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
         a.B = rt->B; a.S = rt->S; a.T = rt->B * rt->S; a.Tp = (a.T + 31) / 32 * 32; a.Lk_max = Lk; a.Lkp = Lk > 0 ? Lk : 1;
         a.r = r; a.M = rt->M;
         a.RB = 64;
-        a.abl = g_tune_cross_abl >= 9 ? 0 : g_tune_cross_abl;
     }
     // (the question span is unbounded, as in the reference -- layer.py:640-653, lora.py:489-499: keys are streamed through LDS in
     //  chunks of 64 with a running softmax; only the caller's workspace grows with Lk_max, moka_cross_ws_bytes)
@@ -2378,10 +2069,10 @@ static int launch_xa(const XaArgs& a, hipStream_t st) {
 }
 
 // number of part slices moka_down_fwd writes for input width C
-static int fwd_ks(int T, int C, int r) { return !g_tune_no_xa ? (C + 511) / 512 : reduce_ks(T, C); }
+static int fwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
 
 // number of g_part slices moka_up_bwd writes for output width C
-static int bwd_ks(int T, int C, int r) { return !g_tune_no_fused_gy || rank_pad(r) == 16 ? (C + 511) / 512 : reduce_ks(T, C); }
+static int bwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
 
 extern "C" {
 
@@ -2400,22 +2091,14 @@ int moka_device_check(void) {
 
 int moka_tune(const char* key, int value) {
     if (!key) return fail(MOKA_EINVAL, "moka_tune: null key");
-    if (!strcmp(key, "reduce_nw")) g_tune_reduce_nw = value;
-    else if (!strcmp(key, "reduce_u")) g_tune_reduce_u = value;
-    else if (!strcmp(key, "wgrad_nw")) g_tune_wgrad_nw = value;
-    else if (!strcmp(key, "no_fused_gy")) g_tune_no_fused_gy = value;
+    if (!strcmp(key, "wgrad_nw")) g_tune_wgrad_nw = value;
     else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
-    else if (!strcmp(key, "no_xa")) g_tune_no_xa = value;
-    else if (!strcmp(key, "cross_nth")) g_tune_cross_nth = value;
     else if (!strcmp(key, "xa_ng")) g_tune_xa_ng = value;
     else if (!strcmp(key, "expand_nq")) g_tune_expand_nq = value;
-    else if (!strcmp(key, "reduce_ks")) g_tune_reduce_ks = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
     else if (!strcmp(key, "wgrad_bpc")) g_tune_wgrad_bpc = value;
-    else if (!strcmp(key, "cross_rows")) g_tune_cross_rows = value;
-    else if (!strcmp(key, "cross_abl")) g_tune_cross_abl = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 }
@@ -2444,53 +2127,33 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
     if (G < 1 || G > MOKA_MAX_GROUP) return fail(MOKA_EINVAL, "moka_down_fwd: G=%d not in 1..%d", G, MOKA_MAX_GROUP);
     if (!x || !A || !tok_mod || !part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
     if (dropout_p != 0.f && !seeds) return fail(MOKA_EINVAL, "moka_down_fwd: dropout without seeds");
-    ReduceArgs a;
-    memset(&a, 0, sizeof(a));
+    DropArgs drop[MOKA_MAX_GROUP];
     float inv_keep = 1.f;
     for (int g = 0; g < G; ++g) {
-        rc = make_drop("moka_down_fwd", dropout_p, seeds ? seeds[g] : 0ull, &a.drop[g]);
+        rc = make_drop("moka_down_fwd", dropout_p, seeds ? seeds[g] : 0ull, &drop[g]);
         if (rc) return rc;
-        inv_keep = a.drop[g].inv_keep;
+        inv_keep = drop[g].inv_keep;
         if (!part[g]) return fail(MOKA_EINVAL, "moka_down_fwd: part[%d] is null", g);
         for (int m = 0; m < M; ++m)
             if (!A[g * M + m]) return fail(MOKA_EINVAL, "moka_down_fwd: A[%d] is null", g * M + m);
     }
-    if ((unsigned long long)T * (unsigned long long)(d_in >> 3) > 0xffffffffull && a.drop[0].thr)
+    if ((unsigned long long)T * (unsigned long long)(d_in >> 3) > 0xffffffffull && drop[0].thr)
         return fail(MOKA_EINVAL, "moka_down_fwd: T * d_in too large for the dropout counter");
-    for (int m = 0; m < M; ++m) a.s_mod[m] = s_in * inv_keep;
-    a.tok_mod = tok_mod; a.T = T; a.r = r; a.M = M; a.ks = reduce_ks(T, d_in);
-    a.in[0] = (const unsigned char*)x; a.C[0] = d_in;
     const int RP = rank_pad(r);
-    if (RP == 16 && !g_tune_no_xa) {
-        // r <= 16: weights of all modalities (and of all G projections) resident per wave, one split-K slice per 512 columns
+    // r <= 16: the weights of all modalities (and of all G projections) are resident per wave -> one launch for the group;
+    // wider ranks: the same kernel with RP / 16 rank tiles, one launch per projection.  One split-K slice per 512 columns.
+    const int per_launch = (RP == 16) ? G : 1;
+    for (int g0 = 0; g0 < G; g0 += per_launch) {
         XaArgs xa;
         memset(&xa, 0, sizeof(xa));
         xa.x = (const unsigned char*)x; xa.tok_mod = tok_mod; xa.T = T; xa.C = d_in; xa.r = r; xa.M = M;
-        for (int m = 0; m < M; ++m) xa.s_mod[m] = a.s_mod[m];
-        for (int g = 0; g < G; ++g) {
-            xa.part[g] = part[g]; xa.drop[g] = a.drop[g];
-            for (int m = 0; m < M; ++m) xa.A[g][m] = (const unsigned char*)A[g * M + m];
+        for (int m = 0; m < M; ++m) xa.s_mod[m] = s_in * inv_keep;
+        for (int g = 0; g < per_launch; ++g) {
+            xa.part[g] = part[g0 + g]; xa.drop[g] = drop[g0 + g];
+            for (int m = 0; m < M; ++m) xa.A[g][m] = (const unsigned char*)A[(g0 + g) * M + m];
         }
-        return G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
-    }
-    if (!g_tune_no_xa) {
-        // r > 16: the same kernel with RP / 16 rank tiles, one launch per projection
-        for (int g = 0; g < G; ++g) {
-            XaArgs xa;
-            memset(&xa, 0, sizeof(xa));
-            xa.x = (const unsigned char*)x; xa.tok_mod = tok_mod; xa.T = T; xa.C = d_in; xa.r = r; xa.M = M;
-            for (int m = 0; m < M; ++m) { xa.s_mod[m] = a.s_mod[m]; xa.A[0][m] = (const unsigned char*)A[g * M + m]; }
-            xa.part[0] = part[g]; xa.drop[0] = a.drop[g];
-            rc = RP == 32 ? launch_xa_wide<32>(xa, (hipStream_t)stream) : launch_xa_wide<64>(xa, (hipStream_t)stream);
-            if (rc) return rc;
-        }
-        return MOKA_OK;
-    }
-    for (int g = 0; g < G; ++g) {                      // r > 16 (or the no_xa diagnostic): one launch per projection
-        ReduceArgs b = a;
-        b.out[0] = part[g]; b.drop[0] = a.drop[g];
-        for (int m = 0; m < M; ++m) b.W[0][m] = (const unsigned char*)A[g * M + m];
-        rc = launch_reduce(b, RP, 1, 1, (hipStream_t)stream);
+        if (RP == 16) rc = G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
+        else rc = RP == 32 ? launch_xa_wide<32>(xa, (hipStream_t)stream) : launch_xa_wide<64>(xa, (hipStream_t)stream);
         if (rc) return rc;
     }
     return MOKA_OK;
@@ -2631,7 +2294,7 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         Cmax = d_out[g] > Cmax ? d_out[g] : Cmax;
     }
     int rc = MOKA_OK;
-    if (g_part && g_part[0] && !g_tune_no_fused_gy) {
+    if (g_part && g_part[0]) {
         // ONE pass over gy produces the g slices (one per 512-column block) and, if requested, dB
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
         // the dB half rides along only for r <= 16: with 32 / 64 ranks its atomics (64 x RP per wave and block) and the single
@@ -2650,20 +2313,6 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         }
         rc = with_db ? launch_gy<true>(gb, G, Cmax, RP, (hipStream_t)stream) : launch_gy<false>(gb, G, Cmax, RP, (hipStream_t)stream);
         if (rc || with_db || !(dB_acc && dB_acc[0])) return rc;
-    } else if (g_part && g_part[0]) {
-        // g = s_out[mod] * gy Bw: contraction over d_out with the transposed weight; one chain per tile
-        if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
-        ReduceArgs ra;
-        memset(&ra, 0, sizeof(ra));
-        ra.tok_mod = tok_mod;
-        for (int m = 0; m < M; ++m) ra.s_mod[m] = s_out[m];
-        ra.T = T; ra.r = RP; ra.M = M; ra.shared_w = 1; ra.ks = g_tune_no_fused_gy && RP == 16 ? (Cmax + 511) / 512 : reduce_ks(T, Cmax);     // BwT has RP zero-padded rows
-        for (int g = 0; g < G; ++g) {
-            if (!BwT[g]) return fail(MOKA_EINVAL, "moka_up_bwd: BwT[%d] is null", g);
-            ra.in[g] = (const unsigned char*)gy[g]; ra.W[g][0] = (const unsigned char*)BwT[g]; ra.out[g] = g_part[g]; ra.C[g] = d_out[g];
-        }
-        rc = launch_reduce(ra, RP, 1, G, (hipStream_t)stream);
-        if (rc) return rc;
     }
     if (dB_acc && dB_acc[0]) {
         if (!hp_kmj) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without hp_kmj");

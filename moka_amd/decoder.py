@@ -142,6 +142,8 @@ def decode_weight(proj: nn.Module) -> Tuple[torch.Tensor, Optional[torch.Tensor]
     elif hasattr(proj, "lora_A") and "text" in getattr(proj, "lora_A", {}):     # VT mirror (wrapped base layer)
         base = proj.get_base_layer()
         W, A, Bw, s, bias = base.weight, proj.lora_A["text"].weight, proj.lora_B["text"].weight, proj.scaling["text"], base.bias
+        if getattr(proj, "fan_in_fan_out", False):
+            W = W.T
     else:                                                          # a projection the adapter was not attached to
         return proj.weight, getattr(proj, "bias", None)
     Wd = (W.float() + s * (Bw.float() @ A.float())).to(W.dtype)
@@ -175,13 +177,19 @@ class MokaLlamaAttention(nn.Module):
         k = k.view(B, S, d.n_kv_heads, d.head_dim).transpose(1, 2)
         v = v.view(B, S, d.n_kv_heads, d.head_dim).transpose(1, 2)
         q, k = _rotate(q, cos, sin), _rotate(k, cos, sin)
-        if kv_cache is not None:
+        past = 0 if kv_cache is None else kv_cache[0].shape[2]
+        if past > 0:
             k, v = torch.cat([kv_cache[0], k], dim=2), torch.cat([kv_cache[1], v], dim=2)
         new_cache = (k, v)
         if d.n_kv_heads != d.n_heads:
             rep = d.n_heads // d.n_kv_heads
             k, v = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
-        o = TF.scaled_dot_product_attention(q, k, v, is_causal=(kv_cache is None and S > 1))
+        if past > 0 and S > 1:
+            # several new tokens behind a cache (chunked prefill, speculative decoding): causal inside the chunk, offset by the past
+            allow = torch.ones(S, past + S, dtype=torch.bool, device=x.device).tril(diagonal=past)
+            o = TF.scaled_dot_product_attention(q, k, v, attn_mask=allow)
+        else:
+            o = TF.scaled_dot_product_attention(q, k, v, is_causal=(S > 1))     # (an empty cache is no cache)
         o = o.transpose(1, 2).reshape(B, S, d.n_heads * d.head_dim)
         return _project(self.o_proj, o, mask_args, merged), new_cache
 

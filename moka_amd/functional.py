@@ -290,6 +290,21 @@ def _grad_accumulators(shapes: Sequence[Tuple[int, int]], device) -> Tuple[torch
     return flat, views
 
 
+def _check_sinks(dB_acc, dA_acc, d_out: int, r: int, d_in: int, M: int, device) -> None:
+    ts = ([dB_acc] if dB_acc is not None else []) + (list(dA_acc) if dA_acc is not None else [])
+    if dA_acc is not None and len(dA_acc) != M:
+        raise ValueError(f"moka_amd: {len(dA_acc)} gradient sinks for {M} lora_A matrices")
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+            raise TypeError("moka_amd: gradient sinks must be contiguous fp32 tensors on the device of the activations")
+    if dB_acc is not None and tuple(dB_acc.shape) != (d_out, r):
+        raise ValueError(f"moka_amd: lora_B gradient sink is {tuple(dB_acc.shape)}, expected {(d_out, r)}")
+    if dA_acc is not None:
+        for t in dA_acc:
+            if tuple(t.shape) != (r, d_in):
+                raise ValueError(f"moka_amd: lora_A gradient sink is {tuple(t.shape)}, expected {(r, d_in)}")
+
+
 def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[torch.Tensor]:
     out, off = [], 0
     for a, b in shapes:
@@ -304,13 +319,17 @@ def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[t
 class AdapterSpec:
     """Static description of one adapted projection (what varies between AVT and VT)."""
 
-    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed")
+    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed", "sinks")
 
     def __init__(self, r: int, s_in: float, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
-                 dropout_p: float = 0.0, seed: Optional[int] = None):
+                 dropout_p: float = 0.0, seed: Optional[int] = None, sinks=None):
         self.r, self.s_in, self.s_out, self.w, self.inv_sqrt_dk = int(r), float(s_in), [float(s) for s in s_out], float(w), float(inv_sqrt_dk)
         self.dropout_p = float(dropout_p)
         self.seed = (draw_seed() if seed is None else int(seed)) if self.dropout_p > 0.0 else 0
+        # sinks = (dB_acc [d_out, r] fp32, [dA_acc_m [r, d_in] fp32 ...]): views of a flat gradient buffer
+        # (moka_amd.parallel.attach) the weight-gradient kernels accumulate into DIRECTLY; the autograd node then returns no
+        # gradient for lora_B / lora_A (the data-parallel step works on the flat buffer).  None: ordinary autograd gradients.
+        self.sinks = sinks
 
 
 class MokaLinearFn(torch.autograd.Function):
@@ -361,10 +380,17 @@ class MokaLinearFn(torch.autograd.Function):
         need_A = any(ctx.needs_input_grad[6:])
         if ctx.needs_input_grad[1]:
             raise _lib.MokaError("moka_amd: the base weight is frozen in MokA; requires_grad on it is not supported")
-        shapes = ([(Bw.shape[0], r)] if need_B else []) + ([(r, x2.shape[1])] * len(A) if need_A else [])
-        flat, acc = _grad_accumulators(shapes, gy2.device) if shapes else (None, [])
-        dB_acc = acc[0] if need_B else None
-        dA_acc = acc[(1 if need_B else 0):] if need_A else None
+        if spec.sinks is not None:
+            # the flat data-parallel gradient buffer is the accumulator (no temporaries, no cast, nothing returned to autograd)
+            dB_acc = spec.sinks[0] if need_B else None
+            dA_acc = list(spec.sinks[1]) if need_A else None
+            _check_sinks(dB_acc, dA_acc, Bw.shape[0], r, x2.shape[1], len(A), gy2.device)
+            flat, shapes = None, []
+        else:
+            shapes = ([(Bw.shape[0], r)] if need_B else []) + ([(r, x2.shape[1])] * len(A) if need_A else [])
+            flat, acc = _grad_accumulators(shapes, gy2.device) if shapes else (None, [])
+            dB_acc = acc[0] if need_B else None
+            dA_acc = acc[(1 if need_B else 0):] if need_A else None
         g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc)
         dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
         if need_A or need_x:
@@ -472,8 +498,17 @@ class MokaLinearGroupFn(torch.autograd.Function):
         need_x = nig[0]
         need_B = any(nig[base + g * per + 2] for g in range(G))
         need_A = any(nig[base + g * per + 3 + m] for g in range(G) for m in range(M))
-        shapes = ([(Bws[g].shape[0], r) for g in range(G)] if need_B else []) + ([(r, x2.shape[1])] * (G * M) if need_A else [])
-        flat, acc = _grad_accumulators(shapes, dev) if shapes else (None, [])
+        use_sinks = all(s_.sinks is not None for s_ in specs)
+        if use_sinks:
+            for g in range(G):
+                _check_sinks(specs[g].sinks[0] if need_B else None, list(specs[g].sinks[1]) if need_A else None,
+                             Bws[g].shape[0], r, x2.shape[1], M, dev)
+            shapes, flat = [], None
+            acc = ([specs[g].sinks[0] for g in range(G)] if need_B else []) + \
+                  ([a_ for g in range(G) for a_ in specs[g].sinks[1]] if need_A else [])
+        else:
+            shapes = ([(Bws[g].shape[0], r) for g in range(G)] if need_B else []) + ([(r, x2.shape[1])] * (G * M) if need_A else [])
+            flat, acc = _grad_accumulators(shapes, dev) if shapes else (None, [])
         dB_accs = acc[:G] if need_B else None
         g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs)
         dx2 = None
@@ -492,9 +527,9 @@ class MokaLinearGroupFn(torch.autograd.Function):
         grads = []
         for g in range(G):
             gbias = gy2[g].sum(0) if (ctx.has_bias[g] and nig[base + g * per + 1]) else None
-            gB = cast[g] if (need_B and nig[base + g * per + 2]) else None
+            gB = cast[g] if (cast and need_B and nig[base + g * per + 2]) else None
             a0 = G if need_B else 0
-            gA = [cast[a0 + g * M + m] if (need_A and nig[base + g * per + 3 + m]) else None for m in range(M)]
+            gA = [cast[a0 + g * M + m] if (cast and need_A and nig[base + g * per + 3 + m]) else None for m in range(M)]
             grads += [None, gbias, gB, *gA]
         return (None if dx2 is None else dx2.reshape(ctx.x_shape), None, None, None, None, *grads)
 

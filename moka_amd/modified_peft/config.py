@@ -35,7 +35,15 @@ class PeftConfig:
     inference_mode: bool = False
 
     def to_dict(self):
-        return {k: (v.value if isinstance(v, enum.Enum) else v) for k, v in asdict(self).items()}
+        # enums by value; sets (LoraConfig turns a list `target_modules` into a set) as sorted lists, as the reference's
+        # save_pretrained does before json.dumps (modified_peft/config.py:67-70)
+        def plain(v):
+            if isinstance(v, enum.Enum):
+                return v.value
+            if isinstance(v, (set, frozenset)):
+                return sorted(v)
+            return v
+        return {k: plain(v) for k, v in asdict(self).items()}
 
     def save_pretrained(self, save_directory, **kwargs):
         if os.path.isfile(save_directory):

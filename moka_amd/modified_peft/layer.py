@@ -200,6 +200,14 @@ class Linear(nn.Module, LoraLayer):
         W, bias, Bw, A, rt, spec = self._plan(x, my_text_mask, my_image_mask, question_mask)
         return moka_linear(x, W, bias, Bw, A, rt, spec)
 
+    # gradient sinks installed by moka_amd.parallel.attach(): {"B": fp32 view for lora_B['text'], "A": [views for lora_A['text'],
+    # lora_A['image']]} of the flat data-parallel gradient buffer (None: ordinary autograd gradients)
+    _moka_sinks = None
+
+    def _sinks(self, n_adapters: int):
+        sk = self._moka_sinks
+        return None if sk is None else (sk["B"], sk["A"][:n_adapters])
+
     def _plan(self, x, my_text_mask, my_image_mask, question_mask, *args, **kwargs):
         """(W, bias, Bw, [A_m], routing, spec) of the adapter path of this call (``layer.py:589-678``), or None when
         the call takes one of the base-layer fallbacks.  Shared with the grouped decoder shim (``moka_amd/decoder.py``)."""
@@ -219,12 +227,13 @@ class Linear(nn.Module, LoraLayer):
         if my_text_mask is not None:
             A_i = self.lora_A["image"].weight
             rt = GLOBAL_ROUTING_CACHE.get("vt", [my_text_mask, my_image_mask, question_mask])
-            spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r), dropout_p=p)
+            spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r), dropout_p=p,
+                               sinks=self._sinks(2))
             return (W, base.bias, B_t, [A_t, A_i], rt, spec)
         # masks None (cached decode steps): plain LoRA with the text adapter (layer.py:672-678)
         B_, S_ = (x.shape[0], x.shape[1]) if x.dim() == 3 else (1, x.shape[0])
         rt = GLOBAL_ROUTING_CACHE.plain(B_, S_, x.device, 1)
-        spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r), dropout_p=p)
+        spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r), dropout_p=p, sinks=self._sinks(1))
         return (W, base.bias, B_t, [A_t], rt, spec)
 
     def __repr__(self) -> str:

@@ -20,20 +20,27 @@ tensors (tests/test_parallel_gloo.py).
 from __future__ import annotations
 
 import math
+import re
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+from torch import nn
 
 
 class FlatGradBucket:
     """Flat fp32 gradient buffer + per-layer slice boundaries + bucketed asynchronous all-reduce."""
 
     def __init__(self, numel: int, layer_end: Sequence[int], device, n_buckets: int = 8,
-                 process_group=None, dtype=torch.float32):
+                 process_group=None, dtype=torch.float32, comm_dtype: Optional[torch.dtype] = None):
+        """comm_dtype: payload type of the all-reduce (None = the buffer's own fp32).  torch.bfloat16 halves the bytes on
+        xGMI (7B r=16: 153 instead of 306 MB per step -- the figure SURVEY.md 8(e) sized): a bucket is rounded to bf16 into a
+        staging buffer, summed there and widened back; accumulation across micro-batches stays fp32."""
         if not layer_end or layer_end[-1] != numel:
             raise ValueError("layer_end must be increasing offsets ending at numel")
         self.flat = torch.zeros(numel, dtype=dtype, device=device)
+        self.comm_dtype = None if comm_dtype in (None, dtype) else comm_dtype
+        self._stage = torch.empty(numel, dtype=self.comm_dtype, device=device) if self.comm_dtype is not None else None
         self.layer_end = list(layer_end)
         self.n_layers = len(self.layer_end)
         self.group = process_group
@@ -69,9 +76,19 @@ class FlatGradBucket:
             ev.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._pending.append(dist.all_reduce(sl, group=self.group, async_op=True))
+                if self._stage is not None:
+                    st = self._stage[lo:hi]
+                    st.copy_(sl)                                   # fp32 -> bf16 on the side stream
+                    self._pending.append((dist.all_reduce(st, group=self.group, async_op=True), lo, hi))
+                else:
+                    self._pending.append((dist.all_reduce(sl, group=self.group, async_op=True), lo, hi))
         else:
-            self._pending.append(dist.all_reduce(sl, group=self.group, async_op=True))
+            if self._stage is not None:
+                st = self._stage[lo:hi]
+                st.copy_(sl)
+                self._pending.append((dist.all_reduce(st, group=self.group, async_op=True), lo, hi))
+            else:
+                self._pending.append((dist.all_reduce(sl, group=self.group, async_op=True), lo, hi))
 
     def finish(self, average: bool = True):
         """Join the outstanding collectives; afterwards ``flat`` holds the (averaged) global gradient."""
@@ -80,13 +97,17 @@ class FlatGradBucket:
         if self.is_cuda:
             done = torch.cuda.Event()
             with torch.cuda.stream(self.comm_stream):
-                for wk in self._pending:
+                for wk, lo, hi in self._pending:
                     wk.wait()
+                    if self._stage is not None:
+                        self.flat[lo:hi].copy_(self._stage[lo:hi])     # widen the summed payload back
                 done.record(self.comm_stream)
             torch.cuda.current_stream(self.flat.device).wait_event(done)
         else:
-            for wk in self._pending:
+            for wk, lo, hi in self._pending:
                 wk.wait()
+                if self._stage is not None:
+                    self.flat[lo:hi].copy_(self._stage[lo:hi])
         self._pending.clear()
         if average:
             self.flat.div_(self.world)
@@ -139,6 +160,150 @@ class FlatAdamW:
                 setattr(self, k, float(sd[k]))
         if "betas" in sd:
             self.betas = (float(sd["betas"][0]), float(sd["betas"][1]))
+
+
+_LAYER_RE = re.compile(r"(?:^|\.)layers\.(\d+)\.")
+
+
+class AdapterDataParallel:
+    """What ``attach`` returns: the flat buffers of a model's adapter, the bucketed gradient all-reduce hooked to the
+    backward of its decoder layers, and the fused optimizer step.
+
+        dp = moka_amd.parallel.attach(model)        # after get_peft_model / PeftMixedModel + set_adapter
+        for batch in loader:
+            loss = model(**batch).loss
+            loss.backward()                         # weight-gradient kernels add into dp.bucket.flat; a finished bucket of
+            dp.step()                               #   layers is all-reduced (RCCL, side stream) while the backward goes on
+    """
+
+    def __init__(self, model: nn.Module, bucket: FlatGradBucket, master: torch.Tensor, work: torch.Tensor, names: List[str],
+                 offsets: List[int], optimizer: Optional[FlatAdamW], handles: list):
+        self.model, self.bucket, self.master, self.work = model, bucket, master, work
+        self.names, self.offsets, self.optimizer, self._handles = names, offsets, optimizer, handles
+        self._done = set()
+        self.sync = True                             # False while accumulating micro-batches: the hooks ship nothing (cf. DDP.no_sync)
+
+    def _layer_done(self, l: int) -> None:
+        if not self.sync or l in self._done:
+            return
+        self._done.add(l)
+        self.bucket.layer_done(l)
+
+    def finish(self, average: bool = True) -> None:
+        """Join the all-reduces (every bucket whose hook did not fire -- frozen layers, models without `.layers.N.` modules --
+        is shipped now).  With ``average`` the flat buffer then holds the mean gradient over the ranks."""
+        for l in range(self.bucket.n_layers - 1, -1, -1):
+            if l not in self._done and (l % self.bucket.layers_per_bucket) == 0:
+                self.bucket.layer_done(l)
+        self._done.clear()
+        self.bucket.finish(average=average)
+
+    def step(self) -> None:
+        """finish() + the fused AdamW kernel (averaging folded into it, gradients left zeroed, bf16 parameters refreshed)."""
+        if self.optimizer is None:
+            raise RuntimeError("attach(..., optimizer=False): call finish() and run your own optimizer on dp.master / dp.bucket.flat")
+        self.finish(average=False)
+        self.optimizer.step(grad_scale=1.0 / self.bucket.world, zero_grad=True)
+
+    def grad_norm(self) -> torch.Tensor:
+        """l2 norm of the (summed, not yet averaged) flat gradient -- for clipping / logging."""
+        return self.bucket.flat.norm()
+
+    def detach(self) -> None:
+        for h in self._handles:
+            h.remove()
+        for m in self.model.modules():
+            if getattr(m, "_moka_sinks", None) is not None:
+                m._moka_sinks = None
+
+
+def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: bool = True, lr: float = 1e-4,
+           betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+           comm_dtype: Optional[torch.dtype] = None) -> AdapterDataParallel:
+    """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
+    base and the full adapter, batches are sharded by sample, and the only exchange is the adapter-gradient sum.
+
+    * every trainable ``lora_`` parameter of ``model`` (the selection of the reference scripts: ``finetune.py:151-160``,
+      ``train.py:576``) is re-seated, in module order, into ONE flat bf16 working buffer (what the kernels read) with an fp32
+      master copy and ONE flat fp32 gradient buffer, grouped by decoder layer (``...layers.<i>...`` in the parameter name);
+    * the adapted projections get views of that gradient buffer as *sinks*: their weight-gradient kernels accumulate
+      straight into it (fp32, across micro-batches too) and autograd carries no adapter gradients at all;
+    * a gradient hook on every decoder layer's input reports the layer as finished; ``FlatGradBucket`` starts the RCCL
+      all-reduce of a finished bucket of layers on a side stream while the remaining layers' backward runs;
+    * ``step()`` joins, and one kernel (``moka_adamw_flat``) averages, applies AdamW, refreshes the bf16 parameters and
+      zeroes the gradients.
+
+    Replaces DeepSpeed ZeRO-2's bucketed reduce-scatter + partitioned optimizer of the reference configurations
+    (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``) for the only trainable part."""
+    named = [(n, p) for n, p in model.named_parameters() if "lora_" in n and p.requires_grad]
+    if not named:
+        raise ValueError("attach: the model has no trainable lora_ parameters (call get_peft_model / set_adapter first)")
+    dev = named[0][1].device
+    if any(p.device != dev for _, p in named):
+        raise ValueError("attach: the adapter parameters must live on one device (one process per GPU)")
+    layer_of = []
+    for n, _ in named:
+        m = _LAYER_RE.search(n)
+        layer_of.append(int(m.group(1)) if m else -1)
+    ids = sorted(set(layer_of))
+    order = sorted(range(len(named)), key=lambda k: (layer_of[k], k))            # layer by layer, module order inside a layer
+    names, offsets, sizes, ends = [], [], [], []
+    off, cur = 0, None
+    for k in order:
+        if cur is not None and layer_of[k] != cur:
+            ends.append(off)
+        cur = layer_of[k]
+        names.append(named[k][0])
+        offsets.append(off)
+        sizes.append(named[k][1].numel())
+        off += (named[k][1].numel() + 7) // 8 * 8                               # 16-byte aligned bf16 / 32-byte fp32 views
+    ends.append(off)
+    bucket = FlatGradBucket(off, ends, dev, n_buckets=n_buckets, process_group=process_group, comm_dtype=comm_dtype)
+    master = torch.zeros(off, dtype=torch.float32, device=dev)
+    work = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+    by_name = dict(named)
+    grad_view = {}
+    with torch.no_grad():
+        for n, o, sz in zip(names, offsets, sizes):
+            p = by_name[n]
+            if p.dtype != torch.bfloat16:
+                raise TypeError(f"attach: {n} is {p.dtype}; the flat working copy is bf16 (the HIP path stores the adapter in bf16)")
+            master[o:o + sz].copy_(p.detach().reshape(-1))
+            work[o:o + sz].copy_(p.detach().reshape(-1))
+            p.data = work[o:o + sz].view(p.shape)                                # the module parameter IS the working copy
+            grad_view[n] = bucket.flat[o:o + sz].view(p.shape)
+    # sinks of the adapted projections (both mirrors)
+    for mod_name, mod in model.named_modules():
+        pre = mod_name + "." if mod_name else ""
+        if hasattr(mod, "lora_B0") and hasattr(mod, "_plan"):                    # AVT mirror: lora_A0.., lora_B0
+            a = [grad_view.get(f"{pre}lora_A{i}.weight") for i in range(getattr(mod, "lora_num", 0))]
+            b = grad_view.get(f"{pre}lora_B0.weight")
+            if b is not None and all(v is not None for v in a):
+                mod._moka_sinks = {"B": b, "A": a}
+        elif hasattr(mod, "lora_A") and hasattr(mod, "_plan") and "text" in getattr(mod, "lora_A", {}):   # VT mirror
+            a = [grad_view.get(f"{pre}lora_A.text.weight"), grad_view.get(f"{pre}lora_A.image.weight")]
+            b = grad_view.get(f"{pre}lora_B.text.weight")
+            if b is not None and all(v is not None for v in a):
+                mod._moka_sinks = {"B": b, "A": a}
+    opt = FlatAdamW(master, bucket.flat, work, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if optimizer else None
+    dp = AdapterDataParallel(model, bucket, master, work, names, offsets, opt, [])
+    # backward hooks: bucket index l = position of the layer id among the layers that own adapter parameters
+    pos = {lid: i for i, lid in enumerate(ids)}
+    # "layer l has finished its backward" = the gradient w.r.t. the layer's INPUT has been formed (every backward node of the
+    # layer, the adapter kernels of its projections included, runs before that).  A tensor hook on the input says exactly that; a
+    # module full-backward hook does not (it fires at the START of the layer's backward when the input needs no gradient -- the
+    # first layer).  Layers whose input carries no gradient are shipped by finish().
+    def pre_hook(l):
+        def hook(_mod, args, kwargs=None):
+            x = args[0] if args else None
+            if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+                x.register_hook(lambda _g, l=l: dp._layer_done(l))
+        return hook
+    for mod_name, mod in model.named_modules():
+        m = re.search(r"(?:^|\.)layers\.(\d+)$", mod_name)
+        if m and int(m.group(1)) in pos:
+            dp._handles.append(mod.register_forward_pre_hook(pre_hook(pos[int(m.group(1))])))
+    return dp
 
 
 def bind_param_grads(params: Sequence[torch.nn.Parameter], bucket: FlatGradBucket, offsets: Sequence[int]):

@@ -73,10 +73,19 @@ class Linear(nn.Linear, LoraLayer):
             nn.init.zeros_(self.lora_B0.weight)
 
     # -- the hot path -------------------------------------------------------------------------
+    # gradient sinks installed by moka_amd.parallel.attach(): {"B": fp32 [d_out, r] view, "A": [fp32 [r, d_in] views]} of the flat
+    # data-parallel gradient buffer -- the weight-gradient kernels accumulate into them directly (None: autograd gradients)
+    _moka_sinks = None
+
+    def _sinks(self, n_adapters: int):
+        sk = self._moka_sinks
+        return None if sk is None else (sk["B"], sk["A"][:n_adapters])
+
     def _spec(self) -> AdapterSpec:
         # lora_dropout acts on x before every A_m (lora.py:477); one counter-based mask per call
         p = self.lora_dropout_p if self.training else 0.0
-        return AdapterSpec(self.d_k, self.scaling[0], [1.0] * self.lora_num, self.blc_weight, 1.0 / math.sqrt(self.d_k), dropout_p=p)
+        return AdapterSpec(self.d_k, self.scaling[0], [1.0] * self.lora_num, self.blc_weight, 1.0 / math.sqrt(self.d_k), dropout_p=p,
+                           sinks=self._sinks(self.lora_num))
 
     def _adapter_weights(self, dtype):
         A = [getattr(self, f"lora_A{i}").weight for i in range(self.lora_num)]
@@ -95,9 +104,13 @@ class Linear(nn.Linear, LoraLayer):
             # decode step: only the text adapter, no masks (lora.py:373-381)
             rt = GLOBAL_ROUTING_CACHE.plain(x.shape[0], x.shape[1], x.device, 1)
             return (W, self.bias, Bw, A[:1], rt,
-                    AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed))
+                    AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed, sinks=self._sinks(1)))
         if "test" in method or "train" in method:
             # prefill / train: token-routed adapters + cross-modal interaction (lora.py:385-532)
+            if modality_mask is None:
+                # the reference subscripts the list unconditionally (lora.py:463-466): same exception type, clearer text
+                raise TypeError("modality_mask is None: the AVT layer needs [text, video, audio, question] masks unless "
+                                "loramethod contains 'test' and the input is a single decode position")
             rt = GLOBAL_ROUTING_CACHE.get("avt", list(modality_mask[:4]))
             return (W, self.bias, Bw, A, rt, spec)
         return None                      # the reference falls off the end of forward (lora.py:532)

@@ -11,6 +11,7 @@ errors), and the result is cached on the identity of the mask tensors.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -215,40 +216,79 @@ class MokaRouting:
 
 
 class RoutingCache:
-    """Routing keyed on the identity (storage pointer, shape, version) of the mask tensors: the
-    decoder passes the very same mask objects to all 7 x n_layers projections of a forward."""
+    """Routing keyed on the identity of the mask tensors (storage pointer, offset, shape, strides, dtype, version
+    counter): the decoder passes the very same mask objects to all 7 x n_layers projections of a forward, so one
+    host read-back serves the whole batch.
+
+    What the key cannot see is a rewrite that does not bump the version counter (``mask.data[...] = ...``, a raw
+    pointer write): such a batch would be routed with the previous batch's masks.  The reference's own pipeline builds
+    fresh mask tensors per batch (``unified_arch.py:306-324``, ``train.py:210-231``), which is always safe; for code
+    that recycles mask buffers either pass explicit routings (``MokaRouting.from_*``) or set ``MOKA_ROUTING_VERIFY=1``:
+    every hit then compares a device-side fingerprint of the masks (one host sync per call -- a debugging mode).
+    Tensors without a version counter (created under ``torch.inference_mode()``) are never cached: their routing is
+    built on the spot, once per call."""
 
     def __init__(self, capacity: int = 8):
         self.capacity = capacity
         self._items: List[tuple] = []
+        self.verify = os.environ.get("MOKA_ROUTING_VERIFY", "0") not in ("", "0")
 
     @staticmethod
     def _key(kind: str, masks: Sequence[torch.Tensor]):
-        return (kind,) + tuple((m.data_ptr(), tuple(m.shape), m._version, m.dtype) for m in masks)
+        parts = []
+        for m in masks:
+            try:
+                ver = m._version
+            except RuntimeError:                 # inference tensors do not track a version counter
+                return None
+            parts.append((m.data_ptr(), m.storage_offset(), tuple(m.shape), tuple(m.stride()), ver, m.dtype, str(m.device)))
+        return (kind,) + tuple(parts)
+
+    @staticmethod
+    def _fingerprint(masks: Sequence[torch.Tensor]) -> torch.Tensor:
+        """Position-weighted sums of the masks (device tensor, no sync): changes whenever a mask bit moves."""
+        out = []
+        for m in masks:
+            f = m.reshape(-1).to(torch.int64)
+            w = torch.arange(1, f.numel() + 1, device=f.device, dtype=torch.int64)
+            out.append((f * w).sum())
+        return torch.stack(out)
+
+    @staticmethod
+    def _build(kind: str, masks: Sequence[torch.Tensor]) -> MokaRouting:
+        if kind == "avt":
+            return MokaRouting.from_avt_masks(masks)
+        if kind == "vt":
+            return MokaRouting.from_vt_masks(*masks)
+        raise ValueError(kind)
+
+    def clear(self) -> None:
+        self._items.clear()
 
     def get(self, kind: str, masks: Sequence[torch.Tensor]) -> MokaRouting:
         key = self._key(kind, masks)
-        for k, rt, _keep in self._items:
+        if key is None:
+            return self._build(kind, masks)
+        for idx, (k, rt, _keep, fp) in enumerate(self._items):
             if k == key:
+                if self.verify and fp is not None and not torch.equal(fp, self._fingerprint(masks)):
+                    del self._items[idx]         # rewritten behind the version counter: rebuild
+                    break
                 return rt
-        if kind == "avt":
-            rt = MokaRouting.from_avt_masks(masks)
-        elif kind == "vt":
-            rt = MokaRouting.from_vt_masks(*masks)
-        else:
-            raise ValueError(kind)
-        self._items.append((key, rt, list(masks)))     # keep the masks alive so data_ptr stays unique
+        rt = self._build(kind, masks)
+        fp = self._fingerprint(masks) if self.verify else None
+        self._items.append((key, rt, list(masks), fp))     # keep the masks alive so data_ptr stays unique
         if len(self._items) > self.capacity:
             self._items.pop(0)
         return rt
 
     def plain(self, B: int, S: int, device, M: int) -> MokaRouting:
         key = ("plain", B, S, str(device), M)
-        for k, rt, _keep in self._items:
+        for k, rt, _keep, _fp in self._items:
             if k == key:
                 return rt
         rt = MokaRouting.plain(B, S, device, M)
-        self._items.append((key, rt, None))
+        self._items.append((key, rt, None, None))
         if len(self._items) > self.capacity:
             self._items.pop(0)
         return rt

@@ -211,6 +211,42 @@ def test_prefill_with_masks_then_cached_decode_equals_full_forward():
     assert rel(step, full[:, S - 1:]) < 2e-2
 
 
+@pytest.mark.gpu
+def test_chunk_of_several_tokens_behind_a_cache_is_causal():
+    """S > 1 with a cache (chunked prefill / speculative decoding) must stay causal inside the chunk, and an
+    empty-but-present cache is no cache.  The chunk's tokens are text tokens, so the mask-free branch equals the full forward."""
+    dev = _dev()
+    torch.manual_seed(1)
+    from moka_amd.modified_peft import Linear as VtLinear
+
+    def make(d_in, d_out):
+        base = torch.nn.Linear(d_in, d_out, bias=False)
+        m = VtLinear(base, "image", r=8, lora_alpha=16, lora_dropout=0.0, attn_weight=0.05)
+        m.update_layer("text", 8, lora_alpha=16, lora_dropout=0.0, init_lora_weights=True, use_rslora=False)
+        m.set_adapter(["image", "text"])
+        for n in ("image", "text"):
+            torch.nn.init.normal_(m.lora_B[n].weight, std=0.05)
+        return m
+
+    st = MokaLlamaStack(DIMS, 2, make).to(dev, torch.bfloat16).eval()
+    B, S, C = 1, 80, 3
+    text = torch.ones(B, S, dtype=torch.bool, device=dev)
+    image = torch.zeros(B, S, dtype=torch.bool, device=dev)
+    image[:, 4:36] = True
+    text &= ~image
+    q = torch.zeros(B, S, dtype=torch.bool, device=dev)
+    q[:, 40:52] = True
+    h = torch.randn(B, S, DIMS.hidden, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        full, _ = st(h, text, image, q)
+        pre, caches = st(h[:, :S - C], text[:, :S - C], image[:, :S - C], q[:, :S - C])
+        chunk, _ = st(h[:, S - C:], None, None, None, kv_caches=caches)
+        empty = [(c[0][:, :, :0], c[1][:, :, :0]) for c in caches]
+        again, _ = st(h[:, :S - C], text[:, :S - C], image[:, :S - C], q[:, :S - C], kv_caches=empty)
+    assert rel(chunk, full[:, S - C:]) < 2e-2
+    assert rel(again, pre) < 1e-6
+
+
 def test_decode_weight_equals_the_text_adapter_branch_on_cpu():
     """decode_weight(W + s B A_text) against the oracle's mask-free branch (plain LoRA with the text adapter), both mirrors'
     parameter layouts emulated with bare modules (no GPU needed: pure tensor algebra)."""

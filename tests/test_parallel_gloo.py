@@ -120,3 +120,39 @@ def test_sharded_frozen_base_single_process():
     store = ShardedFrozenBase(layers, "cpu", dtype=torch.float32)
     for l in (0, 1, 2, 1, 0):
         assert torch.equal(store.layer(l, prefetch_next=None)["w"], ref[l])
+
+
+def test_attach_flattens_the_adapter_layer_by_layer_on_cpu():
+    """attach(): parameters re-seated as views of ONE bf16 buffer in decoder-layer order, fp32 master copy, fp32 gradient sinks on
+    both mirrors, one bucket entry per layer; the optimizer kernel itself is GPU-only (loud error on CPU tensors)."""
+    sys.path.insert(0, ROOT)
+    from moka_amd import _lib
+    from moka_amd.decoder import LlamaDims, MokaLlamaStack
+    from moka_amd.parallel import attach
+    from moka_amd.peft_hyper import Linear
+    dims = LlamaDims(hidden=64, ff=96, n_heads=2, n_kv_heads=2)
+
+    def make(d_in, d_out):
+        return Linear(d_in, d_out, r=(4, 4, 4), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.0,
+                      loramethod="train", bias=False)
+
+    st = MokaLlamaStack(dims, 2, make).to(torch.bfloat16)
+    for n, p in st.named_parameters():
+        p.requires_grad = "lora_" in n
+    ref = {n: p.detach().clone() for n, p in st.named_parameters() if "lora_" in n}
+    dp = attach(st, n_buckets=2)
+    assert dp.bucket.n_layers == 2 and len(dp.names) == 2 * 7 * 4
+    assert all(n.startswith("layers.0.") for n in dp.names[:28]) and all(n.startswith("layers.1.") for n in dp.names[28:])
+    assert dp.offsets == sorted(dp.offsets) and dp.bucket.layer_end[0] == dp.offsets[28]
+    for n, o in zip(dp.names, dp.offsets):
+        p = dict(st.named_parameters())[n]
+        assert p.data_ptr() == dp.work[o:].data_ptr() and torch.equal(p.detach(), ref[n])
+        assert torch.equal(dp.master[o:o + p.numel()].view(p.shape), ref[n].float())
+    q = st.layers[1].self_attn.q_proj
+    assert q._moka_sinks["B"].shape == q.lora_B0.weight.shape and q._moka_sinks["B"].dtype == torch.float32
+    assert [tuple(a.shape) for a in q._moka_sinks["A"]] == [tuple(q.lora_A0.weight.shape)] * 3
+    assert q._moka_sinks["A"][1].data_ptr() == dp.bucket.flat[dp.offsets[dp.names.index("layers.1.self_attn.q_proj.lora_A1.weight")]:].data_ptr()
+    with pytest.raises(_lib.MokaError):
+        dp.step()                                   # no CPU path for the optimizer kernel
+    dp.detach()
+    assert q._moka_sinks is None

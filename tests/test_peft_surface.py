@@ -135,3 +135,15 @@ def test_empty_batch_returns_the_empty_base_output():
     v.set_adapter(["image", "text"])
     m = torch.zeros(0, 5, dtype=torch.bool)
     assert v(torch.zeros(0, 5, 32, dtype=v.get_base_layer().weight.dtype), m, m, m).shape == (0, 5, 64)
+
+
+def test_vt_config_with_list_target_modules_round_trips_through_save_pretrained(tmp_path):
+    """`target_modules=[...]` becomes a set in __post_init__; adapter_config.json must still be written
+    (the reference converts sets to lists, modified_peft/config.py:67-70)."""
+    import json
+    from moka_amd.modified_peft import LoraConfig
+    cfg = LoraConfig(r=8, target_modules=["q_proj", "v_proj"], lora_alpha=16, lora_dropout=0.05, attn_weight=0.05)
+    assert cfg.target_modules == {"q_proj", "v_proj"}
+    cfg.save_pretrained(str(tmp_path))
+    d = json.load(open(tmp_path / "adapter_config.json"))
+    assert d["target_modules"] == ["q_proj", "v_proj"] and d["r"] == 8 and d["attn_weight"] == 0.05 and d["peft_type"] == "LORA"

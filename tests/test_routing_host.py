@@ -69,3 +69,33 @@ def test_routing_cache_is_keyed_on_mask_identity_and_version():
     assert len(cache._items) == 2                                    # capacity honoured (oldest entry dropped)
     p1 = cache.plain(2, 1, "cpu", 3)
     assert cache.plain(2, 1, "cpu", 3) is p1 and p1.Lk_max == 0 and int((p1.tok_mod[:2] == 0).sum()) == 2
+
+
+def test_routing_cache_with_inference_tensors_views_and_data_rewrites():
+    """ADVICE r01: masks made under torch.inference_mode() have no version counter (the reference works there);
+    views of one buffer must not alias; a rewrite through .data is caught by the MOKA_ROUTING_VERIFY fingerprint."""
+    cache = RoutingCache(capacity=4)
+    with torch.inference_mode():
+        t = torch.tensor([[1, 1, 0, 0, 1, 1]], dtype=torch.bool)
+        i = ~t
+        q = torch.tensor([[0, 0, 0, 0, 1, 0]], dtype=torch.bool)
+        r = cache.get("vt", [t, i, q])                              # would raise "Inference tensors do not track version counter"
+        assert int(r.klen[0]) == 1 and len(cache._items) == 0      # built on the spot, never cached
+    # two views of one buffer: same data_ptr for the first, different offset / stride for the others
+    buf = torch.zeros(2, 1, 6, dtype=torch.bool)
+    buf[0, 0, 4] = True
+    buf[1, 0, 5] = True
+    t = torch.tensor([[1, 1, 0, 0, 1, 1]], dtype=torch.bool)
+    ra = cache.get("vt", [t, ~t, buf[0]])
+    rb = cache.get("vt", [t, ~t, buf[1]])
+    assert ra is not rb
+    # .data rewrite does not bump the version: stale by default (documented), caught in verify mode
+    vc = RoutingCache(capacity=4)
+    vc.verify = True
+    q = torch.tensor([[0, 0, 0, 0, 1, 0]], dtype=torch.bool)
+    i = ~t
+    r1 = vc.get("vt", [t, i, q])
+    assert vc.get("vt", [t, i, q]) is r1
+    q.data[0, 5] = True
+    r2 = vc.get("vt", [t, i, q])
+    assert r2 is not r1 and int(r2.klen[0]) == 2

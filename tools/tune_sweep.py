@@ -107,15 +107,12 @@ def main():
         algo = {"down_fwd": E * T * d_in, "up_fwd": 2 * E * T * d_out, "up_bwd(g only)": E * T * d_out, "up_bwd(dB only)": E * T * d_out, "up_bwd(g+dB)": E * T * d_out,
                 "down_bwd(dA only)": E * T * d_in, "down_bwd(dx only)": 2 * E * T * d_in, "cross_fwd": 0, "cross_bwd": 0}
         sweeps = {
-            "down_fwd": [("xa_ng", v) for v in (2, 4, 8)] + [("no_xa", 1)],
-            "up_bwd(g only)": [("reduce_nw", v) for v in (4, 8)] + [("reduce_u", v) for v in (2, 4)] + [("reduce_ks", v) for v in (1, 2, 4)],
+            "down_fwd": [("xa_ng", v) for v in (2, 4, 8)],
             "up_fwd": [("expand_depth", 3)] + [("expand_bpc", v) for v in (2, 4, 8, 12, 16)],
             "down_bwd(dx only)": [("expand_depth", 2)] + [("expand_bpc", v) for v in (2, 4, 8)],
-            "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)] + [("no_fused_gy", 1)],
+            "up_bwd(g+dB)": [("gy_ng", v) for v in (4, 8, 16)],
             "up_bwd(g only)": [("gy_ng", v) for v in (4, 8, 16)],
             "down_bwd(dA only)": [("wgrad_bpc", v) for v in (1, 2, 3, 4, 6, 8)],
-            "cross_fwd": [("cross_nth", 512)] + [("cross_rows", v) for v in (16, 8)],
-            "cross_bwd": [("cross_nth", 512)] + [("cross_rows", v) for v in (16, 8)],
         }
         print(f"\n=== {d_in} -> {d_out}  (T={T}) ===")
         for name, fn in cs.items():
