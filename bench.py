@@ -112,11 +112,6 @@ class Unit:
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
                                                       drop_p, sd, 0)),
-            # the two halves of moka_down_bwd on their own (--wgrad-stream: dA on a side stream, it feeds nothing downstream)
-            "moka_down_bwd_dx": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, None, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0)),
-            "moka_down_bwd_dA": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, None, T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0)),
         }
         # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
         # per-projection definition: a group that reads x once is still credited G reads -- the roofline
@@ -170,11 +165,9 @@ def build_workload(args, dev, lib, bucket_factory):
     Tp = _lib.tok_pad(T)
     max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r), _lib.ksplit_bwd(T, ff, r))
     # scratch shared by all units (consumed before the next unit overwrites it), one slot per group member
-    # (two sets, alternated unit by unit: with --wgrad-stream the dA kernel of a unit still reads its dh pack while the next
-    #  unit's rank-space kernels run)
-    scratch2 = [[dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
-                      dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
-                 for _ in range(3)] for _ in range(2)]
+    scratch = [dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
+                    dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
+               for _ in range(3)]
 
     # units = maximal runs of projections with the same input (--no-group: every projection alone)
     unit_defs = []
@@ -211,7 +204,7 @@ def build_workload(args, dev, lib, bucket_factory):
                                 BwT=torch.empty(RP, d_out, dtype=bf, device=dev), AT=torch.empty(M, d_in, RP, dtype=bf, device=dev)))
         for src, pis in unit_defs:
             mem = [members[pi] for pi in pis]
-            units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch2[len(units) % 2],
+            units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch,
                               1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                               [1000003 * l + pi for pi in pis]))
         layer_end.append(off)
@@ -219,7 +212,7 @@ def build_workload(args, dev, lib, bucket_factory):
     work.copy_(master)
     assert layer_end == bucket.layer_end
     return dict(units=units, units_per_layer=len(unit_defs), rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T,
-                n_params=n_params, layer_end=layer_end, keep=(sets, masks, scratch2))
+                n_params=n_params, layer_end=layer_end, keep=(sets, masks, scratch))
 
 
 ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
@@ -269,46 +262,31 @@ def run_forward(lib, wl, sp, rec=None):
         _call(lib, "moka_up_fwd", u, sp, rec)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, side=None):
-    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
-    side: a second stream for the dA half of moka_down_bwd (the weight gradients feed nothing downstream, so they may run
-    beside the next unit's latency-bound rank-space kernels); joined back into the launch stream after every layer."""
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0):
+    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued."""
     units, per = wl["units"], wl["units_per_layer"]
-    main = torch.cuda.current_stream()
-    done = [None, None]                              # side-stream events of the last two units (their scratch set is reused two units on)
-    j = 0
     for l in range(n_layers - 1, lo - 1, -1):
         for u in reversed(units[l * per:(l + 1) * per]):
             _call(lib, "moka_up_bwd", u, sp, rec)
-            if side is not None and done[j % 2] is not None:
-                main.wait_event(done[j % 2])         # the dA kernel that read this scratch set has finished
             _call(lib, "moka_cross_bwd", u, sp, rec)
-            if side is None:
-                _call(lib, "moka_down_bwd", u, sp, rec)
-            else:
-                side.wait_stream(main)
-                _call(lib, "moka_down_bwd_dA", u, c_void_p(side.cuda_stream), None)
-                done[j % 2] = torch.cuda.Event()
-                done[j % 2].record(side)
-                _call(lib, "moka_down_bwd_dx", u, sp, None)
-            j += 1
+            _call(lib, "moka_down_bwd", u, sp, rec)
         if on_layer_done is not None:
-            if side is not None:
-                main.wait_stream(side)               # the bucket hook ships this layer's gradients
             on_layer_done(l)
-    if side is not None:
-        main.wait_stream(side)
 
 
-# HBM bytes per launch from the PMC counters of profiles/r01_v11_pmc_{fetch,write}_size.md (rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is),
-# measured at T = 8192 tokens per launch; MiB per projection of the given d_out (a batched launch moves the sum of its members).
-PMC_TRAFFIC_MIB_T8192 = {("moka_up_fwd", 4096): 68.36 + 64.00, ("moka_up_fwd", 11008): 183.90 + 172.54}
+# roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
+# PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
+# in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), never a constant in here.
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def pmc_traffic_bytes(name, width, T):
-    v = PMC_TRAFFIC_MIB_T8192.get((name, width))
-    return None if v is None else v * 1024 * 1024 * (T / 8192.0)
+def pmc_traffic_per_launch(T, launches_per_layer):
+    """Average HBM bytes per launch of the dominant kernel, scaled to T tokens; raises when the summary is missing."""
+    if not os.path.exists(PMC_TRAFFIC_FILE):
+        raise SystemExit(f"bench: {PMC_TRAFFIC_FILE} is missing -- run tools/pmc_traffic.sh on the GPU box and commit its "
+                         "pmc_traffic.json there (roofline.traffic is measured, not assumed); --no-traffic skips the field")
+    d = json.load(open(PMC_TRAFFIC_FILE))
+    return d["traffic_bytes_per_layer"] * (T / float(d["tokens"])) / launches_per_layer, os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
 
 
 def usable_cpus() -> int:
@@ -330,9 +308,21 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
-    """The oracle port (torch fp32, all host cores) on a bounded sample: adapter fwd+bwd of ONE
-    decoder layer's 7 projections for ONE sequence, scaled to the 32 layers."""
+    """The oracle port (the CPU restatement of the reference layer, verified equal to it in the build container) on the
+    host cores the job may use, on a bounded sample: adapter fwd+bwd of ONE decoder layer's 7 projections for ONE
+    sequence, fp32 (the headline value, scaled to the layer count) and bf16 operands, with the per-projection split
+    (BASELINE.md section 3).  Baseline only -- never the thing measured or shipped."""
     from oracle import cases as C
     from oracle import moka_oracle as O
     S, r = args.seq, args.rank
@@ -344,30 +334,39 @@ def cpu_baseline(args):
     rt = O.routing_from_avt_masks(masks)
     g = torch.Generator().manual_seed(1)
     data = []
-    for _, di, do, _ in PROJS:
+    for name, di, do, _ in PROJS:
         d_in = d if di == "d" else ff
         d_out = d if do == "d" else ff
-        data.append((torch.randn(1, S, d_in, generator=g), torch.randn(1, S, d_out, generator=g),
+        data.append((name, torch.randn(1, S, d_in, generator=g), torch.randn(1, S, d_out, generator=g),
                      [torch.randn(r, d_in, generator=g) * 0.01 for _ in range(3)], torch.randn(d_out, r, generator=g) * 0.02,
                      torch.randn(1, S, d_out, generator=g)))
 
-    def one_layer():
-        for x, y0, A, Bw, gy in data:
-            y, ctx = O.adapter_forward(x, y0, A, Bw, rt, 16.0 / r, [1.0] * 3, 1.0, r, dtype=torch.float32)
+    def one_layer(dtype, per=None):
+        for name, x, y0, A, Bw, gy in data:
+            t0 = time.perf_counter()
+            y, ctx = O.adapter_forward(x, y0, A, Bw, rt, 16.0 / r, [1.0] * 3, 1.0, r, dtype=dtype)
             O.adapter_backward(gy, ctx)
+            if per is not None:
+                per[name] = per.get(name, 0.0) + (time.perf_counter() - t0)
 
-    one_layer()
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one_layer()
-        n += 1
-        if time.perf_counter() - t0 > args.cpu_seconds or n >= 50:
-            break
-    per_layer = (time.perf_counter() - t0) / n
-    return {"value": S / (per_layer * args.layers), "unit": "tokens/s", "cores": cores, "kind": "port",
+    def timed(dtype, budget):
+        one_layer(dtype)                                  # warm-up
+        per, n = {}, 0
+        t0 = time.perf_counter()
+        while True:
+            one_layer(dtype, per)
+            n += 1
+            if time.perf_counter() - t0 > budget or n >= 50:
+                break
+        return (time.perf_counter() - t0) / n, n, {k: round(v / n * 1e3, 2) for k, v in per.items()}
+
+    per_layer, n, split = timed(torch.float32, args.cpu_seconds * 0.7)
+    per_layer_bf, n_bf, split_bf = timed(torch.bfloat16, args.cpu_seconds * 0.3)
+    return {"value": S / (per_layer * args.layers), "unit": "tokens/s", "cores": cores, "kind": "port", "cpu": cpu_model_string(),
             "sample": f"oracle port (torch fp32), adapter fwd+bwd of 1 decoder layer x 7 projections, 1 sequence of {S} tokens, "
-                      f"{n} repeats, scaled x{args.layers} layers"}
+                      f"{n} repeats, scaled x{args.layers} layers",
+            "per_projection_ms_fp32": split,
+            "bf16": {"value": S / (per_layer_bf * args.layers), "repeats": n_bf, "per_projection_ms": split_bf}}
 
 
 def end_to_end(args, dev):
@@ -474,8 +473,7 @@ def main():
                     help="bracket every n-th launch of the dominant kernel with HIP events inside the timed region (an event record is a "
                          "packet of its own: bracketing all 128 launches of a step costs 0.7 ms of it; 5 is coprime to the 4 unit shapes "
                          "of a layer, so the sample covers them evenly)")
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="run the dA half of moka_down_bwd on a second stream (it feeds nothing downstream), beside the next unit's kernels")
+    ap.add_argument("--no-traffic", action="store_true", help="leave roofline.traffic null instead of reading the PMC summary under profiles/")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -530,14 +528,13 @@ def main():
     # hooks (RCCL all-reduce of a finished bucket) run between the graphs exactly as between live layers.  "all": the whole
     # micro-batch as one graph (single GPU, no brackets: `roofline` then comes from the extra pass).
     fwd_bwd_graph, bwd_graphs = None, None
-    wside = torch.cuda.Stream(device=dev) if args.wgrad_stream else None
     if args.graph != "off":
         try:
             side = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(side):
                 spw = c_void_p(side.cuda_stream)
                 run_forward(lib, wl, spw)
-                run_backward(lib, wl, spw, L, side=wside)   # warm-up on the capture stream (LDS attributes, lazy module load)
+                run_backward(lib, wl, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
             torch.cuda.synchronize()
             if args.graph == "all":
                 assert world == 1, "--graph all: single GPU only"
@@ -545,7 +542,7 @@ def main():
                 with torch.cuda.graph(fwd_bwd_graph, stream=side):
                     spg = c_void_p(torch.cuda.current_stream().cuda_stream)
                     run_forward(lib, wl, spg)
-                    run_backward(lib, wl, spg, L, side=wside)
+                    run_backward(lib, wl, spg, L)
             else:
                 lpb = bucket.layers_per_bucket
                 bwd_graphs = []
@@ -553,7 +550,7 @@ def main():
                     lo = max(0, (hi - 1) // lpb * lpb)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
-                        run_backward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), hi, lo=lo, side=wside)
+                        run_backward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), hi, lo=lo)
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
@@ -575,7 +572,7 @@ def main():
                     for l in range(hi - 1, lo - 1, -1):
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
-                run_backward(lib, wl, sp, L, bucket.layer_done, rec, side=wside)   # all-reduce of finished layer groups overlaps the rest
+                run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
         bucket.finish(average=opt is None)           # join the all-reduces; the optimizer kernel averages (grad_scale)
         if opt is not None:
             opt.step(grad_scale=1.0 / world, zero_grad=True)
@@ -647,14 +644,11 @@ def main():
         dom_bytes = byt[dom]
         dom_avg_ms = tot[dom] / cnt[dom]
         achieved = dom_bytes / cnt[dom] / (dom_avg_ms * 1e-3) / 1e9
-        traffic = None
-        if args.seq == 2048:
-            tr = 0.0
-            for n, u, e0, e1 in live_items:
-                if n == dom:
-                    tr += sum(pmc_traffic_bytes(n, do, T) or float("nan") for do in u.d_outs)
-            if tr == tr:
-                traffic = round(tr / cnt[dom])
+        traffic, traffic_src = None, None
+        if not args.no_traffic and (args.model, args.rank, args.variant) == ("7b", 16, "avt") and not args.no_group:
+            # (the PMC passes profile the headline workload; per launch = per layer / the layer's up-projection launches)
+            traffic, traffic_src = pmc_traffic_per_launch(T, wl["units_per_layer"])
+            traffic = round(traffic)
         out = {
             "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline" if (args.model, args.rank, args.seq) == ("7b", 16, 2048)
                       else "tokens/sec/GPU Llama-2-%s MokA r=%d seq%d bf16; adapter HBM %%roofline" % (args.model.upper(), args.rank, args.seq),
@@ -670,10 +664,16 @@ def main():
                                       args.dropout, args.batch,
                                       "one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points"),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
+            "distributed": {"world_size": world, "dist_world_size": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                            "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
+                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                            "grad_payload": "fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % 8,
+                            "adapter_params": wl["n_params"]},
+            "graph": args.graph,
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(dom_bytes / cnt[dom]),
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches_timed": cnt[dom]},
             "entry_point_ms_per_pass": {n: round(tot_x[n], 3) for n in ENTRY},

@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC passes for roofline.traffic (run on the GPU box from the repo root): gpurun_out/<tag>/{pmc_traffic.json,pmc_fetch_size.md,pmc_write_size.md}
+TAG=${1:-pmc}
+REPO=$PWD
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+LAYERS=4
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pmcF /tmp/pmcW
+# --graph off --steps 1 --warmup 1: 2 optimizer steps + the extra bracketed passes; every pass runs the forward once per layer
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcF -o f -- python $REPO/bench.py --layers $LAYERS --steps 1 --warmup 1 --graph off --no-cpu-baseline --no-traffic > $OUT/runF.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcW -o w -- python $REPO/bench.py --layers $LAYERS --steps 1 --warmup 1 --graph off --no-cpu-baseline --no-traffic > $OUT/runW.log 2>&1
+cd $REPO
+F=$(find /tmp/pmcF -name "*.db" | head -1); W=$(find /tmp/pmcW -name "*.db" | head -1)
+python tools/rocpd_pmc_summary.py $F FETCH_SIZE > $OUT/pmc_fetch_size.md
+python tools/rocpd_pmc_summary.py $W WRITE_SIZE > $OUT/pmc_write_size.md
+python tools/pmc_traffic.py $F $W $LAYERS 8192 > $OUT/pmc_traffic.json
+cat $OUT/pmc_traffic.json | head -12
