@@ -31,7 +31,13 @@
  *                                        kernel (n = 1 for hp, n = M per-modality-masked planes for dh)
  *       BwT           [RP, d_out] bf16   transposed copy of Bw, zero padded, produced by moka_cross_fwd
  *       AT            [M, d_in, RP] bf16 transposed copies of the A_m, zero padded, produced by moka_cross_fwd
- *   - dtype: MOKA_BF16 (=0) is the only storage type implemented (fp32 accumulate).
+ *   - dtype: MOKA_BF16 (=0): the tuned path (bf16 storage, fp32 accumulate, MFMA).  MOKA_F32 (=1): fp32 storage of x / y / gy /
+ *     dx / A_m / Bw (the reference's adapters follow the base dtype, layer.py:124-132; BASELINE configs[0]) on exact-fp32 FMA
+ *     kernels -- a correctness path.  With MOKA_F32 the rank-space operands are the fp32 rows themselves instead of the bf16
+ *     packs:  moka_up_fwd: `hp_tok` = s_out[mod] * hp  fp32 [T, RP];   moka_up_bwd: `hp_kmj` = the same rows, `BwT` = Bw itself
+ *     (fp32 [d_out, r]);   moka_down_bwd: `dh_tok` = s_in * dh  fp32 [T, RP] (0 for tokens of no modality), `dh_kmj` unused,
+ *     `AT` = the A_m stacked, fp32 [M, r, d_in].  moka_cross_fwd / moka_cross_bwd are storage independent (pass hp / dh, which
+ *     are optional for bf16, and NULL for the weight shadows).  Groups run one projection at a time.
  *
  * Unified routed formulation (oracle/moka_oracle.py):
  *     h[t]  = s_in * x[t] A[mod(t)]^T                 (0 when mod(t) == MOKA_MOD_NONE)
@@ -62,6 +68,7 @@ typedef void* moka_stream_t;            /* hipStream_t */
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
 #define MOKA_BF16         0
+#define MOKA_F32          1              /* fp32 storage: see "fp32 storage" below */
 
 #define MOKA_OK           0
 #define MOKA_EINVAL      -1             /* bad argument (shape, alignment, unsupported size) */

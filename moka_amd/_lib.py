@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOKA_HIP_LIB") or os.path.join(_HERE, "libmoka_hip.so")
 
 MOKA_BF16 = 0
+MOKA_F32 = 1
 MOKA_MOD_NONE = 255
 MOKA_MAX_MOD = 3
 

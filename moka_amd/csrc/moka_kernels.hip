@@ -1742,6 +1742,108 @@ __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// fp32 storage (MOKA_F32): x / y / gy / dx / A_m / Bw held in fp32 (the reference's adapters follow the base dtype,
+// layer.py:124-132; BASELINE.json configs[0] is the fp32 bring-up case).  Plain fp32 FMA kernels -- exact products, fp32
+// accumulation, the same split-K slices / routing / dropout mask as the bf16 path, so the rank-space kernels (cross) are shared.
+// They are a correctness path (parity <= 1e-5 against the fp64 goldens), not a tuned one: the metric is quoted on bf16.
+// Rank-space operands are the fp32 rows themselves ([T, RP], pre-scaled by the caller) instead of the bf16 hi/lo packs.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float drop_f32(const DropArgs& d, int t, int c, int C, float v) {
+    if (!d.thr) return v;
+    const KeepMask km = drop_keep8(d, (unsigned)t * (unsigned)(C >> 3) + (unsigned)(c >> 3));
+    return drop_kept(km, c & 7) ? v : 0.f;
+}
+
+struct F32Args {
+    const float* in;                 // x or gy [T][C]
+    float* out;                      // y / dx [T][C] (in/out) or part [KS][T][RP]
+    const float* W[MOKA_MAX_MOD];    // A_m [r][C]  or  Bw [C][r]
+    const float* rs;                 // rank-space rows [T][RP] (hp or dh, pre-scaled)
+    float* acc[MOKA_MAX_MOD];        // dA_m [r][C] / dB [C][r]
+    const unsigned char* tok_mod;
+    float s_mod[4];
+    int T, C, r, M, RP;
+    DropArgs drop;
+};
+
+// part[slice][t][k] = s_mod[mod(t)] * sum_{c in slice} drop(x)[t][c] * W_mod(t)[k][c]        (W = A_m; shared == 0)
+// g_part[slice][t][k] = s_mod[mod(t)] * sum_{c in slice} gy[t][c] * Bw[c][k]                 (shared == 1: W[0] = Bw [C][r])
+template <bool SHARED>
+__global__ void __launch_bounds__(256) moka_f32_reduce_kernel(const F32Args a) {
+    const int t = blockIdx.y * 16 + (threadIdx.x >> 4), k0 = threadIdx.x & 15;
+    const int c0 = blockIdx.x * 512, c1 = min(a.C, c0 + 512);
+    if (t >= a.T) return;
+    const int mod = a.tok_mod[t];
+    float* dst = a.out + ((size_t)blockIdx.x * a.T + t) * a.RP;
+    for (int k = k0; k < a.RP; k += 16) {
+        float acc = 0.f;
+        if (mod < a.M && k < a.r) {
+            const float* xr = a.in + (size_t)t * a.C;
+            if (SHARED) {
+                const float* w = a.W[0] + k;
+                for (int c = c0; c < c1; ++c) acc = fmaf(xr[c], w[(size_t)c * a.r], acc);
+            } else {
+                const float* w = a.W[mod] + (size_t)k * a.C;
+                for (int c = c0; c < c1; ++c) acc = fmaf(drop_f32(a.drop, t, c, a.C, xr[c]), w[c], acc);
+            }
+            acc *= a.s_mod[mod];
+        }
+        dst[k] = acc;
+    }
+}
+
+// y[t][c] += sum_k rs[t][k] * Bw[c][k]                                   (DX == false)
+// dx[t][c] += keep(t, c) / (1 - p) * sum_k rs[t][k] * A_mod(t)[k][c]     (DX == true)
+template <bool DX>
+__global__ void __launch_bounds__(256) moka_f32_expand_kernel(const F32Args a) {
+    const int c = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+    if (c >= a.C) return;
+    const int mod = a.tok_mod[t];
+    if (mod >= a.M) return;                                  // tokens of no modality: nothing to add
+    const float* row = a.rs + (size_t)t * a.RP;
+    float acc = 0.f;
+    if (DX) {
+        const float* w = a.W[mod] + c;
+        for (int k = 0; k < a.r; ++k) acc = fmaf(row[k], w[(size_t)k * a.C], acc);
+        acc = drop_f32(a.drop, t, c, a.C, acc) * a.drop.inv_keep;
+    } else {
+        const float* w = a.W[0] + (size_t)c * a.r;
+        for (int k = 0; k < a.r; ++k) acc = fmaf(row[k], w[k], acc);
+    }
+    a.out[(size_t)t * a.C + c] += acc;
+}
+
+// dB[c][k] += sum_t gy[t][c] * rs[t][k]                                                (DA == false)
+// dA_m[k][c] += 1 / (1 - p) * sum_{t: mod(t) == m} rs[t][k] * drop(x)[t][c]            (DA == true)
+// block = 16 columns x 16 ranks (x RP / 16 rounds) on a run of 256 tokens; one fp32 atomic per (column, rank) and run
+template <bool DA>
+__global__ void __launch_bounds__(256) moka_f32_wgrad_kernel(const F32Args a) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), k0 = threadIdx.x >> 4;
+    const int t0 = blockIdx.y * 256, t1 = min(a.T, t0 + 256);
+    if (c >= a.C) return;
+    for (int k = k0; k < a.r; k += 16) {
+        float acc[MOKA_MAX_MOD] = {0.f, 0.f, 0.f};
+        for (int t = t0; t < t1; ++t) {
+            const int mod = a.tok_mod[t];
+            if (mod >= a.M) continue;
+            const float v = a.in[(size_t)t * a.C + c];
+            const float p = (DA ? drop_f32(a.drop, t, c, a.C, v) : v) * a.rs[(size_t)t * a.RP + k];
+            if (DA) {
+#pragma unroll
+                for (int m = 0; m < MOKA_MAX_MOD; ++m) acc[m] += (m == mod) ? p : 0.f;
+            } else {
+                acc[0] += p;
+            }
+        }
+        if (DA) {
+            for (int m = 0; m < a.M; ++m) atomicAdd(a.acc[m] + (size_t)k * a.C + c, acc[m] * a.drop.inv_keep);
+        } else {
+            atomicAdd(a.acc[0] + (size_t)c * a.r + k, acc[0]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // O: the data-parallel step on the flat adapter buffers (moka_amd/parallel.py): one pass does what the reference's
 // ZeRO-2 step spreads over several (gradient averaging, AdamW, bf16 working copy, gradient zeroing)
 // ------------------------------------------------------------------------------------------
@@ -1873,7 +1975,7 @@ static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs*
 }
 
 static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
-    if (dtype != MOKA_BF16) return fail(MOKA_EDTYPE, "%s: only bf16 storage is implemented (dtype=%d)", fn, dtype);
+    if (dtype != MOKA_BF16 && dtype != MOKA_F32) return fail(MOKA_EDTYPE, "%s: storage dtype %d is neither MOKA_BF16 nor MOKA_F32", fn, dtype);
     if (T < 1) return fail(MOKA_EINVAL, "%s: T=%d", fn, T);
     if (C < 32 || (C % 32) != 0) return fail(MOKA_EINVAL, "%s: feature width %d must be a positive multiple of 32", fn, C);
     if (rank_pad(r) < 0) return fail(MOKA_EINVAL, "%s: rank %d not in 1..64", fn, r);
@@ -2074,6 +2176,13 @@ static int fwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
 // number of g_part slices moka_up_bwd writes for output width C
 static int bwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
 
+// ---- fp32 storage launchers (one projection at a time)
+static void f32_common(F32Args& a, const uint8_t* tok_mod, int T, int C, int r, int M) {
+    memset(&a, 0, sizeof(a));
+    a.tok_mod = tok_mod; a.T = T; a.C = C; a.r = r; a.M = M; a.RP = rank_pad(r);
+    a.drop.inv_keep = 1.f;
+}
+
 extern "C" {
 
 int moka_version(void) { return MOKA_VERSION; }
@@ -2139,6 +2248,18 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
     }
     if ((unsigned long long)T * (unsigned long long)(d_in >> 3) > 0xffffffffull && drop[0].thr)
         return fail(MOKA_EINVAL, "moka_down_fwd: T * d_in too large for the dropout counter");
+    if (dtype == MOKA_F32) {
+        for (int g = 0; g < G; ++g) {
+            F32Args a;
+            f32_common(a, tok_mod, T, d_in, r, M);
+            a.in = (const float*)x; a.out = part[g]; a.drop = drop[g];
+            for (int m = 0; m < M; ++m) { a.W[m] = (const float*)A[g * M + m]; a.s_mod[m] = s_in * drop[g].inv_keep; }
+            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3((d_in + 511) / 512, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+            rc = check_launch("moka_f32_reduce_kernel");
+            if (rc) return rc;
+        }
+        return MOKA_OK;
+    }
     const int RP = rank_pad(r);
     // r <= 16: the weights of all modalities (and of all G projections) are resident per wave -> one launch for the group;
     // wider ranks: the same kernel with RP / 16 rank tiles, one launch per projection.  One split-K slice per 512 columns.
@@ -2266,10 +2387,20 @@ int moka_up_fwd_group(const void* const* hp_tok, const void* const* Bw, const ui
         int rc = check_common("moka_up_fwd", T, d_out[g], r, 1, dtype);
         if (rc) return rc;
         if (!hp_tok[g] || !Bw[g] || !y_inout[g]) return fail(MOKA_EINVAL, "moka_up_fwd: null pointer (projection %d)", g);
+        if (dtype == MOKA_F32) {
+            F32Args a;
+            f32_common(a, tok_mod, T, d_out[g], r, MOKA_MAX_MOD);          // (M only gates tokens of no modality here)
+            a.rs = (const float*)hp_tok[g]; a.W[0] = (const float*)Bw[g]; a.out = (float*)y_inout[g];
+            hipLaunchKernelGGL(moka_f32_expand_kernel<false>, dim3((d_out[g] + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a);
+            rc = check_launch("moka_f32_expand_kernel");
+            if (rc) return rc;
+            continue;
+        }
         ExpandArgs& a = ab.z[g];
         a.pack = (const unsigned short*)hp_tok[g]; a.W[0] = (const unsigned char*)Bw[g]; a.tok_mod = tok_mod;
         a.out = (unsigned char*)y_inout[g]; a.T = T; a.C = d_out[g]; a.r = r; a.M = 1;
     }
+    if (dtype == MOKA_F32) return MOKA_OK;
     return launch_expand<true>(ab, G, rank_pad(r), (hipStream_t)stream);
 }
 
@@ -2294,6 +2425,35 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         Cmax = d_out[g] > Cmax ? d_out[g] : Cmax;
     }
     int rc = MOKA_OK;
+    if (dtype == MOKA_F32) {
+        // slices of the widest projection of the group (moka_ksplit_bwd): narrower members leave their upper slices zero
+        const int ks = (Cmax + 511) / 512;
+        for (int g = 0; g < G; ++g) {
+            if (g_part && g_part[g]) {
+                if (!BwT || !BwT[g]) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without Bw (fp32: pass Bw as BwT)");
+                const int ksg = (d_out[g] + 511) / 512;
+                if (ksg < ks && hipMemsetAsync(g_part[g] + (size_t)ksg * T * RP, 0, (size_t)(ks - ksg) * T * RP * 4, (hipStream_t)stream) != hipSuccess)
+                    return fail(MOKA_ELAUNCH, "moka_up_bwd: memset");
+                F32Args a;
+                f32_common(a, tok_mod, T, d_out[g], r, M);
+                a.in = (const float*)gy[g]; a.out = g_part[g]; a.W[0] = (const float*)BwT[g];
+                for (int m = 0; m < M; ++m) a.s_mod[m] = s_out[m];
+                hipLaunchKernelGGL(moka_f32_reduce_kernel<true>, dim3(ksg, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+                rc = check_launch("moka_f32_reduce_kernel");
+                if (rc) return rc;
+            }
+            if (dB_acc && dB_acc[g]) {
+                if (!hp_kmj || !hp_kmj[g]) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without the scaled hp rows (fp32: pass them as hp_kmj)");
+                F32Args a;
+                f32_common(a, tok_mod, T, d_out[g], r, M);
+                a.in = (const float*)gy[g]; a.rs = (const float*)hp_kmj[g]; a.acc[0] = dB_acc[g];
+                hipLaunchKernelGGL(moka_f32_wgrad_kernel<false>, dim3((d_out[g] + 15) / 16, (T + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+                rc = check_launch("moka_f32_wgrad_kernel");
+                if (rc) return rc;
+            }
+        }
+        return MOKA_OK;
+    }
     if (g_part && g_part[0]) {
         // ONE pass over gy produces the g slices (one per 512-column block) and, if requested, dB
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
@@ -2348,6 +2508,34 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
         if (rc) return rc;
     }
     const int RP = rank_pad(r);
+    if (dtype == MOKA_F32) {
+        if (!dh_tok || !AT) return fail(MOKA_EINVAL, "moka_down_bwd: fp32 storage needs the scaled dh rows (as dh_tok) and the stacked A_m (as AT)");
+        for (int g = 0; g < G; ++g) {
+            if (!dh_tok[g] || !AT[g]) return fail(MOKA_EINVAL, "moka_down_bwd: dh_tok / AT of projection %d is null", g);
+            F32Args a;
+            f32_common(a, tok_mod, T, d_in, r, M);
+            a.rs = (const float*)dh_tok[g]; a.drop = drop[g];
+            for (int m = 0; m < M; ++m) a.W[m] = (const float*)AT[g] + (size_t)m * r * d_in;
+            if (dA_acc) {
+                if (!x) return fail(MOKA_EINVAL, "moka_down_bwd: dA requested without x");
+                a.in = (const float*)x;
+                for (int m = 0; m < M; ++m) {
+                    if (!dA_acc[g * M + m]) return fail(MOKA_EINVAL, "moka_down_bwd: dA_acc[%d] is null", g * M + m);
+                    a.acc[m] = dA_acc[g * M + m];
+                }
+                hipLaunchKernelGGL(moka_f32_wgrad_kernel<true>, dim3((d_in + 15) / 16, (T + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+                rc = check_launch("moka_f32_wgrad_kernel");
+                if (rc) return rc;
+            }
+            if (dx_inout) {
+                a.out = (float*)dx_inout;
+                hipLaunchKernelGGL(moka_f32_expand_kernel<true>, dim3((d_in + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, a);
+                rc = check_launch("moka_f32_expand_kernel");
+                if (rc) return rc;
+            }
+        }
+        return MOKA_OK;
+    }
     const bool fused = G == 1 || can_group(r, G);
     if (dA_acc) {
         if (!dh_kmj || !x) return fail(MOKA_EINVAL, "moka_down_bwd: dA requested without dh_kmj / x");

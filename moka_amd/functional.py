@@ -33,6 +33,18 @@ def _require_bf16(t: torch.Tensor, name: str):
         raise _lib.MokaError(f"moka_amd: `{name}` is {t.dtype}; the HIP path stores activations and weights in bf16")
 
 
+def _storage(tensors, names) -> int:
+    """Storage dtype code of one adapted projection: all operands bf16 (the tuned path) or all fp32 (MOKA_F32: exact-fp32 FMA
+    kernels, the reference's fp32 configuration -- adapters follow the base dtype, layer.py:124-132)."""
+    dts = {t.dtype for t in tensors}
+    if dts == {torch.bfloat16}:
+        return _lib.MOKA_BF16
+    if dts == {torch.float32}:
+        return _lib.MOKA_F32
+    desc = ", ".join(f"{n}: {t.dtype}" for n, t in zip(names, tensors))
+    raise _lib.MokaError(f"moka_amd: operands must be all bf16 or all fp32 on the HIP path ({desc})")
+
+
 def _ptrs(tensors: Sequence[torch.Tensor]):
     arr = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr
@@ -46,7 +58,7 @@ def _floats(vals: Sequence[float]):
 # 1:1 wrappers of the C entry points
 # --------------------------------------------------------------------------------------
 def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float,
-             dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
+             dropout_p: float = 0.0, seed: int = 0, dtype: int = 0) -> torch.Tensor:
     """x2 [T,d_in] bf16 -> part [ks,T,RP] fp32 (split-K partials of s_in * drop(x) A_mod^T)."""
     lib = _lib.load()
     T, d_in = x2.shape
@@ -54,7 +66,7 @@ def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: in
     ks = _lib.ksplit(T, d_in, r)
     part = torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device)
     _lib.check(lib.moka_down_fwd(x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(), part.data_ptr(),
-                                 T, d_in, r, len(A), float(s_in), float(dropout_p), int(seed), _lib.MOKA_BF16,
+                                 T, d_in, r, len(A), float(s_in), float(dropout_p), int(seed), dtype,
                                  _stream_ptr(x2.device)), "moka_down_fwd")
     return part
 
@@ -87,17 +99,17 @@ def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float
     return st
 
 
-def up_fwd_(y2: torch.Tensor, hp_tok: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int):
+def up_fwd_(y2: torch.Tensor, hp_tok: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, dtype: int = 0):
     """In place: y2 [T,d_out] bf16 += (s_out[mod] hp) Bw^T (the scale is already inside hp_tok)."""
     lib = _lib.load()
     T, d_out = y2.shape
     _lib.check(lib.moka_up_fwd(hp_tok.data_ptr(), Bw.data_ptr(), rt.tok_mod.data_ptr(), y2.data_ptr(),
-                               T, r, d_out, _lib.MOKA_BF16, _stream_ptr(y2.device)), "moka_up_fwd")
+                               T, r, d_out, dtype, _stream_ptr(y2.device)), "moka_up_fwd")
     return y2
 
 
 def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: torch.Tensor, rt: MokaRouting, r: int,
-           s_out: Sequence[float], dB_acc: Optional[torch.Tensor]) -> torch.Tensor:
+           s_out: Sequence[float], dB_acc: Optional[torch.Tensor], dtype: int = 0) -> torch.Tensor:
     """gy2 [T,d_out] bf16 -> g_part [ks,T,RP]; dB_acc [d_out,r] fp32 += (may be None: skip)."""
     lib = _lib.load()
     T, d_out = gy2.shape
@@ -107,7 +119,7 @@ def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: torch.Tensor,
     _lib.check(lib.moka_up_bwd(gy2.data_ptr(), None if hp_kmj is None else hp_kmj.data_ptr(), BwT.data_ptr(),
                                rt.tok_mod.data_ptr(), _floats(s_out), g_part.data_ptr(),
                                None if dB_acc is None else dB_acc.data_ptr(),
-                               T, r, d_out, len(s_out), _lib.MOKA_BF16, _stream_ptr(gy2.device)), "moka_up_bwd")
+                               T, r, d_out, len(s_out), dtype, _stream_ptr(gy2.device)), "moka_up_bwd")
     return g_part
 
 
@@ -133,14 +145,14 @@ def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, s_
 
 def down_bwd_(bst: BwdState, x2: torch.Tensor, AT: Optional[torch.Tensor], rt: MokaRouting, r: int,
               dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor],
-              dropout_p: float = 0.0, seed: int = 0):
+              dropout_p: float = 0.0, seed: int = 0, dtype: int = 0):
     """dA_acc[m] [r,d_in] fp32 += ; dx2 [T,d_in] bf16 += (either may be None)."""
     lib = _lib.load()
     T, d_in = x2.shape
-    _lib.check(lib.moka_down_bwd(bst.dh_tok.data_ptr(), bst.dh_kmj.data_ptr(), x2.data_ptr(),
+    _lib.check(lib.moka_down_bwd(bst.dh_tok.data_ptr(), None if bst.dh_kmj is None else bst.dh_kmj.data_ptr(), x2.data_ptr(),
                                  None if AT is None else AT.data_ptr(), rt.tok_mod.data_ptr(),
                                  None if dA_acc is None else _ptrs(dA_acc), None if dx2 is None else dx2.data_ptr(),
-                                 T, d_in, r, rt.M, float(dropout_p), int(seed), _lib.MOKA_BF16,
+                                 T, d_in, r, rt.M, float(dropout_p), int(seed), dtype,
                                  _stream_ptr(x2.device)), "moka_down_bwd")
 
 
@@ -271,6 +283,13 @@ def dropout_mask(dropout_p: float, seed: int, T: int, d_in: int, device) -> torc
     return out
 
 
+def _token_scale(rt: MokaRouting, s_out: Sequence[float], device) -> torch.Tensor:
+    """s_out[mod(t)] per token (0 for tokens of no modality), fp32 [T] -- the scale the bf16 packs carry built in."""
+    lut = torch.zeros(256, dtype=torch.float32, device=device)
+    lut[:len(s_out)] = torch.tensor([float(v) for v in s_out], dtype=torch.float32, device=device)
+    return lut[rt.tok_mod[:rt.T].long()]
+
+
 def draw_seed() -> int:
     """Per-call dropout seed from torch's CPU generator (torch.manual_seed controls it; activation
     checkpointing restores that generator before the re-forward, so the mask replays)."""
@@ -345,10 +364,7 @@ class MokaLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, bias, Bw, rt: MokaRouting, spec: AdapterSpec, *A):
         _require_device(x, "x")
-        for n, t_ in (("x", x), ("base weight", W), ("lora_B", Bw)):
-            _require_bf16(t_, n)
-        for a in A:
-            _require_bf16(a, "lora_A")
+        dt = _storage([x, W, Bw, *A], ["x", "base weight", "lora_B"] + ["lora_A"] * len(A))
         if len(spec.s_out) != rt.M or len(A) != rt.M:
             raise ValueError(f"routing describes {rt.M} modalities but {len(A)} adapters / {len(spec.s_out)} scales were given")
         d_in = x.shape[-1]
@@ -360,11 +376,18 @@ class MokaLinearFn(torch.autograd.Function):
         y = torch.nn.functional.linear(x2, W, bias)                   # frozen base, stock PyTorch-ROCm
         A = [a if a.is_contiguous() else a.contiguous() for a in A]
         Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
-        part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed)
-        st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
-        up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
-        ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
-        ctx.rt, ctx.spec, ctx.x_shape, ctx.has_bias = rt, spec, x.shape, bias is not None
+        part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
+        if dt == _lib.MOKA_F32:
+            # fp32 storage: the rank-space rows themselves are the operands (no bf16 packs, no weight shadows)
+            st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, want_hp=True)
+            hps = st.hp * _token_scale(rt, spec.s_out, x2.device)[:, None]
+            up_fwd_(y, hps, Bw_c, rt, spec.r, dtype=dt)
+            ctx.save_for_backward(x2, W, Bw_c, st.h, hps, Bw_c, None, *A)
+        else:
+            st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
+            up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
+            ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
+        ctx.rt, ctx.spec, ctx.x_shape, ctx.has_bias, ctx.dt = rt, spec, x.shape, bias is not None, dt
         return y.reshape(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -391,11 +414,17 @@ class MokaLinearFn(torch.autograd.Function):
             flat, acc = _grad_accumulators(shapes, gy2.device) if shapes else (None, [])
             dB_acc = acc[0] if need_B else None
             dA_acc = acc[(1 if need_B else 0):] if need_A else None
-        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc)
+        dt = ctx.dt
+        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt)
         dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
         if need_A or need_x:
-            bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
-            down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed)
+            if dt == _lib.MOKA_F32:
+                bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk, want_dh=True)
+                bst.dh_tok, bst.dh_kmj = bst.dh * spec.s_in, None    # the fp32 rows, scaled, stand in for the packs
+                AT = torch.stack(list(A)).contiguous()
+            else:
+                bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+            down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed, dtype=dt)
         gB, gA = None, [None] * len(A)
         if flat is not None:
             cast = _split_like(flat.to(Bw.dtype), shapes)             # one cast kernel for all weight gradients
@@ -536,6 +565,8 @@ class MokaLinearGroupFn(torch.autograd.Function):
 
 def moka_linear_group(x, projections, rt: MokaRouting, specs: Sequence[AdapterSpec]):
     """projections: list of (W, bias|None, Bw, [A_0..A_{M-1}]) fed by the same x.  Returns the list of outputs."""
+    if x.dtype == torch.float32:          # fp32 storage is a correctness path: one projection at a time
+        return [moka_linear(x, W, b, Bw, A, rt, sp) for (W, b, Bw, A), sp in zip(projections, specs)]
     G = len(projections)
     M = len(projections[0][3])
     flat = []

@@ -52,8 +52,8 @@ def test_argument_validation_sets_error_message(lib):
     dummy = ctypes.c_void_p(64)
     arr = (ctypes.c_void_p * 1)(64)
     # unsupported dtype
-    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 1, None)
-    assert rc == -2 and b"bf16" in lib.moka_last_error()
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 7, None)     # 0 = MOKA_BF16, 1 = MOKA_F32
+    assert rc == -2 and b"MOKA_BF16" in lib.moka_last_error()
     # width not a multiple of 32
     rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0.0, 0, 0, None)
     assert rc == -1 and b"multiple of 32" in lib.moka_last_error()

@@ -226,6 +226,75 @@ def test_end_to_end_vs_reference_golden(name):
             assert A[m].grad is None or float(A[m].grad.abs().max()) == 0.0
 
 
+TOL_F32_STORAGE = 1e-5
+
+
+@pytest.mark.parametrize("name", C.case_names(include_errors=False))
+def test_end_to_end_fp32_storage_vs_reference_golden(name):
+    """fp32 storage (MOKA_F32; the reference's adapters follow the base dtype, layer.py:124-132, and BASELINE.json configs[0] is
+    the fp32 case): x / W / A_m / Bw / gy in fp32 through the exact-fp32 kernels, against the fp64 outputs of the real reference
+    layers -- <= 1e-5 relative on y, dx, dA_m, dB (every golden case, `vt_cfg1_q` = configs[0]'s layer shape included)."""
+    from moka_amd.functional import moka_linear
+    dev = _dev()
+    cd = C.make_case_data(name)
+    c = cd.case
+    g = load_golden(name)
+    check_inputs(cd, g)
+    spec, rt, _ = _spec_and_routing(cd, dev)
+    f32 = torch.float32
+    x = cd.x.to(dev, f32).requires_grad_(True)
+    W = cd.W.to(dev, f32)
+    A = [a.to(dev, f32).requires_grad_(True) for a in cd.A]
+    Bw = cd.Bw.to(dev, f32).requires_grad_(True)
+    y = moka_linear(x, W, None, Bw, A, rt, spec)
+    assert y.dtype == f32
+    y.backward(cd.gy.to(dev, f32))
+    big = c.big
+    assert golden_rel_err(g, "y", y, big) < TOL_F32_STORAGE
+    assert golden_rel_err(g, "dx", x.grad, big) < TOL_F32_STORAGE
+    assert golden_rel_err(g, "dB", Bw.grad, big) < TOL_F32_STORAGE
+    for m in range(len(A)):
+        if g[f"norm_dA{m}"][0] > 0:
+            assert golden_rel_err(g, f"dA{m}", A[m].grad, big) < TOL_F32_STORAGE
+        else:
+            assert A[m].grad is None or float(A[m].grad.abs().max()) == 0.0
+
+
+def test_fp32_storage_with_dropout_replays_through_the_oracle():
+    """The fp32 kernels use the same counter-based keep mask as the bf16 ones (moka_dropout_mask): forward and all gradients
+    of a dropout run equal the oracle's replay with that mask."""
+    from moka_amd.functional import AdapterSpec, dropout_mask, moka_linear
+    dev = _dev()
+    cd = C.make_case_data("avt_tiny")
+    c = cd.case
+    spec0, rt, ro = _spec_and_routing(cd, dev)
+    p, seed = 0.1, 1234567
+    spec = AdapterSpec(spec0.r, spec0.s_in, spec0.s_out, spec0.w, spec0.inv_sqrt_dk, dropout_p=p, seed=seed)
+    f32 = torch.float32
+    x = cd.x.to(dev, f32).requires_grad_(True)
+    W = cd.W.to(dev, f32)
+    A = [a.to(dev, f32).requires_grad_(True) for a in cd.A]
+    Bw = cd.Bw.to(dev, f32).requires_grad_(True)
+    y = moka_linear(x, W, None, Bw, A, rt, spec)
+    y.backward(cd.gy.to(dev, f32))
+    keep = dropout_mask(p, seed, c.B * c.S, c.d_in, dev).reshape(c.B, c.S, c.d_in).cpu().double()
+    inv_keep = float(_lib_mod().load().moka_dropout_scale(p))
+    xm = cd.x.double() * keep * inv_keep
+    y0 = torch.nn.functional.linear(cd.x.double(), cd.W.double())
+    yo, ctx = O.adapter_forward(xm, y0, cd.A, cd.Bw, ro, spec.s_in, spec.s_out, spec.w, c.r)
+    dxm, dAo, dBo, _ = O.adapter_backward(cd.gy, ctx)
+    assert rel(y, yo) < TOL_F32_STORAGE
+    assert rel(x.grad, dxm * keep * inv_keep + cd.gy.double() @ cd.W.double()) < TOL_F32_STORAGE
+    assert rel(Bw.grad, dBo) < TOL_F32_STORAGE
+    for m in range(len(A)):
+        assert rel(A[m].grad, dAo[m]) < TOL_F32_STORAGE
+
+
+def _lib_mod():
+    from moka_amd import _lib
+    return _lib
+
+
 # ------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: Llama-2-7B projections, seq 2048, the synthetic layout of SURVEY 8(d)
 # ------------------------------------------------------------------------------------------
