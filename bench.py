@@ -35,23 +35,24 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-LLAMA7B = dict(d=4096, ff=11008, layers=32)
-# --model: the headline is Llama-2-7B; 13b = BASELINE.json configs[3] widths (run it with --rank 64 --seq 4096 --batch 2)
-MODELS = {"7b": LLAMA7B, "13b": dict(d=5120, ff=13824, layers=40)}
+LLAMA7B = dict(d=4096, ff=11008, kv=4096, layers=32)
+# --model: the headline is Llama-2-7B; 13b = BASELINE.json configs[3] widths (run it with --rank 64 --seq 4096 --batch 2);
+# 70b = configs[4] widths (grouped-query attention: k / v project 8192 -> 1024; zero_stage3_config_70b.json is about the FROZEN
+# base, which fits one 288 GB GPU in bf16 -- the adapter path this bench times is the same pure data parallelism)
+MODELS = {"7b": LLAMA7B, "13b": dict(d=5120, ff=13824, kv=5120, layers=40), "70b": dict(d=8192, ff=28672, kv=1024, layers=80)}
 # the 7 adapted projections of one decoder layer in the reference's call order
 # (AudioVisualText/models/modeling_llama.py:326-328,384,222-224): name, d_in, d_out, input id
-PROJS = [("q_proj", "d", "d", "hid"), ("k_proj", "d", "d", "hid"), ("v_proj", "d", "d", "hid"),
+PROJS = [("q_proj", "d", "d", "hid"), ("k_proj", "d", "kv", "hid"), ("v_proj", "d", "kv", "hid"),
          ("o_proj", "d", "d", "attn"), ("gate_proj", "d", "ff", "hid2"), ("up_proj", "d", "ff", "hid2"),
          ("down_proj", "ff", "d", "act")]
 E = 2  # bytes per bf16
 
 
-def algorithmic_bytes_per_token(d, ff, r, layers):
+def algorithmic_bytes_per_token(dims, r, layers):
     """fwd E(d_in + 2 d_out + 2r), bwd E(d_out + 3 d_in + 3r) per projection."""
     fwd = bwd = 0
     for _, di, do, _ in PROJS:
-        di = d if di == "d" else ff
-        do = d if do == "d" else ff
+        di, do = dims[di], dims[do]
         fwd += E * (di + 2 * do + 2 * r)
         bwd += E * (do + 3 * di + 3 * r)
     return fwd * layers, bwd * layers
@@ -128,7 +129,8 @@ def build_workload(args, dev, lib, bucket_factory):
     from moka_amd.routing import MokaRouting
     vt = args.variant == "vt"
     B, S, r, M = args.batch, args.seq, args.rank, (2 if vt else 3)
-    d, ff, L = MODELS[args.model]["d"], MODELS[args.model]["ff"], args.layers
+    dims, L = MODELS[args.model], args.layers
+    d, ff = dims["d"], dims["ff"]
     T = B * S
     tok, q = synthetic_layout(S)
     if vt:
@@ -142,7 +144,7 @@ def build_workload(args, dev, lib, bucket_factory):
         rt = MokaRouting.from_avt_masks(masks)
     RP = _lib.rank_pad(r)
     bf, f32 = torch.bfloat16, torch.float32
-    width = lambda k: d if k == "d" else ff          # noqa: E731
+    width = lambda k: dims[k]          # noqa: E731
 
     # flat parameter / gradient buckets (fp32 master, bf16 working copy, fp32 grads)
     per_layer = sum(M * r * width(di) + r * width(do) for _, di, do, _ in PROJS)
@@ -335,8 +337,7 @@ def cpu_baseline(args):
     g = torch.Generator().manual_seed(1)
     data = []
     for name, di, do, _ in PROJS:
-        d_in = d if di == "d" else ff
-        d_out = d if do == "d" else ff
+        d_in, d_out = MODELS[args.model][di], MODELS[args.model][do]
         data.append((name, torch.randn(1, S, d_in, generator=g), torch.randn(1, S, d_out, generator=g),
                      [torch.randn(r, d_in, generator=g) * 0.01 for _ in range(3)], torch.randn(d_out, r, generator=g) * 0.02,
                      torch.randn(1, S, d_out, generator=g)))
@@ -600,7 +601,7 @@ def main():
 
     out = None
     if rank == 0:
-        fwd_b, bwd_b = algorithmic_bytes_per_token(MODELS[args.model]["d"], MODELS[args.model]["ff"], args.rank, args.layers)
+        fwd_b, bwd_b = algorithmic_bytes_per_token(MODELS[args.model], args.rank, args.layers)
         algo_gbs = (fwd_b + bwd_b) * T / (ms_per_step * 1e-3) / 1e9
         # per-launch durations from the HIP events recorded on the launch stream inside the timed region
         def collect(items):

@@ -357,17 +357,19 @@ class ShardedFrozenBase:
         self.pending = [None, None]
         self.is_cuda = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.is_cuda and self.world > 1) else None
-        self._turn = 0
 
     def shard_bytes(self) -> int:
         return sum(s.numel() * s.element_size() for s in self.shards)
 
     def prefetch(self, l: int) -> None:
-        """Start gathering layer l (no-op if it is already staged or on its way)."""
-        if l < 0 or l >= len(self.shards) or l in self.holds:
+        """Start gathering layer l into staging buffer l % 2 (no-op if it is already there or on its way).  The buffer is
+        a function of the layer alone: tensors handed out for layer l in the forward are valid again -- same storage --
+        once layer l has been gathered again for its backward (autograd's saved views stay meaningful)."""
+        if l < 0 or l >= len(self.shards):
             return
-        slot = self._turn
-        self._turn ^= 1
+        slot = l & 1
+        if self.holds[slot] == l:
+            return
         if self.pending[slot] is not None:         # the buffer's previous gather must have landed before it is reused
             self._wait(slot)
         out = self.stage[slot][:self.padded[l]]
@@ -399,13 +401,49 @@ class ShardedFrozenBase:
         self.pending[slot] = None
 
     def layer(self, l: int, prefetch_next: Optional[int] = None) -> dict:
-        """Full tensors of layer l (views of a staging buffer, valid until two more layers were requested)."""
-        if l not in self.holds:
-            self.prefetch(l)
-        slot = self.holds.index(l)
+        """Full tensors of layer l (views of staging buffer l % 2, valid until a layer of the same parity is requested)."""
+        self.prefetch(l)
+        slot = l & 1
         self._wait(slot)
-        if prefetch_next is not None:
-            self._turn = slot ^ 1                  # never overwrite the buffer that was just handed out
+        if prefetch_next is not None and (prefetch_next & 1) != slot:
             self.prefetch(prefetch_next)
         buf = self.stage[slot]
         return {name: buf[o:o + math.prod(shape)].view(shape) for name, o, shape in self.meta[l]}
+
+    # ------------------------------------------------------------------------------------------------------------
+    @classmethod
+    def shard_stack(cls, stack: nn.Module, process_group=None) -> "ShardedFrozenBase":
+        """ZeRO-3-style partitioning of the FROZEN parameters of a ``MokaLlamaStack`` (or any module with ``.layers``):
+        every decoder layer's frozen tensors (everything without ``lora_`` in its name) move into the 1/N-sharded store;
+        forward pre-hooks gather layer l (and prefetch l + 1) just before it runs and point the parameters at the staging
+        buffer, backward pre-hooks do the same in reverse order (prefetching l - 1) so that the views autograd saved are
+        backed by the right data again.  The adapter parameters stay whole on every rank (``attach`` owns them)."""
+        layers = list(stack.layers)
+        dev = next(stack.parameters()).device
+        per_layer, owners = [], []
+        for layer in layers:
+            items, own = [], []
+            for n, p in layer.named_parameters():
+                if "lora_" in n or p.requires_grad:
+                    continue
+                items.append((n, p.detach()))
+                own.append((n, p))
+            per_layer.append(items)
+            owners.append(own)
+        dtype = per_layer[0][0][1].dtype
+        store = cls(per_layer, dev, process_group=process_group, dtype=dtype)
+        for own in owners:                                    # the full copies are gone: only the shards remain
+            for _, p in own:
+                p.data = torch.empty(0, dtype=p.dtype, device=dev)
+        n_layers = len(layers)
+
+        def bind(l, nxt):
+            tensors = store.layer(l, prefetch_next=nxt if 0 <= nxt < n_layers else None)
+            for n, p in owners[l]:
+                p.data = tensors[n]
+
+        store._hooks = []
+        for l, layer in enumerate(layers):
+            store._hooks.append(layer.register_forward_pre_hook(lambda _m, _a, l=l: bind(l, l + 1)))
+            store._hooks.append(layer.register_full_backward_pre_hook(lambda _m, _g, l=l: bind(l, l - 1)))
+        return store

@@ -183,3 +183,30 @@ def test_attach_feeds_the_kernels_and_matches_plain_autograd():
     assert n_checked == 3 * 7 * 4
     # layer grouping: offsets ascend layer by layer, every layer's hook fired (all buckets were shipped by the hooks)
     assert dp.bucket.n_layers == 3
+
+
+def test_sharded_frozen_base_under_the_real_stack_on_gpu():
+    """SURVEY 8(f3) on hardware (world 1: the shard is the whole layer, the machinery is the same): the frozen tensors of every
+    decoder layer live in ShardedFrozenBase, the layer hooks stage them into the two buffers for forward and backward, the
+    adapter kernels read the staged base weight -- outputs and flat adapter gradients equal the plain stack's bit for bit."""
+    dev = torch.device("cuda:0")
+    from moka_amd.parallel import ShardedFrozenBase, attach
+    st_a, dims = _build("avt", dev)
+    st_b, _ = _build("avt", dev)
+    h, gout, mask_args, _ = _batch("avt", dims, dev)
+    dp_b = attach(st_b, n_buckets=3)
+    _run(st_b, dp_b, h, gout, mask_args, 1.0)
+    dp_b.finish()
+    store = ShardedFrozenBase.shard_stack(st_a)
+    assert all(p.numel() == 0 for n, p in st_a.named_parameters() if "lora_" not in n)
+    dp_a = attach(st_a, n_buckets=3)
+    with torch.no_grad():
+        out_b, _ = st_b(h, *mask_args)
+        out_a, _ = st_a(h, *mask_args)
+    assert torch.equal(out_a, out_b)
+    _run(st_a, dp_a, h, gout, mask_args, 1.0)
+    dp_a.finish()
+    torch.cuda.synchronize()
+    err = ((dp_a.bucket.flat - dp_b.bucket.flat).norm() / dp_b.bucket.flat.norm()).item()
+    assert err <= 1e-5, err                 # (atomics order only)
+    assert store.shard_bytes() == sum(t.numel() * 2 for layer in st_b.layers for n, t in layer.named_parameters() if "lora_" not in n)

@@ -156,3 +156,83 @@ def test_attach_flattens_the_adapter_layer_by_layer_on_cpu():
         dp.step()                                   # no CPU path for the optimizer kernel
     dp.detach()
     assert q._moka_sinks is None
+
+
+class _ToyLayer(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.base = torch.nn.Linear(d, d, bias=True)
+        self.norm = torch.nn.LayerNorm(d)
+        self.lora_A = torch.nn.Linear(d, 4, bias=False)
+        self.lora_B = torch.nn.Linear(4, d, bias=False)
+
+    def forward(self, x):
+        return x + torch.tanh(self.base(self.norm(x))) + self.lora_B(self.lora_A(x))
+
+
+class _ToyStack(torch.nn.Module):
+    def __init__(self, d, n):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(_ToyLayer(d) for _ in range(n))
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+def _toy(d=24, n=5):
+    torch.manual_seed(3)
+    st = _ToyStack(d, n)
+    for n_, p in st.named_parameters():
+        p.requires_grad = "lora_" in n_
+    return st
+
+
+def _toy_run(st, x):
+    out = st(x)
+    out.square().sum().backward()
+    return out.detach().clone(), {n: p.grad.clone() for n, p in st.named_parameters() if p.grad is not None}
+
+
+def _shard_stack_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import ShardedFrozenBase
+    x = torch.randn(3, 7, 24, generator=torch.Generator().manual_seed(9)).requires_grad_(True)
+    ref_out, ref_g = _toy_run(_toy(), x)
+    gx_ref = x.grad.clone()
+    x.grad = None
+    st = _toy()
+    full = sum(p.numel() for n, p in st.named_parameters() if "lora_" not in n)
+    store = ShardedFrozenBase.shard_stack(st)
+    ok = store.shard_bytes() <= (full // world + world * 5) * 4
+    ok = ok and all(p.numel() == 0 for n, p in st.named_parameters() if "lora_" not in n)       # the full copies are gone
+    for _ in range(2):                                                                         # two steps: buffers recycle cleanly
+        for p in st.parameters():
+            p.grad = None
+        x.grad = None
+        out, g = _toy_run(st, x)
+        ok = ok and torch.allclose(out, ref_out, rtol=1e-6, atol=1e-6) and torch.allclose(x.grad, gx_ref, rtol=1e-5, atol=1e-6)
+        ok = ok and set(g) == set(ref_g) and all(torch.allclose(g[n], ref_g[n], rtol=1e-5, atol=1e-6) for n in g)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_stack_hooks_world2_forward_and_backward():
+    """ZeRO-3-style frozen base through the layer hooks (gather before a layer's forward AND before its backward, next layer
+    prefetched): outputs, input gradient and adapter gradients equal the unsharded model's, on 2 ranks over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_stack_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(2)]
+    assert all(ok for _, ok in res), res
