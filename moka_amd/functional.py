@@ -364,7 +364,7 @@ class MokaLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, bias, Bw, rt: MokaRouting, spec: AdapterSpec, *A):
         _require_device(x, "x")
-        dt = _storage([x, W, Bw, *A], ["x", "base weight", "lora_B"] + ["lora_A"] * len(A))
+        dt = _storage([x, Bw, *A] + ([W] if W is not None else []), ["x", "lora_B"] + ["lora_A"] * len(A) + ["base weight"])
         if len(spec.s_out) != rt.M or len(A) != rt.M:
             raise ValueError(f"routing describes {rt.M} modalities but {len(A)} adapters / {len(spec.s_out)} scales were given")
         d_in = x.shape[-1]
@@ -373,7 +373,10 @@ class MokaLinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         if x2.shape[0] != rt.T:
             raise ValueError(f"x has {x2.shape[0]} tokens but the masks describe {rt.T}")
-        y = torch.nn.functional.linear(x2, W, bias)                   # frozen base, stock PyTorch-ROCm
+        if W is not None:
+            y = torch.nn.functional.linear(x2, W, bias)               # frozen base, stock PyTorch-ROCm
+        else:                                                         # adapter term alone (per-sample adapter_names: several adapters add to one base output)
+            y = torch.zeros((x2.shape[0], Bw.shape[0]), dtype=x2.dtype, device=x2.device)
         A = [a if a.is_contiguous() else a.contiguous() for a in A]
         Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
         part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
@@ -401,7 +404,7 @@ class MokaLinearFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         need_B = ctx.needs_input_grad[3]
         need_A = any(ctx.needs_input_grad[6:])
-        if ctx.needs_input_grad[1]:
+        if W is not None and ctx.needs_input_grad[1]:
             raise _lib.MokaError("moka_amd: the base weight is frozen in MokA; requires_grad on it is not supported")
         if spec.sinks is not None:
             # the flat data-parallel gradient buffer is the accumulator (no temporaries, no cast, nothing returned to autograd)
@@ -416,7 +419,9 @@ class MokaLinearFn(torch.autograd.Function):
             dA_acc = acc[(1 if need_B else 0):] if need_A else None
         dt = ctx.dt
         g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt)
-        dx2 = torch.matmul(gy2, W) if need_x else None               # frozen base: dx only, never dW
+        dx2 = None
+        if need_x:                                                   # frozen base: dx only, never dW
+            dx2 = torch.matmul(gy2, W) if W is not None else torch.zeros_like(x2)
         if need_A or need_x:
             if dt == _lib.MOKA_F32:
                 bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk, want_dh=True)

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from ..functional import AdapterSpec, moka_linear
-from ..routing import GLOBAL_ROUTING_CACHE
+from ..routing import GLOBAL_ROUTING_CACHE, routing_for_samples
 from .. import _lib
 
 
@@ -192,13 +192,38 @@ class Linear(nn.Module, LoraLayer):
                 self.unmerge()
             return self.base_layer(x, *args, **kwargs)
         if adapter_names is not None:
-            raise NotImplementedError("moka_amd: per-sample `adapter_names` (mixed-batch LoRA) is outside the MokA path")
+            return self._mixed_batch_forward(x, *args, adapter_names=adapter_names, **kwargs)
         if self.merged:
             return self.base_layer(x, *args, **kwargs)
         if x.numel() == 0:                      # empty batch: the adapter adds nothing to an empty base output
             return self.base_layer(x, *args, **kwargs)
         W, bias, Bw, A, rt, spec = self._plan(x, my_text_mask, my_image_mask, question_mask)
         return moka_linear(x, W, bias, Bw, A, rt, spec)
+
+    def _mixed_batch_forward(self, x: torch.Tensor, *args: Any, adapter_names, **kwargs: Any) -> torch.Tensor:
+        """Per-sample adapters in one batch (``layer.py:346-381``; PEFT's inference-time mixed-batch LoRA, not the MokA
+        interaction): sample b gets plain LoRA with adapter ``adapter_names[b]`` -- ``__base__`` and unknown names get the
+        base output alone.  One adapter pass per distinct name over the whole batch, with a routing in which the other
+        samples' tokens belong to no modality (their tiles are skipped), added to the one base output."""
+        result = self.base_layer(x, *args, **kwargs)
+        if x.numel() == 0:
+            return result
+        xs = x if x.dim() == 3 else x.unsqueeze(1)
+        B_, S_ = xs.shape[0], xs.shape[1]
+        for name in sorted(set(adapter_names)):
+            if name == "__base__" or name not in self.lora_A.keys():
+                continue
+            idx = [i for i, item in enumerate(adapter_names) if item == name]
+            rt = routing_for_samples(B_, S_, idx, x.device)
+            drop = self.lora_dropout[name]
+            p = float(drop.p) if (isinstance(drop, nn.Dropout) and self.training) else 0.0
+            r = self.r[name]
+            spec = AdapterSpec(r, 1.0, [self.scaling[name]], 0.0, 1.0 / math.sqrt(r), dropout_p=p)
+            A_, B_w = self.lora_A[name].weight, self.lora_B[name].weight
+            if A_.dtype != x.dtype:
+                A_, B_w = A_.to(x.dtype), B_w.to(x.dtype)
+            result = result + moka_linear(xs, None, None, B_w, [A_], rt, spec).reshape(result.shape)
+        return result
 
     # gradient sinks installed by moka_amd.parallel.attach(): {"B": fp32 view for lora_B['text'], "A": [views for lora_A['text'],
     # lora_A['image']]} of the flat data-parallel gradient buffer (None: ordinary autograd gradients)

@@ -215,6 +215,17 @@ class MokaRouting:
         return cls(cls._pad_tok_mod(tok), kpos, klen, B, S, 0, M)
 
 
+def routing_for_samples(B: int, S: int, samples: Sequence[int], device) -> MokaRouting:
+    """Plain-LoRA routing of a SUBSET of the batch (per-sample ``adapter_names``, ``layer.py:346-381``): every token of the
+    listed samples goes through adapter 0, all other tokens belong to no modality (the kernels skip them), no interaction."""
+    tok = torch.full((B, S), MOD_NONE, dtype=torch.uint8, device=device)
+    if len(samples):
+        tok[torch.as_tensor(list(samples), dtype=torch.long, device=device)] = 0
+    kpos = torch.full((B, 1), -1, dtype=torch.int32, device=device)
+    klen = torch.zeros((B,), dtype=torch.int32, device=device)
+    return MokaRouting(MokaRouting._pad_tok_mod(tok), kpos, klen, B, S, 0, 1)
+
+
 class RoutingCache:
     """Routing keyed on the identity of the mask tensors (storage pointer, offset, shape, strides, dtype, version
     counter): the decoder passes the very same mask objects to all 7 x n_layers projections of a forward, so one

@@ -12,10 +12,15 @@ bench = importlib.import_module("bench")
 
 
 def test_algorithmic_bytes_match_survey_totals():
-    fwd, bwd = bench.algorithmic_bytes_per_token(4096, 11008, 16, 32)
+    fwd, bwd = bench.algorithmic_bytes_per_token(bench.MODELS["7b"], 16, 32)
     # 7B r=16: fwd 7.731 + bwd 9.573 = 17.305 MB/token
     assert abs(fwd / 1e6 - 7.731) < 2e-3 and abs(bwd / 1e6 - 9.573) < 2e-3
     assert abs((fwd + bwd) / 1e6 - 17.305) < 3e-3
+    # 13B r=64: 27.21 MB/token; 70B r=16 (grouped-query k / v: 8192 -> 1024): 90.20 MB/token
+    f13, b13 = bench.algorithmic_bytes_per_token(bench.MODELS["13b"], 64, 40)
+    assert abs((f13 + b13) / 1e6 - 27.21) < 2e-2
+    f70, b70 = bench.algorithmic_bytes_per_token(bench.MODELS["70b"], 16, 80)
+    assert abs((f70 + b70) / 1e6 - 90.20) < 5e-2
 
 
 def test_synthetic_layout_is_the_survey_layout():

@@ -804,3 +804,32 @@ def test_long_question_spans(variant, r, n_q):
     lora.py:489-499) and so do the cross kernels -- keys stream through LDS in chunks of 64 with a running softmax,
     forward and backward (round 1 refused more than 512 / 247 keys; the last three cases are beyond those limits)."""
     _stage_check(_long_question_case(f"longq_{variant}_{r}_{n_q}", variant, r, n_q))
+
+
+def test_vt_adapter_names_mixed_batch_forward():
+    """VT `adapter_names` (layer.py:346-381, PEFT's per-sample mixed-batch LoRA): sample b gets plain LoRA with its own adapter,
+    `__base__` / unknown names the base output alone; against the formula in fp64, bf16 and fp32 storage."""
+    from moka_amd.modified_peft import Linear as VtLinear
+    dev = _dev()
+    torch.manual_seed(4)
+    d_in, d_out, r, B, S = 96, 160, 8, 5, 37
+    for dtype, tol in ((torch.bfloat16, 6e-3), (torch.float32, 1e-5)):
+        base = torch.nn.Linear(d_in, d_out, bias=True)
+        m = VtLinear(base, "image", r=r, lora_alpha=16, lora_dropout=0.0, attn_weight=0.05)
+        m.update_layer("text", r, lora_alpha=16, lora_dropout=0.0, init_lora_weights=True, use_rslora=False)
+        m.set_adapter(["image", "text"])
+        for n in ("image", "text"):
+            torch.nn.init.normal_(m.lora_B[n].weight, std=0.1)
+        m = m.to(dev, dtype).eval()
+        x = torch.randn(B, S, d_in, device=dev).to(dtype)
+        names = ["text", "image", "__base__", "text", "nope"]
+        with torch.no_grad():
+            y = m(x, None, None, None, adapter_names=names)
+        xd = x.double()
+        ref = torch.nn.functional.linear(xd, base.weight.double(), base.bias.double())
+        for b_, nm in enumerate(names):
+            if nm in ("image", "text"):
+                ref[b_] += m.scaling[nm] * (xd[b_] @ m.lora_A[nm].weight.double().T) @ m.lora_B[nm].weight.double().T
+        assert rel(y, ref) < tol, (dtype, rel(y, ref))
+        with pytest.raises(ValueError):
+            m(x, None, None, None, adapter_names=names[:-1])
