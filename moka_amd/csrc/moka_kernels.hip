@@ -44,10 +44,15 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_TR_PTR(p) ((__attribute__((address_space(3))) bf16x4*)(p))
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-// Guard between MFMAs that sit behind wave-uniform branches and an LDS/global store that reads the accumulator
-// directly: on the path that skips a trailing MFMA the compiler's hazard recogniser let the store read the result
-// of the previous MFMA too early (NaN rows on hardware, tests "ragged" group case).  32 wait states cover the
-// 8-pass MFMA; the accumulator is an operand so the instruction cannot be moved across.
+// Guard in front of LDS / global stores that read an MFMA accumulator directly.  History: round 1 saw intermittent NaN rows (ragged
+// widths) when the SECOND K step of the xa / gy kernels sat behind a wave-uniform branch -- on the skipping path the store followed
+// the first MFMA after only a branch -- and fixed it twice over: the second step became branch-free (operand zeroed instead) and this
+// guard was added.  Round 2 looked at the ISA of the branch-free code (hipcc -save-temps, moka_xa_kernel<16,1,4>): on every path the
+// compiler's own spacing between the last v_mfma and the ds_write2_b32 that reads its result is 8-12 wait states (fall-through:
+// s_or / s_xor / 4 v_mov / s_nop 1; via the modality branches 11-12), at or above the 7 the hazard table asks for a 4-pass XDL op,
+// and a build WITHOUT the guard passed 13 x 23 runs of the group / ragged / fuzz / 70B-width tests.  So the branch-free rewrite was
+// the fix; the guard stays as a belt-and-braces measure because it is free (A/B on one box: 35.67 / 35.61 ms with, 35.59 / 35.65 ms
+// without) -- 32 wait states cover even an 8-pass MFMA; the accumulator is an operand so the instruction cannot be moved across.
 #define MFMA_SETTLE(acc) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc))
 
 // ------------------------------------------------------------------------------------------
