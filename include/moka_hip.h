@@ -97,14 +97,16 @@ const char* moka_last_error(void);
 int         moka_device_check(void);
 
 /* Diagnostic: override a launch heuristic ("expand_bpc", "expand_depth", "expand_nq", "wgrad_nw", "wgrad_ct", "wgrad_bpc",
- * "gy_ng", "xa_ng"; value 0 restores the default).  Results never depend on it. */
+ * "gy_ng", "xa_ng", "xa_form"; value 0 restores the default).  Results never depend on it (set "xa_form" before sizing `part`:
+ * moka_ksplit() follows it). */
 int moka_tune(const char* key, int value);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
 int moka_rank_pad(int r);
 /* Token count rounded up to the pack granularity (32). */
 int moka_tok_pad(int T);
-/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C (one per 512 columns; C = d_in).  `part` holds ks * T * RP floats. */
+/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C = d_in (one per 512 columns; one per 256 for
+ * rank pad 64).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
  * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy. */

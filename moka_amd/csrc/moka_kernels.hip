@@ -1736,6 +1736,135 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// F (second form): the same down-projection with INDEPENDENT waves.  Block = 8 waves on a [16 * sub_per_block tokens x KW
+// columns] tile (KW = 512, or 256 for rank pad 64); a wave takes whole 16-token sub-tiles (all KW columns of the slice), so its
+// [RP x 16] result is complete in its accumulators and goes straight to the split-K slice -- no per-wave partials in LDS, no
+// block reduction, no barrier in the stream (the first form pays two barriers and a 512-thread sum every two groups, with one or
+// two lock-stepped blocks per CU).  The weight fragments cannot stay in registers this way (KW / 32 K steps x modalities x
+// projections); the fragments of the modalities that occur in the block's token run are staged ONCE per block into LDS in
+// MFMA-fragment order (KW / 32 KB per modality, projection and rank tile) and read back with one conflict-free ds_read_b128 per
+// MFMA.  D^T orientation (A = weights, B = x): a lane ends up with 4 consecutive ranks of ONE token -> one 16-byte store per
+// lane and rank tile.
+// ------------------------------------------------------------------------------------------
+template <int RP, int G, int KW>
+__global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_kernel(const XaArgs a, int sub_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK;     // a sub-tile streams in NU units of HK K steps (two units in flight)
+    constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality, projection, rank tile)
+    static_assert(NU % 2 == 0, "units alternate between two buffers");
+    bf16x8* wl = (bf16x8*)smem;                              // [M][G][NT][NKS][64]
+    __shared__ unsigned s_wpm[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int nsub = (a.T + 15) >> 4;
+    const int sb0 = blockIdx.y * sub_per_block, sb1 = min(nsub, sb0 + sub_per_block);
+    if (sb0 >= nsub) return;
+    const int cb0 = blockIdx.x * KW;
+    const int nks = min(NKS, (a.C - cb0) >> 5);              // K steps of this column slice (C % 32 == 0)
+    const int nj = (sb1 - sb0 - wave + 7) >> 3;              // my sub-tiles: sb0 + wave, + 8, ...   (may be <= 0 on a ragged end)
+    const int sub_last = sb0 + wave + 8 * (max(nj, 1) - 1);  // prefetches behind my last sub-tile re-request it (L2 hit)
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    bf16x8 xA[HK], xB[HK];
+    auto issue = [&](bf16x8 (&xb)[HK], int sub_, int half) {
+        const int sub = min(min(sub_, sub_last), nsub - 1);
+        const unsigned char* row = a.x + (size_t)min(16 * sub + i, a.T - 1) * a.C * 2;
+#pragma unroll
+        for (int q = 0; q < HK; ++q) xb[q] = *(const bf16x8*)(row + (size_t)min(cb0 + 32 * (HK * half + q) + 8 * g, a.C - 8) * 2);
+    };
+    issue(xA, sb0 + wave, 0);                                // the x stream starts before the weights are staged
+
+    // modalities of the block's token run -> staged into LDS
+    {
+        unsigned bits = 0;
+        if (tid < (sb1 - sb0) * 16) {
+            const int m = a.tok_mod[sb0 * 16 + tid];
+            if (m < a.M) bits = 1u << m;
+        }
+        unsigned wb = 0;
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (__any((bits >> m) & 1u)) wb |= 1u << m;
+        if (lane == 0) s_wpm[wave] = wb;
+    }
+    __syncthreads();
+    unsigned pmB = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
+    if (pmB == 0) return;                                    // a run of padding only: nothing to write (block uniform)
+    for (int m = 0; m < a.M; ++m) {
+        if (!(pmB & (1u << m))) continue;
+        for (int e = tid; e < G * NT * FR; e += 512) {
+            const int ln = e & 63, ks = (e >> 6) % NKS, nt = (e / FR) % NT, gi = e / (FR * NT);
+            bf16x8 v = z8;
+            // rank rows >= r do not exist: clamp the row, the result rows are zeroed when the slice is written
+            if (ks < nks) v = *(const bf16x8*)(a.A[gi][m] + ((size_t)min(nt * 16 + (ln & 15), a.r - 1) * a.C + cb0 + 32 * ks + 8 * (ln >> 4)) * 2);
+            wl[(size_t)m * G * NT * FR + e] = v;
+        }
+    }
+    __syncthreads();
+
+    for (int j = 0; j < nj; ++j) {
+        const int sub = sb0 + wave + 8 * j;
+        issue(xB, sub, 1);
+        const int mrow = a.tok_mod[16 * sub + i];            // padded past T with MOKA_MOD_NONE
+        unsigned pm = 0;
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+        const bool mixed = (pm & (pm - 1)) != 0;             // span boundary inside the 16 tokens (wave uniform)
+        f32x4 acc[G][NT];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[gi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned trow = (unsigned)min(16 * sub + i, a.T - 1);
+        // one MFMA chain per modality present; in a mixed sub-tile my token only counts in the chain of its own modality.  The
+        // fragment reads of step q + 1 overlap the multiplies of step q (the sched barriers keep the compiler from hoisting all reads).
+        auto compute = [&](bf16x8 (&xb)[HK], int half) {
+#pragma unroll
+            for (int q = 0; q < HK; ++q) {
+                const int ks = HK * half + q;
+                const bf16x8 xq = (ks < nks) ? xb[q] : z8;  // branch-free: a slice of a ragged width has fewer K steps
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    bf16x8 xg = xq;
+                    if (a.drop[gi].thr) xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
+#pragma unroll
+                    for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                        if (!(pm & (1u << m))) continue;     // wave uniform
+                        const bf16x8 xm = (!mixed || mrow == m) ? xg : z8;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[gi][nt] = MFMA16(wl[(((size_t)m * G + gi) * NT + nt) * FR + ks * 64 + lane], xm, acc[gi][nt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NU; u += 2) {
+            if (u) issue(xB, sub, u + 1);
+            if (pm) compute(xA, u);
+            if (u + 2 < NU) issue(xA, sub, u + 2); else issue(xA, sub + 8, 0);
+            if (pm) compute(xB, u + 1);
+        }
+        if (pm) {
+            const float sc = mod_scale(a.s_mod, mrow);       // 0 for tokens of no modality
+            const int t = 16 * sub + i;
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    MFMA_SETTLE(acc[gi][nt]);
+                    f32x4 v;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) v[reg] = (16 * nt + 4 * g + reg < a.r && mrow < a.M) ? acc[gi][nt][reg] * sc : 0.f;
+                    if (t < a.T) *(f32x4*)(a.part[gi] + ((size_t)blockIdx.x * a.T + t) * RP + 16 * nt + 4 * g) = v;
+                }
+        }
+    }
+}
+
 // Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
 __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
     const size_t nchunk = (size_t)T * (C >> 3);
@@ -1774,9 +1903,9 @@ struct F32Args {
 // part[slice][t][k] = s_mod[mod(t)] * sum_{c in slice} drop(x)[t][c] * W_mod(t)[k][c]        (W = A_m; shared == 0)
 // g_part[slice][t][k] = s_mod[mod(t)] * sum_{c in slice} gy[t][c] * Bw[c][k]                 (shared == 1: W[0] = Bw [C][r])
 template <bool SHARED>
-__global__ void __launch_bounds__(256) moka_f32_reduce_kernel(const F32Args a) {
+__global__ void __launch_bounds__(256) moka_f32_reduce_kernel(const F32Args a, int kw) {
     const int t = blockIdx.y * 16 + (threadIdx.x >> 4), k0 = threadIdx.x & 15;
-    const int c0 = blockIdx.x * 512, c1 = min(a.C, c0 + 512);
+    const int c0 = blockIdx.x * kw, c1 = min(a.C, c0 + kw);
     if (t >= a.T) return;
     const int mod = a.tok_mod[t];
     float* dst = a.out + ((size_t)blockIdx.x * a.T + t) * a.RP;
@@ -1943,7 +2072,7 @@ static void ensure_lds(const void* kernel, size_t lds) {
 }
 
 // Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
-static int g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static int g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
     static thread_local int cached[16] = {0};
@@ -2153,6 +2282,20 @@ static void launch_xa_t(const XaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((moka_xa_kernel<RP, G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
 }
 
+template <int RP, int G>
+static int launch_xw(const XaArgs& a, hipStream_t st) {
+    constexpr int KW = (RP == 64) ? 256 : 512;               // LDS budget: M x G x RP/16 x KW/32 KB of weight fragments
+    const int nsub = (a.T + 15) / 16;
+    const int ncb = (a.C + KW - 1) / KW;
+    // sub-tiles per block: long runs amortise the weight staging, short ones give more blocks
+    int spb = (g_tune_xa_ng > 0) ? 2 * g_tune_xa_ng : 16;
+    while (spb > 8 && (long)ncb * ((nsub + spb - 1) / spb) < 2L * num_cu()) spb >>= 1;
+    const size_t lds = (size_t)MOKA_MAX_MOD * G * (RP / 16) * (KW / 32) * 1024;
+    ensure_lds((const void*)moka_xw_kernel<RP, G, KW>, lds);
+    hipLaunchKernelGGL((moka_xw_kernel<RP, G, KW>), dim3(ncb, (nsub + spb - 1) / spb), dim3(512), lds, st, a, spb);
+    return check_launch("moka_xw_kernel");
+}
+
 // r > 16: one projection per launch (G x 3 x 2 x RP/16 resident weight fragments do not fit for G > 1)
 template <int RP>
 static int launch_xa_wide(const XaArgs& a, hipStream_t st) {
@@ -2176,7 +2319,12 @@ static int launch_xa(const XaArgs& a, hipStream_t st) {
 }
 
 // number of part slices moka_down_fwd writes for input width C
-static int fwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
+// which form of the down-projection runs: the weights-in-registers form for r <= 16 (q/k/v and gate/up as one launch), the
+// independent-wave form with the weights staged in LDS for the wider ranks (measured at 13B widths, r = 64, seq 4096: 21.5 -> 13.8 ms
+// per forward pass; at r = 16 the two forms are equal within 5 % and the first one groups).  moka_tune("xa_form", 1 | 2) forces one.
+static bool use_xw(int RP) { return g_tune_xa_form == 2 || (g_tune_xa_form == 0 && RP >= 32); }
+static int fwd_kw(int r) { return (use_xw(rank_pad(r)) && rank_pad(r) == 64) ? 256 : 512; }   // columns per split-K slice
+static int fwd_ks(int /*T*/, int C, int r) { const int kw = fwd_kw(r); return (C + kw - 1) / kw; }
 
 // number of g_part slices moka_up_bwd writes for output width C
 static int bwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
@@ -2209,6 +2357,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
     else if (!strcmp(key, "xa_ng")) g_tune_xa_ng = value;
+    else if (!strcmp(key, "xa_form")) g_tune_xa_form = value;
     else if (!strcmp(key, "expand_nq")) g_tune_expand_nq = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
@@ -2259,7 +2408,7 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             f32_common(a, tok_mod, T, d_in, r, M);
             a.in = (const float*)x; a.out = part[g]; a.drop = drop[g];
             for (int m = 0; m < M; ++m) { a.W[m] = (const float*)A[g * M + m]; a.s_mod[m] = s_in * drop[g].inv_keep; }
-            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3((d_in + 511) / 512, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3(fwd_ks(T, d_in, r), (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, fwd_kw(r));
             rc = check_launch("moka_f32_reduce_kernel");
             if (rc) return rc;
         }
@@ -2278,6 +2427,10 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             xa.part[g] = part[g0 + g]; xa.drop[g] = drop[g0 + g];
             for (int m = 0; m < M; ++m) xa.A[g][m] = (const unsigned char*)A[(g0 + g) * M + m];
         }
+        if (use_xw(RP)) {                                    // independent waves, weights staged in LDS
+            if (RP == 16) rc = G == 1 ? launch_xw<16, 1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xw<16, 2>(xa, (hipStream_t)stream) : launch_xw<16, 3>(xa, (hipStream_t)stream));
+            else rc = RP == 32 ? launch_xw<32, 1>(xa, (hipStream_t)stream) : launch_xw<64, 1>(xa, (hipStream_t)stream);
+        } else
         if (RP == 16) rc = G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
         else rc = RP == 32 ? launch_xa_wide<32>(xa, (hipStream_t)stream) : launch_xa_wide<64>(xa, (hipStream_t)stream);
         if (rc) return rc;
@@ -2443,7 +2596,7 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
                 f32_common(a, tok_mod, T, d_out[g], r, M);
                 a.in = (const float*)gy[g]; a.out = g_part[g]; a.W[0] = (const float*)BwT[g];
                 for (int m = 0; m < M; ++m) a.s_mod[m] = s_out[m];
-                hipLaunchKernelGGL(moka_f32_reduce_kernel<true>, dim3(ksg, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL(moka_f32_reduce_kernel<true>, dim3(ksg, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, 512);
                 rc = check_launch("moka_f32_reduce_kernel");
                 if (rc) return rc;
             }

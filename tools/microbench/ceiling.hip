@@ -89,6 +89,17 @@ __global__ __launch_bounds__(256) void rmw_linear(u32x4* __restrict__ y, size_t 
     }
 }
 
+// reads three quarters of a buffer, writes the sum to the fourth quarter of another one
+__global__ __launch_bounds__(256) void mix31(const u32x4* __restrict__ x, u32x4* __restrict__ y, size_t nq) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + stride < nq; i += 2 * stride) {
+        u32x4 a0 = x[i], b0 = x[nq + i], c0 = x[2 * nq + i], a1 = x[i + stride], b1 = x[nq + i + stride], c1 = x[2 * nq + i + stride];
+        a0.x += b0.x + c0.x; a0.w += b0.w ^ c0.w; a1.x += b1.x + c1.x; a1.w += b1.w ^ c1.w;
+        y[3 * nq + i] = a0; y[3 * nq + i + stride] = a1;
+    }
+}
+
 static hipEvent_t e0, e1;
 template <class F> static float timeit(F f, int reps) {
     f(0); f(1);
@@ -174,6 +185,28 @@ int main() {
                 read_linear<4, false><<<grid, 256>>>((const u32x4*)(buf[b] + off), sz / 16, out); }, 16);
             printf("read_linear U=4 one launch of %.0f MB grid=%5d  %8.2f us  %7.0f GB/s\n", sz * 1e-6, grid, ms * 1e3, sz / ms * 1e-6);
         }
+    }
+    // what a read-only kernel costs BEHIND a read-modify-write kernel (the product's sequence: y += .. of one unit, then the x read of
+    // the next): dirty lines of the RMW kernel sit in the 256 MiB Infinity Cache and are written back while the read kernel allocates
+    {
+        const size_t rd = 67108864, rmw = (size_t)402653184;   // 67 MB read, 402 MB read-modify-write (q+k+v outputs)
+        auto seq = [&](bool with_rmw, bool with_read) {
+            int k = 0;
+            return timeit([&](int b) {
+                const size_t off = ((size_t)(k++ % 4) * ((size_t)512 << 20));
+                if (with_rmw) rmw_linear<4><<<2048, 256>>>((u32x4*)(buf[b] + off), rmw / 16);
+                if (with_read) read_frag<8><<<512, 512>>>(buf[1 - b] + off, 8192, 4096, 4, out);
+            }, 12);
+        };
+        const float t_rmw = seq(true, false), t_rd = seq(false, true), t_both = seq(true, true);
+        printf("sequence probe: rmw 402 MB alone %.2f us, read 67 MB alone %.2f us, rmw + read %.2f us -> the read behind the rmw costs %.2f us\n",
+               t_rmw * 1e3, t_rd * 1e3, t_both * 1e3, (t_both - t_rmw) * 1e3);
+        (void)rd;
+    }
+    // mixed traffic ceiling: 3 parts read, 1 part written (the step's mix: x / gy / base values read, y / dx written)
+    for (int grid : {1024, 2048, 4096}) {
+        float ms = timeit([&](int b) { mix31<<<grid, 256>>>((const u32x4*)buf[b], (u32x4*)buf[1 - b], n16 / 4); }, reps);
+        printf("mix 3 reads : 1 write                grid=%6d  %8.3f ms  %7.0f GB/s (r+w)\n", grid, ms, (double)bytes / ms * 1e-6);
     }
     return 0;
 }
