@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     const int nrow = min(RB, a.S - r0);
     const size_t sstride = (size_t)a.T * RP;
     // ---- round trip 1: routing (sample's key count, my row's modality, the key tokens of the first chunk)
-    constexpr int IPT = (RB * R4) / NTH, SB = (8 / IPT) < 2 ? 2 : 8 / IPT;
+    constexpr int IPT = (RB * R4) / NTH, SB = (IPT >= 4) ? 4 : 8 / IPT;      // 16 (r <= 32) / 32 (rank pad 64) loads in flight per thread
     static_assert(RB * R4 == KC * R4 && (RB * R4) % NTH == 0, "one element of each array per thread and round");
     const int Lk = a.klen[b];
     int my_mod = MOKA_MOD_NONE;
@@ -2192,7 +2192,8 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         // wider ranks: the y kernel keeps 128 columns per wave (r = 64: 48 -> 34 us at 4096), the dx kernel 64
         else if (RP == 32) { if (W_CK && g_tune_expand_nq != 2) launch_expand_t<32, 4, W_CK, 1, 2>(ab, nz, st); else launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st); }
         else { if (W_CK && g_tune_expand_nq != 1 && g_tune_expand_nq != 2) launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); else if (g_tune_expand_nq == 1) launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st); else launch_expand_t<64, 2, W_CK, 1, 2>(ab, nz, st); }
-    } else {                                             // can_group(): RP == 16
+    } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
+        // (tried for rank pad 64 too: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass)
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
         else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st);
     }
