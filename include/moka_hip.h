@@ -210,6 +210,17 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
 int   moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in, uint8_t* keep_out, moka_stream_t stream);
 float moka_dropout_scale(float dropout_p);
 
+/* ---- deterministic weight gradients -------------------------------------------------- */
+
+/* By default dA_m / dB are summed over token runs with fp32 atomics (last bits depend on the arrival order, relative spread
+ * ~1e-7).  With a workspace set (per device, from any thread), the weight-gradient kernels write one partial tile per token run into it with
+ * plain stores and a second small launch adds the runs in index order: bitwise reproducible, independent of scheduling (and of
+ * how a batch was split into launches only as far as the runs coincide).  ws == NULL switches back.  The workspace is the
+ * caller's (no persistent device allocation here); moka_deterministic_ws_bytes() is an upper bound for launches of up to G
+ * projections of width <= C_max on T tokens; a workspace that is too small makes the entry point return MOKA_EINVAL. */
+int    moka_deterministic(void* ws, size_t bytes);
+size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M);
+
 /* ---- data-parallel step on the flat adapter buffers ---------------------------------- */
 
 /* One pass over the flat fp32 adapter buffers (moka_amd/parallel.py: the gradients every weight-gradient kernel

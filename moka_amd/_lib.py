@@ -87,6 +87,8 @@ SYMBOLS = {
     # dropout_p, seed, T, d_in, keep_out, stream
     "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
     "moka_dropout_scale": (c_float, [c_float]),
+    "moka_deterministic": (c_int, [c_void_p, ctypes.c_size_t]),
+    "moka_deterministic_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     # master, work_bf16, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream
     "moka_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
                                 c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),

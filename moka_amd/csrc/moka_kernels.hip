@@ -1164,6 +1164,9 @@ struct WgradArgs {
     int T, Tp, C, r, M, groups_per_block;
     int per_mod;                    // 1: one pack plane per modality (dA); 0: single (dB)
     DropArgs drop;                  // dA only: x passes through its dropout mask
+    float* det;                     // deterministic mode: [token run][plane][det_stride] partial tiles instead of atomics (or null)
+    int det_planes, det_plane0;     // planes per run; first plane of this entry (dA: + modality; dB: the entry itself)
+    size_t det_stride;
 };
 // OUT_CK (dB): blockIdx.z selects one of the batched problems.
 // !OUT_CK (dA) with G > 1: the G entries share `in` (= x) and the routing; wave set g of a block works on entry g.
@@ -1358,7 +1361,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     int round = 0;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        if (!(any & (1u << m))) continue;                         // block uniform
+        if (!(any & (1u << m)) && !(a.det && m < (a.per_mod ? a.M : 1))) continue;   // block uniform (deterministic mode: untouched planes are written as zeros)
         const bool own = ALIAS && !(round & 1);
         float* mine = own ? (float*)my : red + (size_t)wave_all * RSZ;
         // D[row = column c (4g+reg)][col = rank k (i)]
@@ -1386,7 +1389,10 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
                 const float* src = own ? (const float*)(smem + (size_t)(ge * NW + w) * REGION) : red + (size_t)(ge * NW + w) * RSZ;
                 sum += src[OUT_CK ? cl * RPITCH + k : k * RPITCH + cl];
             }
-            atomicAdd(ag.acc[m] + (OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c)), ag.drop.thr ? sum * ag.drop.inv_keep : sum);
+            const size_t off = OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c);
+            const float val = ag.drop.thr ? sum * ag.drop.inv_keep : sum;
+            if (ag.det) ag.det[((size_t)blockIdx.y * ag.det_planes + ag.det_plane0 + m) * ag.det_stride + off] = val;
+            else atomicAdd(ag.acc[m] + off, val);
         }
         if (!ALIAS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // single buffer: reads done before the next round writes
         ++round;
@@ -1407,6 +1413,9 @@ struct GyArgs {
     float* dB;                      // [C][r] fp32 accumulate, or null
     float s_mod[4];
     int T, Tp, C, r, M;
+    float* det;                     // deterministic mode: [token run][projection][det_stride] partial tiles instead of atomics (or null)
+    int det_planes;
+    size_t det_stride;
 };
 struct GyBatch { GyArgs z[MOKA_MAX_GROUP]; };
 
@@ -1579,7 +1588,10 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
             for (int e = lane; e < CTB * 16 * RP; e += 64) {
                 const int cl = e / RP, k = e % RP;
                 const int c = c0 + cb * 16 + cl;
-                if (c < a.C && k < a.r) atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
+                if (c < a.C && k < a.r) {
+                    if (a.det) a.det[((size_t)blockIdx.y * a.det_planes + blockIdx.z) * a.det_stride + (size_t)c * a.r + k] = mine[cl * RP + k];
+                    else atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
+                }
             }
         }
     }
@@ -1898,6 +1910,9 @@ struct F32Args {
     float s_mod[4];
     int T, C, r, M, RP;
     DropArgs drop;
+    float* det;                      // deterministic mode (see WgradArgs): [token run][plane][det_stride]
+    int det_planes;
+    size_t det_stride;
 };
 
 // part[slice][t][k] = s_mod[mod(t)] * sum_{c in slice} drop(x)[t][c] * W_mod(t)[k][c]        (W = A_m; shared == 0)
@@ -1970,10 +1985,27 @@ __global__ void __launch_bounds__(256) moka_f32_wgrad_kernel(const F32Args a) {
             }
         }
         if (DA) {
-            for (int m = 0; m < a.M; ++m) atomicAdd(a.acc[m] + (size_t)k * a.C + c, acc[m] * a.drop.inv_keep);
+            for (int m = 0; m < a.M; ++m) {
+                if (a.det) a.det[((size_t)blockIdx.y * a.det_planes + m) * a.det_stride + (size_t)k * a.C + c] = acc[m] * a.drop.inv_keep;
+                else atomicAdd(a.acc[m] + (size_t)k * a.C + c, acc[m] * a.drop.inv_keep);
+            }
         } else {
-            atomicAdd(a.acc[0] + (size_t)c * a.r + k, acc[0]);
+            if (a.det) a.det[(size_t)blockIdx.y * a.det_planes * a.det_stride + (size_t)c * a.r + k] = acc[0];
+            else atomicAdd(a.acc[0] + (size_t)c * a.r + k, acc[0]);
         }
+    }
+}
+
+// Deterministic mode, second stage: acc[plane][e] += sum over the token runs of det[run][plane][e], runs in index order.
+struct SumRunsArgs { float* acc[MOKA_MAX_GROUP * MOKA_MAX_MOD]; size_t n[MOKA_MAX_GROUP * MOKA_MAX_MOD]; const float* det; int nruns, planes; size_t stride; };
+__global__ void __launch_bounds__(256) moka_sum_runs_kernel(const SumRunsArgs a) {
+    const int p = blockIdx.y;
+    float* acc = a.acc[p];
+    if (!acc) return;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < a.n[p]; e += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int rn = 0; rn < a.nruns; ++rn) v += a.det[((size_t)rn * a.planes + p) * a.stride + e];
+        acc[e] += v;
     }
 }
 
@@ -2031,6 +2063,19 @@ __global__ void __launch_bounds__(256) moka_adamw_kernel(const AdamArgs a) {
 // host side: C ABI
 // ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+
+// moka_deterministic(): workspace of the two-stage weight-gradient sums, one per device (set from any thread: PyTorch runs
+// the backward on its autograd thread; launches of one device are assumed to come from one thread at a time, as in training)
+struct DetSlot { float* ws; size_t bytes; };
+static DetSlot g_det_slots[16] = {};
+static thread_local size_t g_det_need = 0;              // set by a launcher that found the workspace too small
+#define g_det_ws (g_det_slots[current_device() & 15].ws)
+#define g_det_bytes (g_det_slots[current_device() & 15].bytes)
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -2043,13 +2088,12 @@ static int fail(int code, const char* fmt, ...) {
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MOKA_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    if (g_det_need) {                                    // the launch ran on atomics: loud, because the caller asked for determinism
+        const size_t need = g_det_need;
+        g_det_need = 0;
+        return fail(MOKA_EINVAL, "%s: the moka_deterministic() workspace is too small: %zu bytes needed, %zu given", what, need, g_det_bytes);
+    }
     return MOKA_OK;
-}
-
-static int current_device() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
-    return dev;
 }
 
 // Raise the dynamic-LDS cap of a kernel once per (device, kernel): hipFuncSetAttribute applies to the CURRENT device only, and a
@@ -2200,6 +2244,31 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
     return check_launch("moka_expand_kernel");
 }
 
+// Deterministic mode (moka_deterministic): point the nz entries of a weight-gradient launch at the workspace ([run][plane][stride]
+// partial tiles, planes = nz * per_entry) and describe the second stage.  Returns false (atomics) when the mode is off; a workspace
+// that is too small is reported through g_det_error and the launch falls back to atomics -- the entry point then fails loudly.
+static bool det_prepare(WgradBatch& ab, int nz, int per_entry, int nruns, size_t stride, SumRunsArgs* sr) {
+    if (!g_det_ws) return false;
+    const int planes = nz * per_entry;
+    const size_t need = (size_t)nruns * planes * stride * 4;
+    if (need > g_det_bytes) { g_det_need = need; return false; }
+    memset(sr, 0, sizeof(*sr));
+    sr->det = g_det_ws; sr->nruns = nruns; sr->planes = planes; sr->stride = stride;
+    for (int z = 0; z < nz; ++z) {
+        WgradArgs& a = ab.z[z];
+        a.det = g_det_ws; a.det_planes = planes; a.det_plane0 = z * per_entry; a.det_stride = stride;
+        for (int m = 0; m < per_entry; ++m) { sr->acc[z * per_entry + m] = a.acc[m]; sr->n[z * per_entry + m] = (size_t)a.C * a.r; }
+    }
+    return true;
+}
+static void det_finish(const SumRunsArgs& sr, hipStream_t st) {
+    size_t nmax = 0;
+    for (int p = 0; p < sr.planes; ++p) nmax = sr.n[p] > nmax ? sr.n[p] : nmax;
+    unsigned gx = (unsigned)((nmax + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(moka_sum_runs_kernel, dim3(gx, sr.planes), dim3(256), 0, st, sr);
+}
+
 template <int RP, int NSB, int NW, bool OUT_CK, int G>
 static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     constexpr int CCB = NSB * 64;
@@ -2219,7 +2288,10 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     nb = (ngroups + gpb - 1) / gpb;
     const size_t lds = (size_t)NW * G * NSB * 32 * 160 + (size_t)NW * G * (OUT_CK ? CCB * RP : RP * (CCB + 1)) * 4 + 64;
     ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>, lds);
+    SumRunsArgs sr;
+    const bool det = det_prepare(ab, nz, OUT_CK ? 1 : ab.z[0].M, nb, (size_t)Cmax * ab.z[0].r, &sr);
     hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
+    if (det) det_finish(sr, st);
 }
 
 // OUT_CK: nz batched problems.  !OUT_CK: nz projections sharing x (one kernel when can_group()).
@@ -2245,7 +2317,23 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
     const int ntb = ((gb.z[0].Tp >> 5) + NG - 1) / NG;
     const size_t lds = (WITH_DB ? (size_t)8 * (32 * 160) : 0) + (size_t)8 * PH * 32 * RP * 4;
     ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG>, lds);
+    SumRunsArgs sr;
+    bool det = false;
+    if (WITH_DB && g_det_ws) {                          // deterministic mode: dB partial tiles per token run, summed in run order
+        size_t stride = 0;
+        for (int z = 0; z < nz; ++z) stride = (size_t)gb.z[z].C * gb.z[z].r > stride ? (size_t)gb.z[z].C * gb.z[z].r : stride;
+        const size_t need = (size_t)ntb * nz * stride * 4;
+        if (need > g_det_bytes) g_det_need = need;
+        else {
+            det = true;
+            memset(&sr, 0, sizeof(sr));
+            sr.det = g_det_ws; sr.nruns = ntb; sr.planes = nz; sr.stride = stride;
+            GyBatch& gm = const_cast<GyBatch&>(gb);
+            for (int z = 0; z < nz; ++z) { gm.z[z].det = g_det_ws; gm.z[z].det_planes = nz; gm.z[z].det_stride = stride; sr.acc[z] = gm.z[z].dB; sr.n[z] = (size_t)gm.z[z].C * gm.z[z].r; }
+        }
+    }
     hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+    if (det) det_finish(sr, st);
 }
 
 template <int RP, bool WITH_DB>
@@ -2337,9 +2425,35 @@ static void f32_common(F32Args& a, const uint8_t* tok_mod, int T, int C, int r, 
     a.drop.inv_keep = 1.f;
 }
 
+static bool f32_det(F32Args& a, int planes, int nruns, SumRunsArgs* sr) {
+    if (!g_det_ws) return false;
+    const size_t stride = (size_t)a.C * a.r, need = (size_t)nruns * planes * stride * 4;
+    if (need > g_det_bytes) { g_det_need = need; return false; }
+    memset(sr, 0, sizeof(*sr));
+    sr->det = g_det_ws; sr->nruns = nruns; sr->planes = planes; sr->stride = stride;
+    a.det = g_det_ws; a.det_planes = planes; a.det_stride = stride;
+    for (int m = 0; m < planes; ++m) { sr->acc[m] = a.acc[m]; sr->n[m] = stride; }
+    return true;
+}
+
 extern "C" {
 
 int moka_version(void) { return MOKA_VERSION; }
+
+int moka_deterministic(void* ws, size_t bytes) {
+    if (ws && (((uintptr_t)ws & 15) || bytes < 16)) return fail(MOKA_EINVAL, "moka_deterministic: the workspace must be 16-byte aligned and non-empty");
+    DetSlot& slot = g_det_slots[current_device() & 15];
+    slot.ws = (float*)ws;
+    slot.bytes = ws ? bytes : 0;
+    g_det_need = 0;
+    return MOKA_OK;
+}
+
+size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M) {
+    if (T < 1 || C_max < 32 || rank_pad(r) < 0 || G < 1 || G > MOKA_MAX_GROUP || M < 1 || M > MOKA_MAX_MOD) return 0;
+    const size_t runs = ((size_t)T + 127) / 128;        // the shortest token run any weight-gradient launch uses
+    return runs * (size_t)(G * M) * (size_t)C_max * (size_t)r * 4;
+}
 const char* moka_last_error(void) { return g_err; }
 
 int moka_device_check(void) {
@@ -2606,7 +2720,10 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
                 F32Args a;
                 f32_common(a, tok_mod, T, d_out[g], r, M);
                 a.in = (const float*)gy[g]; a.rs = (const float*)hp_kmj[g]; a.acc[0] = dB_acc[g];
+                SumRunsArgs sr;
+                const bool det = f32_det(a, 1, (T + 255) / 256, &sr);
                 hipLaunchKernelGGL(moka_f32_wgrad_kernel<false>, dim3((d_out[g] + 15) / 16, (T + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+                if (det) det_finish(sr, (hipStream_t)stream);
                 rc = check_launch("moka_f32_wgrad_kernel");
                 if (rc) return rc;
             }
@@ -2682,7 +2799,10 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
                     if (!dA_acc[g * M + m]) return fail(MOKA_EINVAL, "moka_down_bwd: dA_acc[%d] is null", g * M + m);
                     a.acc[m] = dA_acc[g * M + m];
                 }
+                SumRunsArgs sr;
+                const bool det = f32_det(a, M, (T + 255) / 256, &sr);
                 hipLaunchKernelGGL(moka_f32_wgrad_kernel<true>, dim3((d_in + 15) / 16, (T + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+                if (det) det_finish(sr, (hipStream_t)stream);
                 rc = check_launch("moka_f32_wgrad_kernel");
                 if (rc) return rc;
             }

@@ -290,6 +290,29 @@ def _token_scale(rt: MokaRouting, s_out: Sequence[float], device) -> torch.Tenso
     return lut[rt.tok_mod[:rt.T].long()]
 
 
+_DET_WS = {}
+
+
+def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G: int = 3, M: int = 3, device=None) -> None:
+    """Bitwise-reproducible weight gradients (``moka_deterministic``): the dA_m / dB kernels write one partial tile per token
+    run into a workspace and a second launch adds the runs in order, instead of fp32 atomics.  The workspace (sized for
+    launches of up to G projections of width <= C_max on T tokens) is allocated here and kept alive; the setting is per
+    device (it also holds for the autograd thread that runs the backward)."""
+    lib = _lib.load()
+    if not enabled:
+        _lib.check(lib.moka_deterministic(None, 0), "moka_deterministic")
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    n = int(lib.moka_deterministic_ws_bytes(int(T), int(C_max), int(r), int(G), int(M)))
+    if n == 0:
+        raise ValueError("set_deterministic: bad T / C_max / r / G / M")
+    ws = _DET_WS.get(dev)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        _DET_WS[dev] = ws
+    _lib.check(lib.moka_deterministic(ws.data_ptr(), ws.numel()), "moka_deterministic")
+
+
 def draw_seed() -> int:
     """Per-call dropout seed from torch's CPU generator (torch.manual_seed controls it; activation
     checkpointing restores that generator before the re-forward, so the mask replays)."""

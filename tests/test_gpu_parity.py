@@ -833,3 +833,50 @@ def test_vt_adapter_names_mixed_batch_forward():
         assert rel(y, ref) < tol, (dtype, rel(y, ref))
         with pytest.raises(ValueError):
             m(x, None, None, None, adapter_names=names[:-1])
+
+
+def test_deterministic_weight_gradients_are_bitwise_reproducible():
+    """moka_deterministic: dA_m / dB through per-run partial tiles + an ordered second stage instead of fp32 atomics -- two runs
+    give the same BITS (the atomics path is only reproducible to ~1e-7), and the values equal the default path's to fp32
+    rounding; bf16 single projection, the q/k/v group, and fp32 storage."""
+    from moka_amd.functional import AdapterSpec, moka_linear, moka_linear_group, set_deterministic
+    dev = _dev()
+    cd = _full_case("det_case", "avt", 2, 1024, 1024, 1536, 16, 91)
+    c = cd.case
+    spec, rt, _ = _spec_and_routing(cd, dev)
+
+    def run(dtype, group):
+        x = cd.x.to(dev, dtype).requires_grad_(True)
+        W = cd.W.to(dev, dtype)
+        A = [a.to(dev, dtype).requires_grad_(True) for a in cd.A]
+        Bw = cd.Bw.to(dev, dtype).requires_grad_(True)
+        if group:
+            sp = [AdapterSpec(spec.r, spec.s_in, spec.s_out, spec.w, spec.inv_sqrt_dk) for _ in range(3)]
+            ys = moka_linear_group(x, [(W, None, Bw, A)] * 3, rt, sp)
+            sum(y.float().sum() for y in ys).backward()
+        else:
+            moka_linear(x, W, None, Bw, A, rt, spec).backward(cd.gy.to(dev, dtype))
+        torch.cuda.synchronize()
+        return [Bw.grad.clone()] + [a.grad.clone() for a in A]
+
+    for dtype, group in ((torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, False)):
+        base = run(dtype, group)
+        set_deterministic(True, T=c.B * c.S, C_max=max(c.d_in, c.d_out), r=c.r, G=3, M=3)
+        try:
+            g1 = run(dtype, group)
+            g2 = run(dtype, group)
+        finally:
+            set_deterministic(False)
+        for a, b, d in zip(g1, g2, base):
+            assert torch.equal(a, b), (dtype, group)
+            assert rel(a, d) < (1e-2 if dtype == torch.bfloat16 else 1e-5)      # bf16: the returned gradient is cast to bf16
+    # a workspace that is too small fails loudly
+    from moka_amd import _lib
+    lib = _lib.load()
+    tiny = torch.empty(4096, dtype=torch.uint8, device=dev)
+    _lib.check(lib.moka_deterministic(tiny.data_ptr(), tiny.numel()), "moka_deterministic")
+    try:
+        with pytest.raises(_lib.MokaError, match="workspace is too small"):
+            run(torch.bfloat16, False)
+    finally:
+        set_deterministic(False)
