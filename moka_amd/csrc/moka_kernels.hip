@@ -1185,7 +1185,7 @@ struct WgradBatch { WgradArgs z[MOKA_MAX_GROUP]; };
 // same token runs against the packs / accumulators of projection g.  The G waves of a run request the
 // same x lines within a short time, so the copies are served by L1 / L2 (hit-on-miss) and HBM sees
 // each line once; per-wave registers and LDS stay those of the single-projection kernel.
-template <int RP, int NSB, int NW, bool OUT_CK, int G>
+template <int RP, int NSB, int NW, bool OUT_CK, int G, bool DET>
 __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatch ab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
@@ -1361,7 +1361,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     int round = 0;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        if (!(any & (1u << m)) && !(a.det && m < (a.per_mod ? a.M : 1))) continue;   // block uniform (deterministic mode: untouched planes are written as zeros)
+        if (!(any & (1u << m)) && !(DET && m < (a.per_mod ? a.M : 1))) continue;   // block uniform (deterministic mode: untouched planes are written as zeros)
         const bool own = ALIAS && !(round & 1);
         float* mine = own ? (float*)my : red + (size_t)wave_all * RSZ;
         // D[row = column c (4g+reg)][col = rank k (i)]
@@ -1391,7 +1391,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
             }
             const size_t off = OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c);
             const float val = ag.drop.thr ? sum * ag.drop.inv_keep : sum;
-            if (ag.det) ag.det[((size_t)blockIdx.y * ag.det_planes + ag.det_plane0 + m) * ag.det_stride + off] = val;
+            if (DET) ag.det[((size_t)blockIdx.y * ag.det_planes + ag.det_plane0 + m) * ag.det_stride + off] = val;
             else atomicAdd(ag.acc[m] + off, val);
         }
         if (!ALIAS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // single buffer: reads done before the next round writes
@@ -1430,7 +1430,7 @@ struct GyBatch { GyArgs z[MOKA_MAX_GROUP]; };
 //     in the wgrad kernel, reduced over the block at the end.
 // Replaces moka_reduce_kernel + moka_wgrad_kernel<OUT_CK> on gy, which each read gy once (measured: 36 us
 // for a 67 MB gy where one pass costs ~20 us).
-template <int RP, bool WITH_DB, int NG>
+template <int RP, bool WITH_DB, int NG, bool DET>
 __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
@@ -1589,7 +1589,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
                 const int cl = e / RP, k = e % RP;
                 const int c = c0 + cb * 16 + cl;
                 if (c < a.C && k < a.r) {
-                    if (a.det) a.det[((size_t)blockIdx.y * a.det_planes + blockIdx.z) * a.det_stride + (size_t)c * a.r + k] = mine[cl * RP + k];
+                    if (DET) a.det[((size_t)blockIdx.y * a.det_planes + blockIdx.z) * a.det_stride + (size_t)c * a.r + k] = mine[cl * RP + k];
                     else atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
                 }
             }
@@ -2287,11 +2287,16 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     for (int z = 0; z < nz; ++z) ab.z[z].groups_per_block = gpb;
     nb = (ngroups + gpb - 1) / gpb;
     const size_t lds = (size_t)NW * G * NSB * 32 * 160 + (size_t)NW * G * (OUT_CK ? CCB * RP : RP * (CCB + 1)) * 4 + 64;
-    ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>, lds);
     SumRunsArgs sr;
     const bool det = det_prepare(ab, nz, OUT_CK ? 1 : ab.z[0].M, nb, (size_t)Cmax * ab.z[0].r, &sr);
-    hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
-    if (det) det_finish(sr, st);
+    if (det) {
+        ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G, true>, lds);
+        hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G, true>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
+        det_finish(sr, st);
+    } else {
+        ensure_lds((const void*)moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G, false>, lds);
+        hipLaunchKernelGGL((moka_wgrad_kernel<RP, NSB, NW, OUT_CK, G, false>), dim3(nc, nb, nzg), dim3(NW * G * 64), lds, st, ab);
+    }
 }
 
 // OUT_CK: nz batched problems.  !OUT_CK: nz projections sharing x (one kernel when can_group()).
@@ -2316,7 +2321,6 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
     constexpr int PH = (RP == 64) ? 1 : 2;
     const int ntb = ((gb.z[0].Tp >> 5) + NG - 1) / NG;
     const size_t lds = (WITH_DB ? (size_t)8 * (32 * 160) : 0) + (size_t)8 * PH * 32 * RP * 4;
-    ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG>, lds);
     SumRunsArgs sr;
     bool det = false;
     if (WITH_DB && g_det_ws) {                          // deterministic mode: dB partial tiles per token run, summed in run order
@@ -2332,8 +2336,14 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
             for (int z = 0; z < nz; ++z) { gm.z[z].det = g_det_ws; gm.z[z].det_planes = nz; gm.z[z].det_stride = stride; sr.acc[z] = gm.z[z].dB; sr.n[z] = (size_t)gm.z[z].C * gm.z[z].r; }
         }
     }
-    hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
-    if (det) det_finish(sr, st);
+    if (det) {
+        ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, WITH_DB>, lds);
+        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, WITH_DB>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+        det_finish(sr, st);
+    } else {
+        ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, false>, lds);
+        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, false>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+    }
 }
 
 template <int RP, bool WITH_DB>
