@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAVES"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc$i -o p$i -- python $REPO/bench.py --layers 4 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/run$i.log 2>&1 || echo "pass $i ($grp) failed" >> $OUT/errors.txt
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc$i -o p$i -- python $REPO/bench.py --layers 4 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic --graph off > $OUT/run$i.log 2>&1 || echo "pass $i ($grp) failed" >> $OUT/errors.txt
 done
 python $REPO/tools/rocpd_pmc_multi.py $(find /tmp/pmc* -name "*.db") > $OUT/summary.md 2>> $OUT/errors.txt
 tail -5 $OUT/errors.txt 2>/dev/null
