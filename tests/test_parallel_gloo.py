@@ -236,3 +236,54 @@ def test_shard_stack_hooks_world2_forward_and_backward():
         assert p.exitcode == 0
     res = [q.get(timeout=5) for _ in range(2)]
     assert all(ok for _, ok in res), res
+
+
+def _dp_semantics_worker(rank, world, port, comm_bf16, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import FlatGradBucket
+    from oracle import cases as C
+    from oracle import moka_oracle as O
+    cd = C.make_case_data("avt_tiny")                       # B = 2 samples: one per rank
+    c = cd.case
+    M = len(cd.A)
+    sizes = [c.d_out * c.r] + [c.r * c.d_in] * M            # dB, dA_0..dA_{M-1} -> one "layer" of a flat bucket
+    bucket = FlatGradBucket(sum(sizes), [sum(sizes)], "cpu", n_buckets=1, comm_dtype=torch.bfloat16 if comm_bf16 else None)
+
+    def grads(lo, hi):
+        masks = [m[lo:hi] for m in cd.masks]
+        rt = O.routing_from_avt_masks(masks)
+        y0 = torch.zeros(hi - lo, c.S, c.d_out, dtype=torch.float64)
+        _, ctx = O.adapter_forward(cd.x[lo:hi], y0, cd.A, cd.Bw, rt, c.alpha / c.r, [1.0] * M, c.w, c.r)
+        _, dA, dB, _ = O.adapter_backward(cd.gy[lo:hi], ctx)
+        return torch.cat([dB.reshape(-1)] + [a.reshape(-1) for a in dA]).float()
+
+    bucket.flat.copy_(grads(rank, rank + 1))                # what the weight-gradient kernels of this rank would leave
+    bucket.layer_done(0)
+    bucket.finish(average=True)
+    full = grads(0, c.B) / world                            # gradient of the MEAN loss over the whole batch
+    err = ((bucket.flat - full).norm() / full.norm()).item()
+    q.put((rank, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_bf16", [False, True])
+def test_sample_sharding_mean_of_rank_gradients_is_the_full_batch_gradient(comm_bf16):
+    """DP semantics of the adapter gradients: the batch is sharded by sample, every rank's dB / dA_m (here from
+    the oracle -- the kernels' version of this test is tests/test_gpu_dp.py) go through the flat bucket's all-reduce, and the
+    average equals the gradient of the mean loss over the whole batch (samples are independent, lora.py:485 / layer.py:628)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_semantics_worker, args=(r, 2, port, comm_bf16, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(2)]
+    tol = 2e-2 if comm_bf16 else 1e-6
+    assert all(err <= tol for _, err in res), res
