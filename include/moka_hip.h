@@ -25,10 +25,13 @@
  *       h, hp, dh     [T, RP]     fp32   rank-space activations / gradients
  *       *_tok  pack   [Tp, 2*RP]  bf16   token-major  [hi(RP) | lo(RP)]  of an fp32 row (hi+lo == value
  *                                        to 2^-17): the MFMA operand of the expand kernel
- *       *_kmj  pack   [n, 2, RP, Tp] bf16  rank-major (hi plane, lo plane), tokens permuted inside
- *                                        every group of 32 (position 8g+e holds token 4g+e for e<4,
- *                                        16+4g+e-4 otherwise): the MFMA operand of the weight-gradient
- *                                        kernel (n = 1 for hp, n = M per-modality-masked planes for dh)
+ *       *_kmj  pack   n x 2 planes (hi, lo) of RP*Tp bf16, each plane [RP/16 rank tiles][Tp/32 groups]
+ *                                        [64 lanes][8]: the 1 KB block of a (rank tile, group) holds the
+ *                                        16-byte MFMA operand fragments in lane order -- rank k, position p
+ *                                        of the group at lane (k & 15) + 16 * (p >> 3), element p & 7, where
+ *                                        position 8g+e holds token 4g+e for e<4, 16+4g+e-4 otherwise: the
+ *                                        operand of the weight-gradient kernels (n = 1 for hp, n = M
+ *                                        per-modality-masked planes for dh)
  *       BwT           [RP, d_out] bf16   transposed copy of Bw, zero padded, produced by moka_cross_fwd
  *       AT            [M, d_in, RP] bf16 transposed copies of the A_m, zero padded, produced by moka_cross_fwd
  *   - dtype: MOKA_BF16 (=0): the tuned path (bf16 storage, fp32 accumulate, MFMA).  MOKA_F32 (=1): fp32 storage of x / y / gy /

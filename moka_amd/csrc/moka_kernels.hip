@@ -171,6 +171,21 @@ static __device__ __forceinline__ int kmj_pos(int tl) {
     return (tl < 16) ? (8 * (tl >> 2) + (tl & 3)) : (8 * ((tl - 16) >> 2) + 4 + (tl & 3));
 }
 
+// *_kmj packs, per plane: [rank tile k / 16][group of 32 tokens][lane = (k & 15) + 16 * (p >> 3)][p & 7], p = kmj_pos(t & 31):
+// the 16-byte MFMA operand fragments of one (rank tile, group) are 1 KB contiguous, in lane order.  (A rank-major [RP][Tp] plane
+// made every fragment load 16 segments of 64 bytes a power-of-two stride apart -- the same L2 channel for all of them; at rank
+// pad 64 these loads were half of the weight-gradient kernels' time.)
+template <int RP>
+static __device__ __forceinline__ size_t kmj_off(int plane, int k, int t, int Tp) {
+    const int p = kmj_pos(t & 31);
+    return (((size_t)plane * (RP / 16) + (k >> 4)) * (size_t)(Tp >> 5) + (size_t)(t >> 5)) * 512 + (size_t)((((k & 15) + 16 * (p >> 3)) << 3) + (p & 7));
+}
+// fragment of (plane, rank tile nt, group grp) for this lane (the lo plane follows RP * Tp elements later)
+template <int RP>
+static __device__ __forceinline__ const unsigned short* kmj_frag(const unsigned short* pack, int plane, int nt, int grp, int Tp, int lane) {
+    return pack + (((size_t)plane * (RP / 16) + nt) * (size_t)(Tp >> 5) + (size_t)grp) * 512 + (lane << 3);
+}
+
 static __device__ __forceinline__ float mod_scale(const float* s_mod, int m) {
     float sc = 0.f;
     if (m == 0) sc = s_mod[0]; else if (m == 1) sc = s_mod[1]; else if (m == 2) sc = s_mod[2];
@@ -192,7 +207,7 @@ struct CrossArgs {
     float* out_f32;                 // fwd: h (never null)        bwd: dh or null
     float* out_f32b;                // fwd: hp or null
     unsigned short* pack_tok;       // [Tp][2*RP]
-    unsigned short* pack_kmj;       // fwd: [2][RP][Tp]   bwd: [M][2][RP][Tp]
+    unsigned short* pack_kmj;       // fwd: 2 planes (hi, lo) of RP * Tp   bwd: M x 2 planes   (layout: kmj_off)
     const unsigned short* Bw;       // fwd: [C][r] or null
     unsigned short* BwT;            // fwd: [RP][C] or null
     const unsigned short* Aw[MOKA_MAX_MOD];   // fwd: A_m [r][Cin] or null
@@ -211,9 +226,8 @@ static __device__ __forceinline__ void write_packs_fwd(const CrossArgs& a, int t
     split_hi_lo(v_scaled, hi, lo);
     a.pack_tok[(size_t)t * (2 * RP) + k] = hi;
     a.pack_tok[(size_t)t * (2 * RP) + RP + k] = lo;
-    const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
-    a.pack_kmj[((size_t)0 * RP + k) * a.Tp + pos] = hi;
-    a.pack_kmj[((size_t)1 * RP + k) * a.Tp + pos] = lo;
+    a.pack_kmj[kmj_off<RP>(0, k, t, a.Tp)] = hi;
+    a.pack_kmj[kmj_off<RP>(1, k, t, a.Tp)] = lo;
 }
 template <int RP>
 static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t, int k, int m, float v_scaled) {
@@ -221,12 +235,11 @@ static __device__ __forceinline__ void write_packs_bwd(const CrossArgs& a, int t
     split_hi_lo(v_scaled, hi, lo);
     a.pack_tok[(size_t)t * (2 * RP) + k] = hi;
     a.pack_tok[(size_t)t * (2 * RP) + RP + k] = lo;
-    const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
 #pragma unroll
     for (int mm = 0; mm < MOKA_MAX_MOD; ++mm) {
         if (mm < a.M) {
-            a.pack_kmj[(((size_t)mm * 2 + 0) * RP + k) * a.Tp + pos] = (mm == m) ? hi : (unsigned short)0;
-            a.pack_kmj[(((size_t)mm * 2 + 1) * RP + k) * a.Tp + pos] = (mm == m) ? lo : (unsigned short)0;
+            a.pack_kmj[kmj_off<RP>(mm * 2 + 0, k, t, a.Tp)] = (mm == m) ? hi : (unsigned short)0;
+            a.pack_kmj[kmj_off<RP>(mm * 2 + 1, k, t, a.Tp)] = (mm == m) ? lo : (unsigned short)0;
         }
     }
 }
@@ -513,9 +526,8 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
             unsigned short hi[4], lo[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) split_hi_lo(Hp[(row + c) * KP + k] * mod_scale(a.s_mod, s_mod[row + c]), hi[c], lo[c]);
-            const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
-            *(uint2*)(a.pack_kmj + ((size_t)0 * RP + k) * a.Tp + pos) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-            *(uint2*)(a.pack_kmj + ((size_t)1 * RP + k) * a.Tp + pos) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+            *(uint2*)(a.pack_kmj + kmj_off<RP>(0, k, t, a.Tp)) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+            *(uint2*)(a.pack_kmj + kmj_off<RP>(1, k, t, a.Tp)) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
         }
     } else {
         for (int e = tid; e < nrow * RP; e += NTH) {
@@ -533,9 +545,8 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
                 const int t = b * a.S + r0 + row;
                 unsigned short hi, lo;
                 split_hi_lo(Hp[row * KP + k] * mod_scale(a.s_mod, s_mod[row]), hi, lo);
-                const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
-                a.pack_kmj[((size_t)0 * RP + k) * a.Tp + pos] = hi;
-                a.pack_kmj[((size_t)1 * RP + k) * a.Tp + pos] = lo;
+                a.pack_kmj[kmj_off<RP>(0, k, t, a.Tp)] = hi;
+                a.pack_kmj[kmj_off<RP>(1, k, t, a.Tp)] = lo;
             }
         }
     }
@@ -799,15 +810,14 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab
                 mm4[c] = s_mod[row + c];
                 split_hi_lo((mm4[c] == MOKA_MOD_NONE) ? 0.f : Dh[(row + c) * KP + k] * a.s_mod[0], hi[c], lo[c]);
             }
-            const size_t pos = (size_t)(t & ~31) + kmj_pos(t & 31);
 #pragma unroll
             for (int mm = 0; mm < MOKA_MAX_MOD; ++mm) {
                 if (mm < a.M) {
                     unsigned short h4[4], l4[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { h4[c] = (mm4[c] == mm) ? hi[c] : (unsigned short)0; l4[c] = (mm4[c] == mm) ? lo[c] : (unsigned short)0; }
-                    *(uint2*)(a.pack_kmj + (((size_t)mm * 2 + 0) * RP + k) * a.Tp + pos) = make_uint2(h4[0] | ((unsigned)h4[1] << 16), h4[2] | ((unsigned)h4[3] << 16));
-                    *(uint2*)(a.pack_kmj + (((size_t)mm * 2 + 1) * RP + k) * a.Tp + pos) = make_uint2(l4[0] | ((unsigned)l4[1] << 16), l4[2] | ((unsigned)l4[3] << 16));
+                    *(uint2*)(a.pack_kmj + kmj_off<RP>(mm * 2 + 0, k, t, a.Tp)) = make_uint2(h4[0] | ((unsigned)h4[1] << 16), h4[2] | ((unsigned)h4[3] << 16));
+                    *(uint2*)(a.pack_kmj + kmj_off<RP>(mm * 2 + 1, k, t, a.Tp)) = make_uint2(l4[0] | ((unsigned)l4[1] << 16), l4[2] | ((unsigned)l4[3] << 16));
                 }
             }
         }
@@ -1237,7 +1247,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     auto load_pack = [&](bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp, int m) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const unsigned short* ph = a.pack + (((size_t)m * 2 + 0) * RP + nt * 16 + i) * a.Tp + (grp << 5) + 8 * g;
+            const unsigned short* ph = kmj_frag<RP>(a.pack, m * 2, nt, grp, a.Tp, lane);
             bh[nt] = *(const bf16x8*)ph;
             bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
         }
@@ -1399,6 +1409,246 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     }
 }
 
+// Wide ranks (RP = 64): the same product with the RANK TILES split across the waves of a block.
+// A wave of moka_wgrad_kernel<64> carries 16 (dB) or 48 (dA: one set per modality) accumulator tiles and runs one
+// per SIMD; its 2-deep ring then keeps only 16 KB per CU in flight and the stream stalls at ~1.5 TB/s.  Here a
+// block is 2 sets of 4 waves.  A set walks its own half of the block's token run in stages of 4 groups (128 tokens
+// x 64 columns, 16 KB): the set's 256 threads request the next stage (four 16-byte loads each), write the
+// current one -- through the dropout mask -- into the set's LDS buffer, and after one LDS-only barrier wave nt
+// multiplies the WHOLE transposed tile by ITS rank tile nt of the pack (4 or 12 accumulator tiles per wave; the
+// pack fragments are prefetched like the tile).  64 KB per CU in flight, two waves per
+// SIMD whose LDS / MFMA phases overlap.  At the end the two sets exchange halves of their accumulators through
+// the idle stage buffers and every wave sends its sums to memory straight from the MFMA result registers: the
+// operand roles are chosen so that the 16 lanes of a row cover 64 contiguous bytes of the destination
+// (dA [r][C]: A = pack, B = x^T, lanes run over columns;  dB [C][r]: A = x^T, B = pack, lanes run over ranks).
+template <bool OUT_CK, bool DET>
+__global__ void __launch_bounds__(512) moka_wgrad_wide_kernel(const WgradBatch ab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RP = 64, CT = 4, SG = 4, NSET = 2;
+    constexpr int NM = OUT_CK ? 1 : MOKA_MAX_MOD;
+    constexpr int PITCH = 64 * 2 + 32;              // bytes per LDS row; odd multiple of 32
+    constexpr int STAGE = SG * 32 * PITCH;          // 20480
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int set = wave_all >> 2, nt = wave_all & 3;
+    const WgradArgs& a = ab.z[blockIdx.z];
+    const int i = lane & 15, g = lane >> 4;
+    const int c_begin = blockIdx.x * 64;
+    if (c_begin >= a.C) return;                     // batched problems of different width (block uniform)
+    unsigned char* buf0 = smem + (size_t)set * 2 * STAGE;
+    unsigned* touched = (unsigned*)(smem + (size_t)NSET * 2 * STAGE);
+    if (tid == 0) *touched = 0;
+    const int ngroups = a.Tp >> 5, grp_last = ngroups - 1;
+    const int grp_begin = blockIdx.y * a.groups_per_block;
+    const int grp_end = min(ngroups, grp_begin + a.groups_per_block);
+    const int per_set = ((grp_end - grp_begin + NSET - 1) / NSET + SG - 1) / SG * SG;
+    const int nstages = (per_set / SG + 1) & ~1;    // block uniform (both sets pass the same barriers), even: a stage past the set's run
+                                                    // re-requests its last group and multiplies nothing
+    const int sbeg = grp_begin + set * per_set;
+    const int send = min(grp_end, sbeg + per_set);
+    const int st = tid & 255, lrow = st >> 3, lcol = st & 7;
+
+    f32x4 acc[NM][CT];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[m][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned ever = 0;
+
+    // routing bytes of a stage (two groups per load) -> 4 bits per group: modalities present (dB: bit 0 = any routed token)
+    auto load_rv = [&](int (&rv)[2], int g0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int gq = g0 + 2 * h + (lane >> 5);
+            rv[h] = a.tok_mod[(min(gq, grp_last + 1) << 5) + (lane & 31)];             // padded past T: unconditional; used raw, one
+        }                                                                                    // iteration later (no ALU on it here: that would be a wait)
+    };
+    auto present_of = [&](const int (&rv)[2], int g0) -> unsigned {
+        unsigned pm = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool valid = g0 + 2 * h + (lane >> 5) < send;
+#pragma unroll
+            for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                if (m >= a.M) continue;
+                const unsigned long long bm = __ballot(valid && rv[h] == m);
+                const unsigned bit = a.per_mod ? (1u << m) : 1u;
+                if ((unsigned)bm) pm |= bit << (4 * (2 * h));
+                if ((unsigned)(bm >> 32)) pm |= bit << (4 * (2 * h + 1));
+            }
+        }
+        return pm;
+    };
+    auto load_pack = [&](bf16x8& bh, bf16x8& bl, int grp, int m) {
+        const unsigned short* ph = kmj_frag<RP>(a.pack, m * 2, nt, min(grp, grp_last), a.Tp, lane);
+        bh = *(const bf16x8*)ph;
+        bl = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
+    };
+    // a stage's tile (clamped, unconditional) / the pack fragments of each of its groups' first modality
+    auto issue_x = [&](uint4 (&ld)[SG], int g0) {
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const int grp = min(g0 + u, grp_last);
+            const size_t rowoff = (size_t)min((grp << 5) + lrow, a.T - 1) * a.C;
+            const int c = min(c_begin + lcol * 8, a.C - 8);                              // C % 32 == 0; columns >= C never reach the output
+            ld[u] = *(const uint4*)(a.in + (rowoff + c) * 2);
+        }
+    };
+    auto issue_pack = [&](bf16x8 (&bh)[SG], bf16x8 (&bl)[SG], int g0, unsigned pm) {
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const unsigned pu = (pm >> (4 * u)) & 15u;
+            load_pack(bh[u], bl[u], g0 + u, pu ? __builtin_ctz(pu) : 0);
+        }
+    };
+    auto stage_write = [&](uint4 (&ld)[SG], unsigned char* buf, int g0) {
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            uint4 v = ld[u];
+            if (a.drop.thr) {
+                const unsigned trow = (unsigned)min((min(g0 + u, grp_last) << 5) + lrow, a.T - 1);
+                const KeepMask keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)(c_begin >> 3) + (unsigned)lcol);
+                bf16x8 t8 = drop_apply(*(bf16x8*)&v, keep);
+                v = *(uint4*)&t8;
+            }
+            *(uint4*)(buf + (u * 32 + lrow) * PITCH + lcol * 16) = v;
+        }
+    };
+    auto compute = [&](const unsigned char* buf, bf16x8 (&bh0)[SG], bf16x8 (&bl0)[SG], int g0, unsigned pm) {
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const unsigned pu = (pm >> (4 * u)) & 15u;
+            if (!pu) continue;
+            ever |= pu;
+            const int mfirst = __builtin_ctz(pu);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                if (!(pu & (1u << m))) continue;
+                bf16x8 bh = bh0[u], bl = bl0[u];
+                if (m != mfirst) {
+                    // a group that straddles a span boundary (rare): its other planes are fetched here, by loads the compiler's
+                    // vmcnt bookkeeping does not see -- a load it MIGHT have issued makes every later wait a vmcnt(0) and the
+                    // ring would drain in every stage.  The explicit wait drains it on this path only.
+                    const unsigned short* ph = kmj_frag<RP>(a.pack, m * 2, nt, min(g0 + u, grp_last), a.Tp, lane);
+                    const unsigned short* pl = ph + (size_t)RP * a.Tp;
+                    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(bh), "=&v"(bl) : "v"(ph), "v"(pl) : "memory");
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const unsigned char* base = buf + (u * 32 + 4 * g + (i >> 2)) * PITCH + (ct * 16 + 4 * (i & 3)) * 2;
+                    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
+                    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * PITCH));
+                    const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    if (OUT_CK) {
+                        acc[m][ct] = MFMA16(av, bh, acc[m][ct]);      // D[column 4g+reg][rank i]
+                        acc[m][ct] = MFMA16(av, bl, acc[m][ct]);
+                    } else {
+                        acc[m][ct] = MFMA16(bh, av, acc[m][ct]);      // D[rank 4g+reg][column i]
+                        acc[m][ct] = MFMA16(bl, av, acc[m][ct]);
+                    }
+                }
+            }
+        }
+    };
+
+    // Two register stages and the LDS buffer make a pipeline three deep: as soon as stage t has gone from its registers into
+    // LDS, the same registers take the request for stage t+2, so the tiles of t+1 and t+2 (2 x 16 KB per set) are in flight
+    // while t is multiplied; the pack fragments of t+2 follow once those of t have been used, and the routing bytes of t+3 go
+    // out ahead of the tile.  The only wait of an iteration is the one on the routing bytes of t+2 at its top: everything
+    // older (tile and fragments of t) has landed with them, everything younger (12 requests) stays in flight.
+    uint4 ldA[SG], ldB[SG];
+    bf16x8 bhA[SG], blA[SG], bhB[SG], blB[SG];
+    unsigned pm_cur, pm_nxt;
+    int rv[2];
+    {
+        int rv0[2], rv1[2];
+        load_rv(rv0, sbeg);
+        load_rv(rv1, sbeg + SG);
+        pm_cur = present_of(rv0, sbeg);
+        pm_nxt = present_of(rv1, sbeg + SG);
+        // the same order of requests as a loop iteration leaves behind (fenced: the scheduler would interleave them), so that the
+        // compiler's wait counts of the loop entry and of the back edge merge exactly
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(ldA, sbeg);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pack(bhA, blA, sbeg, pm_cur);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rv(rv, sbeg + 2 * SG);
+        issue_x(ldB, sbeg + SG);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pack(bhB, blB, sbeg + SG, pm_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int s = 0; s < nstages; s += 2) {
+        int g0 = sbeg + s * SG;
+        unsigned pm_nn = present_of(rv, g0 + 2 * SG);      // stage s + 2
+        stage_write(ldA, buf0, g0);
+        load_rv(rv, g0 + 3 * SG);
+        issue_x(ldA, g0 + 2 * SG);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        compute(buf0, bhA, blA, g0, pm_cur);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pack(bhA, blA, g0 + 2 * SG, pm_nn);
+        __builtin_amdgcn_sched_barrier(0);
+        pm_cur = pm_nxt; pm_nxt = pm_nn;
+
+        g0 += SG;
+        pm_nn = present_of(rv, g0 + 2 * SG);               // stage s + 3
+        stage_write(ldB, buf0 + STAGE, g0);
+        load_rv(rv, g0 + 3 * SG);
+        issue_x(ldB, g0 + 2 * SG);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        compute(buf0 + STAGE, bhB, blB, g0, pm_cur);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pack(bhB, blB, g0 + 2 * SG, pm_nn);
+        __builtin_amdgcn_sched_barrier(0);
+        pm_cur = pm_nxt; pm_nxt = pm_nn;
+    }
+
+    // ---- the two sets exchange halves (set 0 keeps column tiles 0-1, set 1 keeps 2-3) through the idle stage buffers
+    if (lane == 0 && ever) atomicOr(touched, ever);
+    __syncthreads();                                // every compute() done: the stage buffers are free
+    const unsigned any = *touched;
+    float* xch = (float*)smem;                      // [set][m][2 ct][4 reg][256]   (2 * 3 * 8 * 1 KB = 48 KB)
+    constexpr int HALF = CT / 2;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        if (!(any & (1u << m))) continue;
+#pragma unroll
+        for (int h = 0; h < HALF; ++h) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)                   // the half the OTHER set keeps
+                xch[(((size_t)(set * NM + m) * HALF + h) * 4 + reg) * 256 + nt * 64 + lane] = (set == 0) ? acc[m][HALF + h][reg] : acc[m][h][reg];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const bool live = any & (1u << m);
+        if (!live && !(DET && m < (a.per_mod ? a.M : 1))) continue;   // deterministic mode: untouched planes are written as zeros
+#pragma unroll
+        for (int h = 0; h < HALF; ++h) {
+            const int ct = (set == 0) ? h : HALF + h;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float v = 0.f;
+                if (live) {
+                    const float mine = (set == 0) ? acc[m][h][reg] : acc[m][HALF + h][reg];
+                    v = mine + xch[(((size_t)((1 - set) * NM + m) * HALF + h) * 4 + reg) * 256 + nt * 64 + lane];
+                }
+                const int k = OUT_CK ? nt * 16 + i : nt * 16 + 4 * g + reg;
+                const int c = c_begin + ct * 16 + (OUT_CK ? 4 * g + reg : i);
+                if (c >= a.C || k >= a.r) continue;
+                const size_t off = OUT_CK ? ((size_t)c * a.r + k) : ((size_t)k * a.C + c);
+                const float val = a.drop.thr ? v * a.drop.inv_keep : v;
+                if (DET) a.det[((size_t)blockIdx.y * a.det_planes + a.det_plane0 + m) * a.det_stride + off] = val;
+                else atomicAdd(a.acc[m] + off, val);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Y: one pass over gy for BOTH halves of moka_up_bwd (r <= 16):
 //      g_part[cb][t][k] = s_out[mod(t)] * sum_{c in column block cb} gy[t][c] BwT[k][c]
@@ -1488,7 +1738,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
         if (WITH_DB) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned short* ph = a.pack + ((size_t)(nt * 16 + i)) * a.Tp + (grp << 5) + 8 * g;
+                const unsigned short* ph = kmj_frag<RP>(a.pack, 0, nt, grp, a.Tp, lane);
                 bh[nt] = *(const bf16x8*)ph;
                 bl[nt] = *(const bf16x8*)(ph + (size_t)RP * a.Tp);
             }
@@ -2277,8 +2527,7 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     const int nc = (Cmax + CCB - 1) / CCB;
     const int ngroups = ab.z[0].Tp / 32;
     // 4-wave blocks (wide inputs): three per CU, so that the 172 column blocks of an 11008-wide input spread evenly (55 -> 50 us)
-    // (RP = 64 runs 4-wave blocks for its register budget, not for width: one per CU, 61 -> 43 us)
-    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : ((NW == 4 && G == 1 && RP < 64) ? 3 : 1);
+    const int bpc = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc : ((NW == 4 && G == 1) ? 3 : 1);
     const int nzg = (G == 1) ? nz : 1;                  // grid z
     int nb = (bpc * num_cu() + nc * nzg - 1) / (nc * nzg);
     if (nb > (ngroups + NW - 1) / NW) nb = (ngroups + NW - 1) / NW;
@@ -2299,16 +2548,46 @@ static void launch_wgrad_t(WgradBatch& ab, int nz, hipStream_t st) {
     }
 }
 
+// RP = 64: one 8-wave block per CU (its LDS and the in-flight budget are sized for that); as many token runs as fit
+template <bool OUT_CK>
+static void launch_wgrad_wide(WgradBatch& ab, int nz, hipStream_t st) {
+    int Cmax = 0;
+    for (int z = 0; z < nz; ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
+    const int nc = (Cmax + 63) / 64;
+    const int ngroups = ab.z[0].Tp / 32;
+    const int target = g_tune_wgrad_bpc > 0 ? g_tune_wgrad_bpc * num_cu() : num_cu();
+    int nb = target / (nc * nz);                        // never more blocks than CUs: a second round would double the launch
+    if (nb > (ngroups + 7) / 8) nb = (ngroups + 7) / 8;
+    if (nb < 1) nb = 1;
+    const int gpb = (ngroups + nb - 1) / nb;
+    for (int z = 0; z < nz; ++z) ab.z[z].groups_per_block = gpb;
+    nb = (ngroups + gpb - 1) / gpb;
+    const size_t lds = (size_t)2 * 2 * 4 * 32 * 160 + 64;
+    SumRunsArgs sr;
+    const bool det = det_prepare(ab, nz, OUT_CK ? 1 : ab.z[0].M, nb, (size_t)Cmax * ab.z[0].r, &sr);
+    if (det) {
+        ensure_lds((const void*)moka_wgrad_wide_kernel<OUT_CK, true>, lds);
+        hipLaunchKernelGGL((moka_wgrad_wide_kernel<OUT_CK, true>), dim3(nc, nb, nz), dim3(512), lds, st, ab);
+        det_finish(sr, st);
+    } else {
+        ensure_lds((const void*)moka_wgrad_wide_kernel<OUT_CK, false>, lds);
+        hipLaunchKernelGGL((moka_wgrad_wide_kernel<OUT_CK, false>), dim3(nc, nb, nz), dim3(512), lds, st, ab);
+    }
+}
+
 // OUT_CK: nz batched problems.  !OUT_CK: nz projections sharing x (one kernel when can_group()).
 template <bool OUT_CK>
 static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
+    if (RP == 64) {
+        launch_wgrad_wide<OUT_CK>(ab, nz, st);
+        return check_launch("moka_wgrad_wide_kernel");
+    }
     if (OUT_CK || nz == 1) {
         if (RP == 16) {
             if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK, 1>(ab, nz, st);
             else if (g_tune_wgrad_nw == 4 || (g_tune_wgrad_nw == 0 && !OUT_CK && ab.z[0].C > 8192)) launch_wgrad_t<16, 1, 4, OUT_CK, 1>(ab, nz, st);   // measured at C = 11008: 56 vs 60 us
             else launch_wgrad_t<16, 1, 8, OUT_CK, 1>(ab, nz, st);
-        } else if (RP == 32) launch_wgrad_t<32, 1, 8, OUT_CK, 1>(ab, nz, st);
-        else launch_wgrad_t<64, 1, 4, OUT_CK, 1>(ab, nz, st);
+        } else launch_wgrad_t<32, 1, 8, OUT_CK, 1>(ab, nz, st);
     } else {                                             // can_group(): RP == 16
         if (nz == 2) launch_wgrad_t<16, 1, 4, false, 2>(ab, nz, st);
         else launch_wgrad_t<16, 1, 4, false, 3>(ab, nz, st);

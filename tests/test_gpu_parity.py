@@ -138,10 +138,16 @@ def _stage_check(cd, y0=None, tol_f32=TOL_F32):
     hps = (ctx.hp * scale).reshape(T, r)
     tokpack = st.hp_tok[:T].float()
     assert rel((tokpack[:, :RP] + tokpack[:, RP:])[:, :r], hps) < tol_f32, "hp_tok pack"
+    # layout of a plane (moka_hip.h): [rank tile][group of 32 tokens][lane = (k & 15) + 16 * (p >> 3)][p & 7], p = position of the
+    # token inside its group (tokens 0-3 -> 0-3, 4-7 -> 8-11, ..., 16-19 -> 4-7, ...)
     Tp = st.hp_kmj.shape[2]
-    tl = torch.arange(Tp) % 32
-    pos = torch.where(tl < 16, 8 * (tl // 4) + tl % 4, 8 * ((tl - 16) // 4) + 4 + tl % 4) + (torch.arange(Tp) // 32) * 32
-    kmj = (st.hp_kmj[0].float() + st.hp_kmj[1].float()).cpu()[:, pos]          # [RP, Tp] in natural token order
+    tt = torch.arange(Tp)
+    tl = tt % 32
+    p = torch.where(tl < 16, 8 * (tl // 4) + tl % 4, 8 * ((tl - 16) // 4) + 4 + tl % 4)
+    kk = torch.arange(RP).reshape(RP, 1)
+    off = ((kk // 16) * (Tp // 32) + (tt // 32).reshape(1, Tp)) * 512 + ((kk % 16) + 16 * (p // 8).reshape(1, Tp)) * 8 + (p % 8).reshape(1, Tp)
+    flat = (st.hp_kmj[0].float() + st.hp_kmj[1].float()).cpu().reshape(-1)
+    kmj = flat[off]                                                              # [RP, Tp] in natural (rank, token) order
     assert rel(kmj[:r, :T].t(), hps) < tol_f32, "hp_kmj pack"
     assert float(kmj[:, T:].abs().max() if Tp > T else 0.0) == 0.0
     assert torch.equal(st.BwT[:r].cpu(), cd.Bw.to(bf).t().contiguous()), "BwT"
