@@ -919,7 +919,7 @@ struct ExpandBatch { ExpandArgs z[MOKA_MAX_GROUP]; };
 // for the whole block, other modalities' fragments are fetched from L2 for the (few) tiles that need them.
 // G > 1 (dx only): G projections read the same x (q/k/v, gate/up), so their input gradients land in the
 // same dx: one read-modify-write pass adds all G terms (each through its own dropout mask).
-template <int RP, int NQ, bool W_CK, int G, int DEPTH>
+template <int RP, int NQ, bool W_CK, int G, int DEPTH, bool RUNS>
 __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) {
     constexpr int KH = (RP + 31) / 32;                 // 32-wide rank blocks per hi (or lo) plane
     constexpr int WC = NQ * 32;                        // columns per wave
@@ -956,6 +956,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
                 for (int kh = 0; kh < KH; ++kh) wf0[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[0], q, p, kh);
 
+    int mcur = 0;                                                 // RUNS: modality of the resident weight set
     const int ntiles = (a.T + 15) >> 4;
     const size_t prow = (size_t)(2 * RP) * 2;                     // pack row bytes
     const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -975,8 +976,15 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     };
     auto body = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
+    // tiles of this wave: blockIdx.y, + gridDim.y, ... ; RUNS: the contiguous run [t_first, t_last) -- spans are contiguous in the
+    // token order, so a run stays inside one modality for long stretches and ONE resident weight set (reloaded at span
+    // boundaries) replaces "text resident + the others fetched per tile"
+    const int t_per = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_first = RUNS ? (int)blockIdx.y * t_per : (int)blockIdx.y;
+    const int t_last = RUNS ? min(ntiles, t_first + t_per) : ntiles;
+    const int step = RUNS ? 1 : (int)gridDim.y;
     auto issue = [&](Tile& R, int tile) {
-        const int tt = min(tile, ntiles - 1);
+        const int tt = min(tile, t_last - 1);
         const int t = min((tt << 4) + i, a.T - 1);                // operand / result lanes: token = lane & 15
         R.mrow = a.tok_mod[(tt << 4) + i];
         // B operand: my token's pack row.  RP == 16: K = 32 is [hi(16) | lo(16)] = elements 8g..8g+7 of the row.
@@ -1032,7 +1040,55 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
                         if (RP != 16) d[gi][q][p] = MFMA16(wf[q][p][kh], mine ? R.bl[gi][kh] : z8, d[gi][q][p]);
                     }
         };
-        if (W_CK || (same && m0 == 0)) {
+        if constexpr (RUNS && !W_CK) {
+            // the resident set follows the run: reloaded (from the L2-resident shadow) when the tile's modality differs from it
+            // In place, by loads the compiler does not see, followed by an explicit wait (nothing else is in flight at this point: the
+            // tile's own data has landed, the prefetch has not gone out): written as ordinary loads the conditional reload costs 84
+            // more registers -- the fragments are fetched into temporaries and copied -- and a wave per SIMD.
+            auto reload = [&](int m) {
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int kh = 0; kh < KH; ++kh) {
+                                const int c = min(c_wave + 32 * q + 8 * (i >> 2) + 4 * p + (i & 3), a.C - 1);   // columns >= C are never stored
+                                const unsigned short* src = (const unsigned short*)ab.z[G == 1 ? blockIdx.z : gi].W[m] + (size_t)c * RP + ((RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g);
+                                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(wf0[gi][q][p][kh]) : "v"(src) : "memory");
+                            }
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int kh = 0; kh < KH; ++kh) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf0[gi][q][p][kh]) : : "memory");
+                mcur = m;
+            };
+            if (same) {
+                if (m0 != mcur && m0 < a.M) reload(m0);                       // wave uniform (a padding tile multiplies zeros with any set)
+                issue(N, next_tile);
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) chain(gi, wf0[gi], mrow < a.M);
+            } else {
+                // a span boundary inside the tile (rare): one chain per modality present, the other tokens masked out of the operand
+                issue(N, next_tile);
+                unsigned todo = 0;
+#pragma unroll
+                for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) todo |= 1u << m;
+#pragma unroll 1
+                while (todo) {
+                    const int m = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    if (m != mcur) reload(m);
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) chain(gi, wf0[gi], mrow == m);
+                }
+            }
+        } else if (W_CK || (same && m0 == 0)) {
             // shared Bw (the modality scale is in the pack) / all-text tile: resident fragments
             issue(N, next_tile);
 #pragma unroll
@@ -1131,14 +1187,13 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     // ring of DEPTH tiles: while tile j is processed, tiles j+1 .. j+DEPTH-1 are in flight; processing tile j
     // issues the prefetch of tile j+DEPTH-1 into the slot tile j-1 has just left
     Tile ring[DEPTH];
-    const int step = gridDim.y;
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) issue(ring[d], blockIdx.y + d * step);
-    for (int tile = blockIdx.y; tile < ntiles; tile += DEPTH * step) {
+    for (int d = 0; d < DEPTH - 1; ++d) issue(ring[d], t_first + d * step);
+    for (int tile = t_first; tile < t_last; tile += DEPTH * step) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int tj = tile + d * step;
-            if (tj >= ntiles) break;
+            if (tj >= t_last) break;
             process(ring[d], tj, ring[(d + DEPTH - 1) % DEPTH], tj + (DEPTH - 1) * step);
         }
     }
@@ -1147,13 +1202,14 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     // one 16-byte look at the routing bytes of each of my tiles (lane j <-> my j-th tile) decides the path
     bool fast = (c_wave + WC <= a.C) && (a.T % 16 == 0) && (((size_t)a.tok_mod & 15) == 0);
     {
-        const int step = gridDim.y;
-        const int nmine = (ntiles - (int)blockIdx.y + step - 1) / step;
-        if (nmine > 64) fast = false;
+        const int per = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int first = RUNS ? (int)blockIdx.y * per : (int)blockIdx.y, stp = RUNS ? 1 : (int)gridDim.y;
+        const int nmine = RUNS ? min(ntiles, first + per) - first : (ntiles - first + stp - 1) / stp;
+        if (nmine > 64 || nmine < 1) fast = false;
         if (fast) {
             bool pad = false;
             if (lane < nmine) {
-                const uint4 m = *(const uint4*)(a.tok_mod + ((size_t)(blockIdx.y + lane * step) << 4));
+                const uint4 m = *(const uint4*)(a.tok_mod + ((size_t)(first + lane * stp) << 4));
                 pad = (m.x & m.y & m.z & m.w) == 0xffffffffu;      // all 16 tokens of the tile have no modality
             }
             if (__any(pad)) fast = false;
@@ -2463,7 +2519,7 @@ static int launch_cross(bool bwd, CrossBatch& ab, int nz, const moka_routing* rt
     return check_launch(fn);
 }
 
-template <int RP, int NQ, bool W_CK, int G, int DEPTH>
+template <int RP, int NQ, bool W_CK, int G, int DEPTH, bool RUNS = false>
 static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     constexpr int CW = 4 * NQ * 32;
     int Cmax = 0;
@@ -2474,7 +2530,7 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     int gy = (bpc * num_cu() + nc * nz - 1) / (nc * nz);   // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G, DEPTH>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, ab);
+    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G, DEPTH, RUNS>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, ab);
 }
 
 // W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
@@ -2482,10 +2538,18 @@ template <bool W_CK>
 static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) {
     // two tiles in flight per wave everywhere (measured: 3-4 deep rings gain nothing once loads and stores are unconditional)
     if (W_CK || nz == 1) {
+        // RP == 16: the per-tile form (text set resident, the others fetched for the tiles that need them); contiguous runs with one
+        // resident set lose there (dx pass 11.1 -> 11.8 ms), win at rank pad 32 (16.2 -> 15.9) and 64 (37.4 -> 30.7, with 128 columns per wave)
         if (RP == 16) { if (g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
         // wider ranks: the y kernel keeps 128 columns per wave (r = 64: 48 -> 34 us at 4096), the dx kernel 64
-        else if (RP == 32) { if (W_CK && g_tune_expand_nq != 2) launch_expand_t<32, 4, W_CK, 1, 2>(ab, nz, st); else launch_expand_t<32, 2, W_CK, 1, 2>(ab, nz, st); }
-        else { if (W_CK && g_tune_expand_nq != 1 && g_tune_expand_nq != 2) launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); else if (g_tune_expand_nq == 1) launch_expand_t<64, 1, W_CK, 1, 2>(ab, nz, st); else launch_expand_t<64, 2, W_CK, 1, 2>(ab, nz, st); }
+        else if (RP == 32) {
+            if (W_CK) { if (g_tune_expand_nq != 2) launch_expand_t<32, 4, true, 1, 2>(ab, nz, st); else launch_expand_t<32, 2, true, 1, 2>(ab, nz, st); }
+            else if (g_tune_expand_nq == 3) launch_expand_t<32, 2, false, 1, 2>(ab, nz, st);        // the per-tile form (A/B)
+            else launch_expand_t<32, 4, false, 1, 2, true>(ab, nz, st);
+        }
+        else if (W_CK) { if (g_tune_expand_nq == 2) launch_expand_t<64, 2, true, 1, 2>(ab, nz, st); else launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); }
+        else if (g_tune_expand_nq == 3) launch_expand_t<64, 2, false, 1, 2>(ab, nz, st);            // the per-tile form (A/B)
+        else launch_expand_t<64, 4, false, 1, 2, true>(ab, nz, st);
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
         // (tried for rank pad 64 too: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass)
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
