@@ -112,7 +112,8 @@ int moka_tok_pad(int T);
  * rank pad 64).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
- * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy. */
+ * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy (per 1024 columns for
+ * 32 < r <= 64). */
 int moka_ksplit_bwd(int T, int C, int r);
 
 /* ---- forward ----------------------------------------------------------------------- */

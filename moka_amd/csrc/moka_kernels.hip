@@ -1715,7 +1715,7 @@ struct GyArgs {
     const unsigned short* pack;     // hp_kmj [2][RP][Tp] (may be null when dB is)
     const unsigned char* BwT;       // [RP][C] bf16, zero padded rows
     const unsigned char* tok_mod;
-    float* g_part;                  // [ncb][T][RP]  one slice per 512-column block (ncb = grid x)
+    float* g_part;                  // [ncb][T][RP]  one slice per column block (512 columns; 1024 at rank pad 64), ncb = grid x
     float* dB;                      // [C][r] fp32 accumulate, or null
     float s_mod[4];
     int T, Tp, C, r, M;
@@ -1736,8 +1736,9 @@ struct GyBatch { GyArgs z[MOKA_MAX_GROUP]; };
 //     in the wgrad kernel, reduced over the block at the end.
 // Replaces moka_reduce_kernel + moka_wgrad_kernel<OUT_CK> on gy, which each read gy once (measured: 36 us
 // for a 67 MB gy where one pass costs ~20 us).
-template <int RP, bool WITH_DB, int NG, bool DET>
+template <int RP, bool WITH_DB, int NG, bool DET, int KK = 2>
 __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
+    static_assert(KK == 2 || (KK == 4 && !WITH_DB), "KK = K steps (32 columns) per wave: 128 columns per wave only for the g-only form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16;
     constexpr int NW = 8, PH = (RP == 64) ? 1 : 2, CT = 4;   // NG = 32-token groups per block; PH: LDS budget (RP = 64: 64 KB of slots per phase)
@@ -1749,7 +1750,8 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     const int ngroups = a.Tp >> 5;
     const int grp0 = blockIdx.y * NG;
     if (grp0 >= ngroups) return;
-    const int cb0 = blockIdx.x * 512;
+    constexpr int WCOL = 32 * KK, BCOL = 8 * WCOL;       // columns per wave / per block (= per split-K slice)
+    const int cb0 = blockIdx.x * BCOL;
     float* slice = a.g_part + (size_t)blockIdx.x * a.T * RP;
     if (cb0 >= a.C) {                                    // batched projections of different width: empty slice
         for (int e = tid; e < NG * 32 * RP; e += 512) {
@@ -1758,16 +1760,16 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
         }
         return;
     }
-    const int c0 = cb0 + 64 * wave;
+    const int c0 = cb0 + WCOL * wave;
     const bool wactive = c0 < a.C;                       // wave uniform (C % 32 == 0: a wave may own 32 valid columns)
     unsigned char* my = smem + wave * REGION;            // (WITH_DB only: the g-only form carries no tile regions, more blocks per CU)
     float* rbuf = (float*)(smem + (WITH_DB ? NW * REGION : 0));   // [NW][PH][32][RP]
     float* myr = rbuf + (size_t)wave * PH * RSLOT;
 
     // weight fragments of my 64 columns (two K steps), resident: lane (n = rank i, k chunk g)
-    bf16x8 bwt[2][NT];
+    bf16x8 bwt[KK][NT];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c = c0 + 32 * kk + 8 * g;
@@ -1780,13 +1782,13 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     // F[st][kk]: rows 16st + i of the group, columns c0 + 32kk + 8g .. +7   (unconditional, clamped)
     // (the prefetch behind the block's last group is clamped to that group: its lines were requested a moment ago, so the
     //  unconditional load costs an L2 hit -- not a second HBM read of the NEXT block's first group, which was 1/NG of the traffic)
-    auto issue = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp_) {
+    auto issue = [&](bf16x8 (&F)[2][KK], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int grp_) {
         const int grp = min(min(grp_, grp0 + NG - 1), grp_last);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const size_t rowoff = (size_t)min((grp << 5) + 16 * st + i, a.T - 1) * a.C;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
                 const int c = min(c0 + 32 * kk + 8 * g, a.C - 8);
                 F[st][kk] = *(const bf16x8*)(a.gy + (rowoff + c) * 2);
             }
@@ -1806,7 +1808,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) accW[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](bf16x8 (&F)[2][2], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int gi) {
+    auto compute = [&](bf16x8 (&F)[2][KK], bf16x8 (&bh)[NT], bf16x8 (&bl)[NT], int gi) {
         const int grp = grp0 + gi;
         const bool live = wactive && grp < ngroups;      // wave uniform
         // ---- g: [32 tokens x RP] partial over my columns -> my LDS slot of this phase
@@ -1819,7 +1821,8 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
                 if (live) {
                     const bf16x8 z8r = {0, 0, 0, 0, 0, 0, 0, 0};
                     accR = MFMA16(F[st][0], bwt[0][nt], accR);
-                    accR = MFMA16((c0 + 32 < a.C) ? F[st][1] : z8r, bwt[1][nt], accR);   // branch-free, see moka_xa_kernel
+#pragma unroll
+                    for (int kk = 1; kk < KK; ++kk) accR = MFMA16((c0 + 32 * kk < a.C) ? F[st][kk] : z8r, bwt[kk][nt], accR);   // branch-free, see moka_xa_kernel
                 }
                 MFMA_SETTLE(accR);
 #pragma unroll
@@ -1863,7 +1866,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    bf16x8 FA[2][2], FB[2][2], bhA[NT], blA[NT], bhB[NT], blB[NT];
+    bf16x8 FA[2][KK], FB[2][KK], bhA[NT], blA[NT], bhB[NT], blB[NT];
     issue(FA, bhA, blA, grp0);
 #pragma unroll
     for (int gi = 0; gi < NG; gi += 2) {
@@ -2659,7 +2662,7 @@ static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
     return check_launch("moka_wgrad_kernel");
 }
 
-template <int RP, bool WITH_DB, int NG>
+template <int RP, bool WITH_DB, int NG, int KK = 2>
 static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
     constexpr int PH = (RP == 64) ? 1 : 2;
     const int ntb = ((gb.z[0].Tp >> 5) + NG - 1) / NG;
@@ -2680,17 +2683,28 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
         }
     }
     if (det) {
-        ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, WITH_DB>, lds);
-        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, WITH_DB>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+        ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, WITH_DB, KK>, lds);
+        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, WITH_DB, KK>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
         det_finish(sr, st);
     } else {
-        ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, false>, lds);
-        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, false>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+        ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, false, KK>, lds);
+        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, false, KK>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
     }
 }
 
 template <int RP, bool WITH_DB>
 static int launch_gy_rp(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
+    if constexpr (RP == 64 && !WITH_DB) {
+        // rank pad 64: 128 columns per wave, one split-K slice per 1024 columns (bwd_kw): the rank-space backward reads half as many
+        // slices (7.2 -> 6.3 ms per step); this pass itself is unchanged (150-166 VGPRs leave one block per CU where 95 left two,
+        // which cancels the halved eight-wave sums; capped at 128 registers it spills and loses 9 ms)
+        const int ncb4 = (Cmax + 1023) / 1024;
+        const int ngroups4 = gb.z[0].Tp >> 5;
+        const long b4 = (long)ncb4 * nz * ((ngroups4 + 3) / 4);
+        if (g_tune_gy_ng == 2 || (g_tune_gy_ng == 0 && b4 < 2L * num_cu())) launch_gy_t<64, false, 2, 4>(gb, nz, ncb4, st);
+        else launch_gy_t<64, false, 4, 4>(gb, nz, ncb4, st);
+        return check_launch("moka_gy_kernel");
+    }
     const int ncb = (Cmax + 511) / 512;
     const int ngroups = gb.z[0].Tp >> 5;
     // groups per block: without dB short runs (more blocks); with dB the longest run that still gives every CU a block
@@ -2769,7 +2783,8 @@ static int fwd_kw(int r) { return (use_xw(rank_pad(r)) && rank_pad(r) == 64) ? 2
 static int fwd_ks(int /*T*/, int C, int r) { const int kw = fwd_kw(r); return (C + kw - 1) / kw; }
 
 // number of g_part slices moka_up_bwd writes for output width C
-static int bwd_ks(int /*T*/, int C, int /*r*/) { return (C + 511) / 512; }
+static int bwd_kw(int r) { return rank_pad(r) == 64 ? 1024 : 512; }                              // columns per g_part slice
+static int bwd_ks(int /*T*/, int C, int r) { const int kw = bwd_kw(r); return (C + kw - 1) / kw; }
 
 // ---- fp32 storage launchers (one projection at a time)
 static void f32_common(F32Args& a, const uint8_t* tok_mod, int T, int C, int r, int M) {
@@ -3053,18 +3068,18 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
     int rc = MOKA_OK;
     if (dtype == MOKA_F32) {
         // slices of the widest projection of the group (moka_ksplit_bwd): narrower members leave their upper slices zero
-        const int ks = (Cmax + 511) / 512;
+        const int kw = bwd_kw(r), ks = (Cmax + kw - 1) / kw;
         for (int g = 0; g < G; ++g) {
             if (g_part && g_part[g]) {
                 if (!BwT || !BwT[g]) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without Bw (fp32: pass Bw as BwT)");
-                const int ksg = (d_out[g] + 511) / 512;
+                const int ksg = (d_out[g] + kw - 1) / kw;
                 if (ksg < ks && hipMemsetAsync(g_part[g] + (size_t)ksg * T * RP, 0, (size_t)(ks - ksg) * T * RP * 4, (hipStream_t)stream) != hipSuccess)
                     return fail(MOKA_ELAUNCH, "moka_up_bwd: memset");
                 F32Args a;
                 f32_common(a, tok_mod, T, d_out[g], r, M);
                 a.in = (const float*)gy[g]; a.out = g_part[g]; a.W[0] = (const float*)BwT[g];
                 for (int m = 0; m < M; ++m) a.s_mod[m] = s_out[m];
-                hipLaunchKernelGGL(moka_f32_reduce_kernel<true>, dim3(ksg, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, 512);
+                hipLaunchKernelGGL(moka_f32_reduce_kernel<true>, dim3(ksg, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, kw);
                 rc = check_launch("moka_f32_reduce_kernel");
                 if (rc) return rc;
             }
@@ -3084,7 +3099,7 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         return MOKA_OK;
     }
     if (g_part && g_part[0]) {
-        // ONE pass over gy produces the g slices (one per 512-column block) and, if requested, dB
+        // ONE pass over gy produces the g slices (one per bwd_kw() columns) and, if requested, dB
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
         // the dB half rides along only for r <= 16: with 32 / 64 ranks its atomics (64 x RP per wave and block) and the single
         // resident block per CU cost more than the second read of gy (measured: 47 vs 45 us at RP = 32, 97 vs 79 us at RP = 64)
