@@ -124,24 +124,23 @@ class Unit:
                      "moka_down_bwd": 3 * E * T * self.d_in * G, "moka_cross_fwd": 3 * 4 * T * r * G, "moka_cross_bwd": 3 * 4 * T * r * G}
 
 
-def build_workload(args, dev, lib, bucket_factory):
+def build_workload(args, dev, lib, bucket_factory, chains=1):
+    """`chains` > 1: the micro-batch as that many part-batches (B / chains sequences each) with their own activations, routing,
+    scratch and saved tensors, sharing the parameters and the gradient accumulators -- independent chains of launches (nothing in
+    the model mixes tokens of different samples), see --chains."""
     from moka_amd import _lib
     from moka_amd.routing import MokaRouting
     vt = args.variant == "vt"
     B, S, r, M = args.batch, args.seq, args.rank, (2 if vt else 3)
     dims, L = MODELS[args.model], args.layers
     d, ff = dims["d"], dims["ff"]
-    T = B * S
+    assert B % chains == 0, "--chains must divide --batch"
+    Bc = B // chains
+    T, Tc = B * S, Bc * S
     tok, q = synthetic_layout(S)
     if vt:
         # BASELINE.json configs[1]: visual-text -- the audio span becomes text, bool [B,S] masks (VisualText/train/train.py:206-231)
         tok = torch.where(tok == 2, torch.zeros_like(tok), tok)
-        masks = [(tok == 0).reshape(1, S).repeat(B, 1).to(dev), (tok == 1).reshape(1, S).repeat(B, 1).to(dev), q.reshape(1, S).repeat(B, 1).to(dev)]
-        rt = MokaRouting.from_vt_masks(*masks)
-    else:
-        masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)]
-        masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev))
-        rt = MokaRouting.from_avt_masks(masks)
     RP = _lib.rank_pad(r)
     bf, f32 = torch.bfloat16, torch.float32
     width = lambda k: dims[k]          # noqa: E731
@@ -153,39 +152,11 @@ def build_workload(args, dev, lib, bucket_factory):
     gbuf = bucket.flat
     master = torch.empty(n_params, dtype=f32, device=dev)
     work = torch.empty(n_params, dtype=bf, device=dev)
-
-    # activation buffers: `args.distinct` layer sets cycled (each set >> 256 MiB Infinity Cache).  Projections fed
-    # by the same tensor (q/k/v <- hid, gate/up <- hid2) share ONE input and ONE input-gradient buffer, as in the
-    # decoder (autograd sums their dx).
-    nset = max(1, min(L, args.distinct))
-    sets = []
-    for _ in range(nset):
-        acts = {k: torch.randn(T, width(wk), device=dev, dtype=bf) for k, wk in (("hid", "d"), ("attn", "d"), ("hid2", "d"), ("act", "ff"))}
-        dacts = {k: torch.randn(T, width(wk), device=dev, dtype=bf) for k, wk in (("hid", "d"), ("attn", "d"), ("hid2", "d"), ("act", "ff"))}
-        ys = [torch.randn(T, width(do), device=dev, dtype=bf) for _, _, do, _ in PROJS]
-        sets.append((acts, dacts, ys))
-    Tp = _lib.tok_pad(T)
-    max_ks = max(_lib.ksplit(T, ff, r), _lib.ksplit(T, d, r), _lib.ksplit_bwd(T, ff, r))
-    # scratch shared by all units (consumed before the next unit overwrites it), one slot per group member
-    scratch = [dict(part=torch.empty(max_ks, T, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
-                    dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
-               for _ in range(3)]
-
-    # units = maximal runs of projections with the same input (--no-group: every projection alone)
-    unit_defs = []
-    for pi, (name, di, do, src) in enumerate(PROJS):
-        if unit_defs and not args.no_group and unit_defs[-1][0] == src and len(unit_defs[-1][1]) < 3:
-            unit_defs[-1][1].append(pi)
-        else:
-            unit_defs.append((src, [pi]))
-
-    s = 16.0 / r
-    units, layer_end, keep = [], [], []
+    layer_end, params = [], []
     off = 0
     bound = lambda n: 1.0 / math.sqrt(n)  # noqa: E731  kaiming_uniform(a=sqrt(5))
     for l in range(L):
-        acts, dacts, ys = sets[l % nset]
-        members = []
+        row = []
         for pi, (name, di, do, src) in enumerate(PROJS):
             d_in, d_out = width(di), width(do)
             A, dA = [], []
@@ -197,24 +168,65 @@ def build_workload(args, dev, lib, bucket_factory):
                 off += n
             n = d_out * r
             master[off:off + n].normal_(0, 0.02)
-            Bw = work[off:off + n].view(d_out, r)
-            dB = gbuf[off:off + n].view(d_out, r)
+            row.append(dict(name=name, d_in=d_in, d_out=d_out, A=A, dA=dA, Bw=work[off:off + n].view(d_out, r), dB=gbuf[off:off + n].view(d_out, r)))
             off += n
-            # saved forward -> backward, per projection: h (fp32), the rank-major hp pack, the weight shadows
-            members.append(dict(name=name, d_in=d_in, d_out=d_out, A=A, dA=dA, Bw=Bw, dB=dB, y=ys[pi],
-                                h=torch.empty(T, RP, dtype=f32, device=dev), hp_kmj=torch.empty(2, RP, Tp, dtype=bf, device=dev),
-                                BwT=torch.empty(RP, d_out, dtype=bf, device=dev), AT=torch.empty(M, d_in, RP, dtype=bf, device=dev)))
-        for src, pis in unit_defs:
-            mem = [members[pi] for pi in pis]
-            units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, T, r, M, rt, acts[src], dacts[src], scratch,
-                              1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
-                              [1000003 * l + pi for pi in pis]))
+        params.append(row)
         layer_end.append(off)
     assert off == n_params
     work.copy_(master)
     assert layer_end == bucket.layer_end
-    return dict(units=units, units_per_layer=len(unit_defs), rt=rt, master=master, work=work, gbuf=gbuf, bucket=bucket, T=T,
-                n_params=n_params, layer_end=layer_end, keep=(sets, masks, scratch))
+
+    # units = maximal runs of projections with the same input (--no-group: every projection alone)
+    unit_defs = []
+    for pi, (name, di, do, src) in enumerate(PROJS):
+        if unit_defs and not args.no_group and unit_defs[-1][0] == src and len(unit_defs[-1][1]) < 3:
+            unit_defs[-1][1].append(pi)
+        else:
+            unit_defs.append((src, [pi]))
+
+    s = 16.0 / r
+    nset = max(1, min(L, args.distinct))
+    Tp = _lib.tok_pad(Tc)
+    max_ks = max(_lib.ksplit(Tc, ff, r), _lib.ksplit(Tc, d, r), _lib.ksplit_bwd(Tc, ff, r))
+    chain_list, keep = [], []
+    for ci in range(chains):
+        if vt:
+            masks = [(tok == 0).reshape(1, S).repeat(Bc, 1).to(dev), (tok == 1).reshape(1, S).repeat(Bc, 1).to(dev), q.reshape(1, S).repeat(Bc, 1).to(dev)]
+            rt = MokaRouting.from_vt_masks(*masks)
+        else:
+            masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(Bc, 1, 1).to(dev) for m in range(3)]
+            masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(Bc, 1, 1).to(dev))
+            rt = MokaRouting.from_avt_masks(masks)
+        # activation buffers: `args.distinct` layer sets cycled (all chains together: each set >> 256 MiB Infinity Cache).  Projections
+        # fed by the same tensor (q/k/v <- hid, gate/up <- hid2) share ONE input and ONE input-gradient buffer, as in the
+        # decoder (autograd sums their dx).
+        sets = []
+        for _ in range(nset):
+            acts = {k: torch.randn(Tc, width(wk), device=dev, dtype=bf) for k, wk in (("hid", "d"), ("attn", "d"), ("hid2", "d"), ("act", "ff"))}
+            dacts = {k: torch.randn(Tc, width(wk), device=dev, dtype=bf) for k, wk in (("hid", "d"), ("attn", "d"), ("hid2", "d"), ("act", "ff"))}
+            ys = [torch.randn(Tc, width(do), device=dev, dtype=bf) for _, _, do, _ in PROJS]
+            sets.append((acts, dacts, ys))
+        # scratch shared by all units of the chain (consumed before the next unit overwrites it), one slot per group member
+        scratch = [dict(part=torch.empty(max_ks, Tc, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
+                        dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
+                   for _ in range(3)]
+        units = []
+        for l in range(L):
+            acts, dacts, ys = sets[l % nset]
+            members = []
+            for pi, pr in enumerate(params[l]):
+                # saved forward -> backward, per projection: h (fp32), the rank-major hp pack, the weight shadows
+                members.append(dict(pr, y=ys[pi], h=torch.empty(Tc, RP, dtype=f32, device=dev), hp_kmj=torch.empty(2, RP, Tp, dtype=bf, device=dev),
+                                    BwT=torch.empty(RP, pr["d_out"], dtype=bf, device=dev), AT=torch.empty(M, pr["d_in"], RP, dtype=bf, device=dev)))
+            for src, pis in unit_defs:
+                mem = [members[pi] for pi in pis]
+                units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch,
+                                  1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
+                                  [1000003 * l + pi + 7919 * 104729 * ci for pi in pis]))      # every chain its own dropout masks
+        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc))
+        keep.append((sets, masks, scratch))
+    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], chains=chain_list, master=master, work=work,
+                gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
 ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
@@ -476,6 +488,12 @@ def main():
                          "of a layer, so the sample covers them evenly)")
     ap.add_argument("--comm-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (153 instead of 306 MB per step at 7B r=16; accumulation stays fp32)")
     ap.add_argument("--no-traffic", action="store_true", help="leave roofline.traffic null instead of reading the PMC summary under profiles/")
+    ap.add_argument("--chains", type=int, default=1,
+                    help="process the micro-batch as this many part-batches (batch / chains sequences each) whose launch chains run on "
+                         "separate HIP streams of the one hipGraph: nothing in the model mixes tokens of different samples, so the chains "
+                         "are independent, and the fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide "
+                         "behind the streaming kernels of the other.  Single GPU with --graph all only; per-kernel durations (`roofline`, "
+                         "`kernels`) are then taken with the chains back to back on one stream")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -507,7 +525,10 @@ def main():
     lib = _lib.load()
     _lib.check(lib.moka_device_check(), "moka_device_check")
     from moka_amd.parallel import FlatGradBucket
-    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None))
+    if args.chains > 1 and (world > 1 or args.graph != "all"):
+        raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")
+    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None),
+                        chains=args.chains)
     T = wl["T"]
     torch.cuda.synchronize()
 
@@ -535,16 +556,25 @@ def main():
             side = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(side):
                 spw = c_void_p(side.cuda_stream)
-                run_forward(lib, wl, spw)
-                run_backward(lib, wl, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
+                for ch in wl["chains"]:
+                    run_forward(lib, ch, spw)
+                    run_backward(lib, ch, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
             torch.cuda.synchronize()
             if args.graph == "all":
                 assert world == 1, "--graph all: single GPU only"
                 fwd_bwd_graph = torch.cuda.CUDAGraph()
+                branch = [torch.cuda.Stream(device=dev) for _ in range(args.chains - 1)]
                 with torch.cuda.graph(fwd_bwd_graph, stream=side):
-                    spg = c_void_p(torch.cuda.current_stream().cuda_stream)
-                    run_forward(lib, wl, spg)
-                    run_backward(lib, wl, spg, L)
+                    cur = torch.cuda.current_stream()
+                    for st in branch:
+                        st.wait_stream(cur)          # fork: the branch streams join the capture
+                    for ch, st in zip(wl["chains"], [cur] + branch):
+                        with torch.cuda.stream(st):
+                            spg = c_void_p(st.cuda_stream)
+                            run_forward(lib, ch, spg)
+                            run_backward(lib, ch, spg, L)
+                    for st in branch:
+                        cur.wait_stream(st)          # join
             else:
                 lpb = bucket.layers_per_bucket
                 bwd_graphs = []
@@ -624,14 +654,16 @@ def main():
             # graph replay: nothing can be bracketed inside the timed region -> the dominant entry point is bracketed (every n-th
             # launch, as in the live mode) in extra live passes right behind it, same buffers, same kernel sequence
             for _ in range(min(args.steps, 3)):
-                run_forward(lib, wl, sp_, records)
-                run_backward(lib, wl, sp_, L, None, None)
+                for ch in wl["chains"]:
+                    run_forward(lib, ch, sp_, records)
+                    run_backward(lib, ch, sp_, L, None, None)
             torch.cuda.synchronize()
         tot, cnt, byt, per_shape = collect(records.items)         # the dominant entry point (LIVE)
         # every entry point, in one extra untimed pass (full bracketing would perturb the timed region)
         extra = Recorder()
-        run_forward(lib, wl, sp_, extra)
-        run_backward(lib, wl, sp_, L, None, extra)
+        for ch in wl["chains"]:
+            run_forward(lib, ch, sp_, extra)
+            run_backward(lib, ch, sp_, L, None, extra)
         torch.cuda.synchronize()
         tot_x, cnt_x, byt_x, per_shape_x = collect(extra.items)
         live_items = records.items
@@ -650,7 +682,9 @@ def main():
         if not args.no_traffic and (args.model, args.rank, args.variant) == ("7b", 16, "avt") and not args.no_group:
             # (the PMC passes profile the headline workload; per launch = per layer / the layer's up-projection launches)
             traffic, traffic_src = pmc_traffic_per_launch(T, wl["units_per_layer"])
-            traffic = round(traffic)
+            traffic = round(traffic / args.chains)       # (the PMC passes profile whole-batch launches; traffic is linear in the tokens)
+            if args.chains > 1:
+                traffic_src += " / %d (launches of %d tokens)" % (args.chains, T // args.chains)
         out = {
             "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline" if (args.model, args.rank, args.seq) == ("7b", 16, 2048)
                       else "tokens/sec/GPU Llama-2-%s MokA r=%d seq%d bf16; adapter HBM %%roofline" % (args.model.upper(), args.rank, args.seq),
@@ -664,7 +698,8 @@ def main():
                                       ("%d image + %d question + text" % (args.seq // 8, args.seq // 32)) if args.variant == "vt"
                                       else ("%d image + %d audio + %d question + text" % (args.seq // 8, args.seq // 16, args.seq // 32)),
                                       args.dropout, args.batch,
-                                      "one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points"),
+                                      ("one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points")
+                                      + ("" if args.chains == 1 else ", as %d independent part-batch chains on %d streams" % (args.chains, args.chains))),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
             "distributed": {"world_size": world, "dist_world_size": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                             "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
@@ -672,6 +707,7 @@ def main():
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
                             "adapter_params": wl["n_params"]},
             "graph": args.graph,
+            "chains": args.chains,
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
