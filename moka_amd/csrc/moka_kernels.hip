@@ -907,7 +907,10 @@ struct ExpandArgs {
 };
 // W_CK (y += hp.Bw^T): blockIdx.z selects one of the batched problems.
 // !W_CK (dx += sum_g dh_g.A_g): the G entries share tok_mod / out / T / C and differ in pack, W, drop.
-struct ExpandBatch { ExpandArgs z[MOKA_MAX_GROUP]; };
+struct ExpandBatch {
+    ExpandArgs z[MOKA_MAX_GROUP];
+    int xend[MOKA_MAX_GROUP];      // G == 1: blockIdx.x < xend[z] belongs to problem z (cumulative column blocks: no block without work)
+};
 
 // D^T orientation: MFMA rows = output columns, MFMA columns = tokens, so every lane ends up with 8
 // consecutive bf16 of one token row (16 B) and a wave touches 16 rows x 64 B per instruction (the
@@ -924,10 +927,19 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     constexpr int KH = (RP + 31) / 32;                 // 32-wide rank blocks per hi (or lo) plane
     constexpr int WC = NQ * 32;                        // columns per wave
     constexpr int CW = 4 * WC;                         // columns per block
-    const ExpandArgs& a = ab.z[G == 1 ? blockIdx.z : 0];
+    // G == 1: batched problems share the x dimension of the grid (a problem narrower than the widest one would otherwise leave most
+    // of its grid row as blocks that exit at once, and launching those is not free: 2900 of them cost the 70B q+k+v launch 60 us)
+    // (problems of one width keep a grid row each, blockIdx.z: measured 1 % faster on the q/k/v launch of the 7B widths)
+    int zi = blockIdx.z, xb = blockIdx.x;
+    if (G == 1 && ab.xend[0] > 0) {
+        zi = 0;
+        while (zi + 1 < MOKA_MAX_GROUP && xb >= ab.xend[zi]) ++zi;
+        if (zi) xb -= ab.xend[zi - 1];
+    }
+    const ExpandArgs& a = ab.z[G == 1 ? zi : 0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int c_wave = blockIdx.x * CW + wave * WC;
+    const int c_wave = xb * CW + wave * WC;
     if (c_wave >= a.C) return;                         // C % 32 == 0, WC may overshoot in the last block
     const int wr = W_CK ? a.r : RP;                    // row length of the weight source (AT is padded to RP)
 
@@ -954,7 +966,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int kh = 0; kh < KH; ++kh) wf0[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[0], q, p, kh);
+                for (int kh = 0; kh < KH; ++kh) wf0[gi][q][p][kh] = load_frag(ab.z[G == 1 ? zi : gi].W[0], q, p, kh);
 
     int mcur = 0;                                                 // RUNS: modality of the resident weight set
     const int ntiles = (a.T + 15) >> 4;
@@ -990,7 +1002,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         // B operand: my token's pack row.  RP == 16: K = 32 is [hi(16) | lo(16)] = elements 8g..8g+7 of the row.
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const unsigned char* prp = (const unsigned char*)ab.z[G == 1 ? blockIdx.z : gi].pack + (size_t)t * prow;
+            const unsigned char* prp = (const unsigned char*)ab.z[G == 1 ? zi : gi].pack + (size_t)t * prow;
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) {
                 if (RP == 16) {
@@ -1055,7 +1067,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
                             for (int kh = 0; kh < KH; ++kh) {
                                 const int c = min(c_wave + 32 * q + 8 * (i >> 2) + 4 * p + (i & 3), a.C - 1);   // columns >= C are never stored
-                                const unsigned short* src = (const unsigned short*)ab.z[G == 1 ? blockIdx.z : gi].W[m] + (size_t)c * RP + ((RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g);
+                                const unsigned short* src = (const unsigned short*)ab.z[G == 1 ? zi : gi].W[m] + (size_t)c * RP + ((RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g);
                                 asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(wf0[gi][q][p][kh]) : "v"(src) : "memory");
                             }
 #pragma unroll
@@ -1111,7 +1123,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
-                        for (int kh = 0; kh < KH; ++kh) wfx[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[mA], q, p, kh);
+                        for (int kh = 0; kh < KH; ++kh) wfx[gi][q][p][kh] = load_frag(ab.z[G == 1 ? zi : gi].W[mA], q, p, kh);
             issue(N, next_tile);
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) {
@@ -1128,7 +1140,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 #pragma unroll
                         for (int p = 0; p < 2; ++p)
 #pragma unroll
-                            for (int kh = 0; kh < KH; ++kh) wfx[gi][q][p][kh] = load_frag(ab.z[G == 1 ? blockIdx.z : gi].W[mB], q, p, kh);
+                            for (int kh = 0; kh < KH; ++kh) wfx[gi][q][p][kh] = load_frag(ab.z[G == 1 ? zi : gi].W[mB], q, p, kh);
                     chain(gi, wfx[gi], mrow == mB);
                 }
             }
@@ -1136,7 +1148,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const ExpandArgs& ag = ab.z[G == 1 ? blockIdx.z : gi];
+            const ExpandArgs& ag = ab.z[G == 1 ? zi : gi];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!FAST && c_wave + 32 * q >= a.C) continue;
@@ -1723,7 +1735,11 @@ struct GyArgs {
     int det_planes;
     size_t det_stride;
 };
-struct GyBatch { GyArgs z[MOKA_MAX_GROUP]; };
+struct GyBatch {
+    GyArgs z[MOKA_MAX_GROUP];
+    int xend[MOKA_MAX_GROUP];      // blockIdx.x < xend[z] belongs to problem z: its column blocks, plus ONE block per token run that zeroes
+    int ncb_max;                   // the slices a narrower member leaves unwritten (the group's consumers read ncb_max slices of everyone)
+};
 
 // Block = 8 waves on a [NG*32 tokens x 512 columns] tile of gy; wave w owns columns 64w..64w+63 for the
 // block's NG 32-token groups (NG: long runs keep the number of dB atomics down -- they cost ~3 us per
@@ -1744,19 +1760,27 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     constexpr int NW = 8, PH = (RP == 64) ? 1 : 2, CT = 4;   // NG = 32-token groups per block; PH: LDS budget (RP = 64: 64 KB of slots per phase)
     constexpr int PITCH = 64 * 2 + 32, REGION = 32 * PITCH;
     constexpr int RSLOT = 32 * RP;                       // floats per (wave, group) partial
-    const GyArgs& a = ab.z[blockIdx.z];
+    // the x dimension of the grid enumerates the column blocks of all batched problems (a grid row per problem left a narrow member
+    // -- grouped-query k / v beside q -- with 14 of 16 blocks that only zero a slice, and launching a block is not free)
+    int zi = 0, xb = blockIdx.x;
+    while (zi + 1 < MOKA_MAX_GROUP && xb >= ab.xend[zi]) ++zi;
+    if (zi) xb -= ab.xend[zi - 1];
+    const GyArgs& a = ab.z[zi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ngroups = a.Tp >> 5;
     const int grp0 = blockIdx.y * NG;
     if (grp0 >= ngroups) return;
     constexpr int WCOL = 32 * KK, BCOL = 8 * WCOL;       // columns per wave / per block (= per split-K slice)
-    const int cb0 = blockIdx.x * BCOL;
-    float* slice = a.g_part + (size_t)blockIdx.x * a.T * RP;
-    if (cb0 >= a.C) {                                    // batched projections of different width: empty slice
-        for (int e = tid; e < NG * 32 * RP; e += 512) {
-            const int t = grp0 * 32 + e / RP;
-            if (t < a.T) slice[(size_t)t * RP + (e % RP)] = 0.f;
+    const int cb0 = xb * BCOL;
+    float* slice = a.g_part + (size_t)xb * a.T * RP;
+    if (cb0 >= a.C) {                                    // the one extra block of a narrower member: zero its unwritten slices for my token run
+        for (int sl = xb; sl < ab.ncb_max; ++sl) {
+            float* zs = a.g_part + (size_t)sl * a.T * RP;
+            for (int e = tid; e < NG * 32 * RP / 4; e += 512) {
+                const int t = grp0 * 32 + (4 * e) / RP;
+                if (t < a.T) *(f32x4*)(zs + (size_t)t * RP + (4 * e) % RP) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
         return;
     }
@@ -1898,7 +1922,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
                 const int cl = e / RP, k = e % RP;
                 const int c = c0 + cb * 16 + cl;
                 if (c < a.C && k < a.r) {
-                    if (DET) a.det[((size_t)blockIdx.y * a.det_planes + blockIdx.z) * a.det_stride + (size_t)c * a.r + k] = mine[cl * RP + k];
+                    if (DET) a.det[((size_t)blockIdx.y * a.det_planes + zi) * a.det_stride + (size_t)c * a.r + k] = mine[cl * RP + k];
                     else atomicAdd(a.dB + (size_t)c * a.r + k, mine[cl * RP + k]);
                 }
             }
@@ -2530,10 +2554,24 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     const int nc = (Cmax + CW - 1) / CW;
     const int ntiles = (ab.z[0].T + 15) / 16;
     const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : ((Cmax > 8192 || (W_CK && nz > 1)) ? 8 : 2);
-    int gy = (bpc * num_cu() + nc * nz - 1) / (nc * nz);   // blocks per CU, each walking several token tiles
+    // the x dimension of the grid enumerates the column blocks of all batched problems (xend): grouped-query k / v beside q are
+    // 16 + 2 + 2 column blocks, not 3 x 16
+    ExpandBatch sb = ab;
+    int active = 0;
+    bool uniform = true;
+    for (int z = 0; z < MOKA_MAX_GROUP; ++z) {
+        if (z < (G == 1 ? nz : 1)) { active += (ab.z[z].C + CW - 1) / CW; uniform = uniform && ab.z[z].C == ab.z[0].C; }
+        sb.xend[z] = active;
+    }
+    int gy = (bpc * num_cu() + active - 1) / active;        // blocks per CU, each walking several token tiles
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G, DEPTH, RUNS>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, ab);
+    if (G > 1 || uniform) {
+        for (int z = 0; z < MOKA_MAX_GROUP; ++z) sb.xend[z] = 0;      // a grid row per problem
+        hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G, DEPTH, RUNS>), dim3(nc, gy, G == 1 ? nz : 1), dim3(256), 0, st, sb);
+    } else {
+        hipLaunchKernelGGL((moka_expand_kernel<RP, NQ, W_CK, G, DEPTH, RUNS>), dim3(active, gy, 1), dim3(256), 0, st, sb);
+    }
 }
 
 // W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
@@ -2682,18 +2720,30 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
             for (int z = 0; z < nz; ++z) { gm.z[z].det = g_det_ws; gm.z[z].det_planes = nz; gm.z[z].det_stride = stride; sr.acc[z] = gm.z[z].dB; sr.n[z] = (size_t)gm.z[z].C * gm.z[z].r; }
         }
     }
+    GyBatch& gx = const_cast<GyBatch&>(gb);              // (the caller's own copy)
+    constexpr int BCOL = 256 * KK;
+    int xtot = 0;
+    for (int z = 0; z < MOKA_MAX_GROUP; ++z) {
+        if (z < nz) {
+            const int nact = (gb.z[z].C + BCOL - 1) / BCOL;
+            xtot += nact + (nact < ncb ? 1 : 0);        // + the block that zeroes the slices a narrower member does not write
+        }
+        gx.xend[z] = xtot;
+    }
+    gx.ncb_max = ncb;
     if (det) {
         ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, WITH_DB, KK>, lds);
-        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, WITH_DB, KK>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, WITH_DB, KK>), dim3(xtot, ntb, 1), dim3(512), lds, st, gb);
         det_finish(sr, st);
     } else {
         ensure_lds((const void*)moka_gy_kernel<RP, WITH_DB, NG, false, KK>, lds);
-        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, false, KK>), dim3(ncb, ntb, nz), dim3(512), lds, st, gb);
+        hipLaunchKernelGGL((moka_gy_kernel<RP, WITH_DB, NG, false, KK>), dim3(xtot, ntb, 1), dim3(512), lds, st, gb);
     }
 }
 
 template <int RP, bool WITH_DB>
-static int launch_gy_rp(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
+static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) {
+    GyBatch gb = gb_in;                                  // (launch_gy_t fills in the grid map)
     if constexpr (RP == 64 && !WITH_DB) {
         // rank pad 64: 128 columns per wave, one split-K slice per 1024 columns (bwd_kw): the rank-space backward reads half as many
         // slices (7.2 -> 6.3 ms per step); this pass itself is unchanged (150-166 VGPRs leave one block per CU where 95 left two,
@@ -2711,7 +2761,9 @@ static int launch_gy_rp(const GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     // (measured at T = 8192: 4096 wide -> 8, 11008 wide -> 8, 3 x 4096 -> 8/16, 2 x 11008 -> 16; g only -> 4)
     int ng = 4;
     if (WITH_DB) {
-        auto blocks = [&](int n) { return (long)ncb * nz * ((ngroups + n - 1) / n); };
+        long active = 0;                                    // column blocks that do work (narrower batch members: see launch_expand_t)
+        for (int z = 0; z < nz; ++z) active += (gb.z[z].C + 511) / 512;
+        auto blocks = [&](int n) { return active * ((ngroups + n - 1) / n); };
         ng = blocks(16) >= 2L * num_cu() ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
     }
     if (g_tune_gy_ng == 4 || g_tune_gy_ng == 8 || g_tune_gy_ng == 16) ng = g_tune_gy_ng;
