@@ -66,7 +66,7 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      400            /* 0.4.0 */
+#define MOKA_VERSION      410            /* 0.4.1: *_kmj pack layout, moka_ksplit_bwd at rank pad 64 */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
