@@ -1,3 +1,5 @@
+"""Host-side cost of one adapted projection through the autograd nodes (tiny tensors, so the GPU time is negligible): Python / ctypes
+overhead per forward + backward of moka_linear and moka_linear_group.  Run on the GPU box from the repo root."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import bench
