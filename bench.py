@@ -480,8 +480,8 @@ def main():
     ap.add_argument("--graph", choices=("auto", "off", "bwd", "all"), default="auto",
                     help="hipGraph replay (the library only enqueues on the stream it is given, so its launches capture unchanged): "
                          "all = the whole micro-batch as one graph (single GPU; nothing can be bracketed inside a graph, so `roofline` comes "
-                         "from one extra, live, fully bracketed pass after the timed region); bwd = one graph per gradient bucket of the "
-                         "backward (forward live, DP hooks between the graphs); off = every launch live; auto = all on 1 GPU, bwd on N > 1")
+                         "from extra live passes after the timed region); bwd = the forward as one graph and one graph per gradient bucket of the "
+                         "backward (DP hooks between the graphs); off = every launch live; auto = all on 1 GPU, bwd on N > 1")
     ap.add_argument("--bracket-every", type=int, default=5,
                     help="bracket every n-th launch of the dominant kernel with HIP events inside the timed region (an event record is a "
                          "packet of its own: bracketing all 128 launches of a step costs 0.7 ms of it; 5 is coprime to the 4 unit shapes "
@@ -546,11 +546,11 @@ def main():
     records.reserve(2 * len(wl["units"]) * args.steps + 16)
 
     # hipGraphs (the library only enqueues on the stream it is given -- no allocation, no synchronisation -- so its launches
-    # capture unchanged).  "bwd": the backward launches of every gradient bucket (4 layers: 80 kernels) replay as one graph each;
-    # the forward stays live so that the dominant kernel is bracketed with HIP events inside the timed region, and the bucket
-    # hooks (RCCL all-reduce of a finished bucket) run between the graphs exactly as between live layers.  "all": the whole
-    # micro-batch as one graph (single GPU, no brackets: `roofline` then comes from the extra pass).
-    fwd_bwd_graph, bwd_graphs = None, None
+    # capture unchanged).  "bwd": the forward as one graph and the backward launches of every gradient bucket (4 layers: 80 kernels)
+    # as one graph each; the bucket hooks (RCCL all-reduce of a finished bucket) run between the graphs exactly as between live
+    # layers.  "all": the whole micro-batch as one graph (single GPU).  Nothing can be bracketed inside a graph: `roofline` then
+    # comes from the extra live passes behind the timed region.
+    fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
     if args.graph != "off":
         try:
             side = torch.cuda.Stream(device=dev)
@@ -576,6 +576,9 @@ def main():
                     for st in branch:
                         cur.wait_stream(st)          # join
             else:
+                fwd_graph = torch.cuda.CUDAGraph()       # the forward has no hooks: one graph
+                with torch.cuda.graph(fwd_graph, stream=side):
+                    run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream))
                 lpb = bucket.layers_per_bucket
                 bwd_graphs = []
                 for hi in range(L, 0, -lpb):             # buckets are aligned groups of layers, walked last -> first
@@ -587,7 +590,7 @@ def main():
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
             print(f"bench: hipGraph capture failed ({exc!r}); launching live", file=sys.stderr)
-            fwd_bwd_graph, bwd_graphs = None, None
+            fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
             torch.cuda.synchronize()
 
     def step(i, rec=None):
@@ -597,7 +600,10 @@ def main():
         if fwd_bwd_graph is not None:
             fwd_bwd_graph.replay()
         else:
-            run_forward(lib, wl, sp, rec)
+            if fwd_graph is not None:
+                fwd_graph.replay()
+            else:
+                run_forward(lib, wl, sp, rec)
             if bwd_graphs is not None:
                 for g, lo, hi in bwd_graphs:
                     g.replay()
