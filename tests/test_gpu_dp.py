@@ -185,6 +185,39 @@ def test_attach_feeds_the_kernels_and_matches_plain_autograd():
     assert dp.bucket.n_layers == 3
 
 
+def test_two_half_batches_on_two_streams_add_up_to_the_full_batch():
+    """The samples of a micro-batch are independent chains of launches (nothing in the model mixes tokens of different samples):
+    half the batch on each of two HIP streams, forward + backward through the kernels CONCURRENTLY, the weight-gradient kernels of
+    both adding into the same flat bucket (atomics) -- the sum equals the gradient of the whole batch in one pass.  (The schedule
+    `bench.py --chains 2` measures; this pins that the library is safe to drive from two streams at once.  Under data parallelism the
+    chains run with `dp.sync = False` -- a layer is only finished when BOTH halves have passed it -- and `finish()` ships the buckets.)"""
+    dev = torch.device("cuda:0")
+    from moka_amd.parallel import attach
+    st, dims = _build("avt", dev)
+    dp = attach(st, n_buckets=3)
+    h, gout, mask_args, sl = _batch("avt", dims, dev)
+    x_full = h.clone().requires_grad_(True)
+    _run(st, dp, x_full, gout, mask_args, 1.0)
+    dp.finish(average=False)
+    torch.cuda.synchronize()
+    ref, ref_dx = dp.bucket.flat.clone(), x_full.grad.clone()
+    dp.bucket.flat.zero_()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    xs = [h[b:b + 1].clone().requires_grad_(True) for b in range(2)]
+    torch.cuda.synchronize()
+    for b, sm in enumerate(streams):
+        with torch.cuda.stream(sm):
+            _run(st, dp, xs[b], gout[b:b + 1], sl(b, b + 1), 1.0)
+    torch.cuda.synchronize()
+    dp.finish(average=False)
+    torch.cuda.synchronize()
+    err = ((dp.bucket.flat - ref).norm() / ref.norm()).item()
+    assert err <= 2e-4, err                                           # same products, another summation order
+    for b in range(2):
+        e = ((xs[b].grad.float() - ref_dx[b:b + 1].float()).norm() / ref_dx[b:b + 1].float().norm()).item()
+        assert e <= 2e-2, (b, e)                                      # bf16 activations, per-sample vs batched launches
+
+
 def test_sharded_frozen_base_under_the_real_stack_on_gpu():
     """SURVEY 8(f3) on hardware (world 1: the shard is the whole layer, the machinery is the same): the frozen tensors of every
     decoder layer live in ShardedFrozenBase, the layer hooks stage them into the two buffers for forward and backward, the
