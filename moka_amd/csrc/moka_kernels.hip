@@ -6,7 +6,9 @@
 //   gy      (Y)  gy[T,C] bf16 -> g_part[KS,T,RP] fp32 + dB            B1: gy.Bw and dB in one pass over gy
 //   cross   (X)  rank-r cross-modal softmax interaction, fwd and bwd: fp32 MFMA (16x16x4), keys streamed in chunks, + operand packs
 //   expand  (E)  out[T,C] bf16 += pack[T,:] . W^T                     F2: y += hp.Bw^T     B3: dx += dh.A_m
-//   wgrad   (G)  acc[C,r] fp32 += sum_t in[t,c] * pack[k,t]           B1: dB (r > 16)      B3: dA_m
+//   wgrad   (G)  acc[C,r] fp32 += sum_t in[t,c] * pack[k,t]           B1: dB (r > 16)      B3: dA_m     (rank pad 64: the "wide" form,
+//                rank tiles split across the waves of a block, tile staged block-wide in LDS)
+//   xw      (F') the down-projection with independent waves and the weight fragments staged in LDS (rank pads 32 / 64)
 //   adamw   (O)  AdamW + gradient averaging + bf16 working copy + gradient zeroing on the flat adapter buffers
 //
 // Design (numbers measured on MI355X; profiles/ and tools/microbench/):
@@ -22,6 +24,10 @@
 //     fragments; the [32 x RP] partials of the eight waves meet in LDS and leave as one split-K slice.
 //   * E: each wave keeps the weight fragments of its 128 output columns in registers and walks over token
 //     tiles; per tile one 16-byte pack load feeds 8 MFMAs and 4 x 16-byte read-modify-writes of the in/out tensor.
+//     (dx at rank pads 32 / 64: contiguous token runs with ONE resident weight set, reloaded at span boundaries.)
+//   * The small operands beside the stream decide more than their size suggests: the rank-major packs are stored as
+//     contiguous 1 KB blocks in MFMA lane order (16 segments of 64 B a power-of-two stride apart hit one L2 channel and
+//     cost half of the rank-64 weight-gradient time); batched launches enumerate only blocks that have work.
 //   * G: tokens are the MFMA K dimension, so the streamed tile must be K-major: each wave copies its
 //     own 32-token x 64-column tile to a private LDS region and reads it back transposed with
 //     ds_read_b64_tr_b16 -- no block barrier in the stream.  A block owns 64 columns for a long run
