@@ -779,11 +779,6 @@ def _random_case(seed, ranks=(4, 8, 16, 16, 16, 32)):
     return C.make_case_data(name)
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
-def test_random_shapes_and_layouts(seed):
-    _stage_check(_random_case(seed))
-
-
 def _fuzz_seeds(default):
     """MOKA_FUZZ_SEEDS="a-b" widens a fuzz test to seeds a..b-1 (stress runs on the GPU box; the default keeps the suite short)."""
     spec = os.environ.get("MOKA_FUZZ_SEEDS", "")
@@ -791,6 +786,11 @@ def _fuzz_seeds(default):
         lo, hi = spec.split("-")
         return list(range(int(lo), int(hi)))
     return list(default)
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(range(16)))
+def test_random_shapes_and_layouts(seed):
+    _stage_check(_random_case(seed))
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds(range(100, 108)))
