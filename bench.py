@@ -460,7 +460,7 @@ def end_to_end(args, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60, help="timed steps (default: ~2 s of GPU work, long enough for an external busy sampler to see it)")
+    ap.add_argument("--steps", type=int, default=120, help="timed steps (default: ~4 s of GPU work, long enough for an external busy sampler to see it)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="sequences per GPU (reference AVT micro-batch: ft_musicavqa.sh:12-13)")
     ap.add_argument("--seq", type=int, default=2048)
