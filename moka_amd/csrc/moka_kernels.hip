@@ -44,6 +44,20 @@
 
 #include "moka_hip.h"
 
+// Per-wave timeline probe (tools/microbench/passlab.hip builds this file with -DMOKA_TRACE): lane 0 of every wave writes the
+// 100 MHz wall clock into slot `s` of its row of the buffer the harness installed.  Compiled out of the product library.
+#ifdef MOKA_TRACE
+__device__ unsigned long long* g_moka_trace = nullptr;
+#define TRACE_ROWS 65536            // rows (waves) per kernel family
+// (the pointer is read ONCE, at kernel entry: read at every probe it is a vector load followed by s_waitcnt vmcnt(0), which
+//  drains the very prefetches the probe is meant to observe)
+#define TRACE_DECL(fam) unsigned long long* const trace_p = g_moka_trace; const size_t trace_row = ((size_t)(fam) * TRACE_ROWS + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8
+#define TRACE(s) do { if (trace_p && (threadIdx.x & 63) == 0) trace_p[trace_row + (s)] = wall_clock64(); } while (0)
+#else
+#define TRACE_DECL(fam)
+#define TRACE(s)
+#endif
+
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -944,8 +958,11 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     }
     const ExpandArgs& a = ab.z[G == 1 ? zi : 0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int GY = (int)gridDim.y, BY = (int)blockIdx.y;
     const int i = lane & 15, g = lane >> 4;
     const int c_wave = xb * CW + wave * WC;
+    TRACE_DECL(3);
+    TRACE(0);
     if (c_wave >= a.C) return;                         // C % 32 == 0, WC may overshoot in the last block
     const int wr = W_CK ? a.r : RP;                    // row length of the weight source (AT is padded to RP)
 
@@ -997,10 +1014,10 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     // tiles of this wave: blockIdx.y, + gridDim.y, ... ; RUNS: the contiguous run [t_first, t_last) -- spans are contiguous in the
     // token order, so a run stays inside one modality for long stretches and ONE resident weight set (reloaded at span
     // boundaries) replaces "text resident + the others fetched per tile"
-    const int t_per = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int t_first = RUNS ? (int)blockIdx.y * t_per : (int)blockIdx.y;
+    const int t_per = (ntiles + GY - 1) / GY;
+    const int t_first = RUNS ? BY * t_per : BY;
     const int t_last = RUNS ? min(ntiles, t_first + t_per) : ntiles;
-    const int step = RUNS ? 1 : (int)gridDim.y;
+    const int step = RUNS ? 1 : GY;
     auto issue = [&](Tile& R, int tile) {
         const int tt = min(tile, t_last - 1);
         const int t = min((tt << 4) + i, a.T - 1);                // operand / result lanes: token = lane & 15
@@ -1220,8 +1237,8 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     // one 16-byte look at the routing bytes of each of my tiles (lane j <-> my j-th tile) decides the path
     bool fast = (c_wave + WC <= a.C) && (a.T % 16 == 0) && (((size_t)a.tok_mod & 15) == 0);
     {
-        const int per = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
-        const int first = RUNS ? (int)blockIdx.y * per : (int)blockIdx.y, stp = RUNS ? 1 : (int)gridDim.y;
+        const int per = (ntiles + GY - 1) / GY;
+        const int first = RUNS ? BY * per : BY, stp = RUNS ? 1 : GY;
         const int nmine = RUNS ? min(ntiles, first + per) - first : (ntiles - first + stp - 1) / stp;
         if (nmine > 64 || nmine < 1) fast = false;
         if (fast) {
@@ -1235,6 +1252,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
     }
     if (fast) body(std::true_type{});
     else body(std::false_type{});
+    TRACE(7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1299,6 +1317,8 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     const int grp_end = min(ngroups, grp_begin + a.groups_per_block);
     const int lrow = lane >> 3, lcol = lane & 7;
     if (tid == 0) *touched = 0;
+    TRACE_DECL(2);
+    TRACE(0);
 
     f32x4 acc[NM][NSB][CT][NT];
 #pragma unroll
@@ -1422,6 +1442,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
         second_pack(grp, pres_cur);
         issue(ldB, bhB, blB, min(grp + 1, wlast), pres_nxt);
         if (pres_cur) compute(ldA, bhA, blA, bhx, blx, grp, pres_cur);
+        if (grp == grp_begin + wave * per_wave) TRACE(1);
         grp += 1; pres_cur = pres_nxt; mym_nxt = mym_nn;
         if (grp >= wend) break;
         mym_nn = routing_of(grp + 2);
@@ -1438,8 +1459,10 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     // round, a full L2 round trip per modality (measured: 8.5 us of a 29 us dA launch).  Consecutive
     // rounds alternate between two buffers (the wave's own, now idle, tile region and `red`), so one
     // barrier per round is enough: round k+2 rewrites a buffer only after everybody passed barrier k+1.
+    TRACE(5);
     if (lane == 0 && ever) atomicOr(touched, ever);
     __syncthreads();
+    TRACE(6);
     const unsigned any = *touched;
     constexpr bool ALIAS = (size_t)RSZ * 4 <= (size_t)REGION;
     int round = 0;
@@ -1481,6 +1504,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
         if (!ALIAS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // single buffer: reads done before the next round writes
         ++round;
     }
+    TRACE(7);
 }
 
 // Wide ranks (RP = 64): the same product with the RANK TILES split across the waves of a block.
@@ -1774,6 +1798,8 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     const GyArgs& a = ab.z[zi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
+    TRACE_DECL(1);
+    TRACE(0);
     const int ngroups = a.Tp >> 5;
     const int grp0 = blockIdx.y * NG;
     if (grp0 >= ngroups) return;
@@ -1902,12 +1928,16 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
     for (int gi = 0; gi < NG; gi += 2) {
         issue(FB, bhB, blB, grp0 + gi + 1);
         compute(FA, bhA, blA, gi);
+        if (gi == 0) TRACE(1);
         issue(FA, bhA, blA, grp0 + gi + 2);
         if (PH == 1) reduce_phase(gi);
         compute(FB, bhB, blB, gi + 1);
+        if (gi == 0) TRACE(2);
         if (PH == 1) reduce_phase(gi + 1);
         else reduce_phase(gi / 2);
+        if (gi == 0) TRACE(3);
     }
+    TRACE(6);
 
     if (WITH_DB) {
         // dB leaves as [column][rank] rows: wave w's accumulators hold columns cb0 + 64w .. of it, the destination rows of the waves
@@ -1934,6 +1964,7 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
             }
         }
     }
+    TRACE(7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1962,6 +1993,8 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
     constexpr int RSLOT = 32 * RP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
+    TRACE_DECL(0);
+    TRACE(0);
     const int ngroups = (a.T + 31) >> 5;
     const int grp0 = blockIdx.y * NG;
     if (grp0 >= ngroups) return;
@@ -2081,10 +2114,14 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
     for (int gi_ = 0; gi_ < NG; gi_ += 2) {
         issue(FB, mrB, grp0 + gi_ + 1);
         compute(FA, mrA, gi_, 0);
+        if (gi_ == 0) TRACE(1);
         issue(FA, mrA, grp0 + gi_ + 2);
         compute(FB, mrB, gi_ + 1, 1);
+        if (gi_ == 0) TRACE(2);
         reduce_phase(gi_ / 2);
+        if (gi_ == 0) TRACE(3);
     }
+    TRACE(7);
 }
 
 // ------------------------------------------------------------------------------------------
