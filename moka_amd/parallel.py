@@ -162,52 +162,139 @@ class FlatAdamW:
             self.betas = (float(sd["betas"][0]), float(sd["betas"][1]))
 
 
-_LAYER_RE = re.compile(r"(?:^|\.)layers\.(\d+)\.")
+_LAYER_RE = re.compile(r"^(.*?(?:^|\.)layers)\.(\d+)\.")
+
+
+def _in_backward() -> bool:
+    """True while an autograd backward pass is running on this thread (activation checkpointing re-runs layer forwards there)."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return bool(f is not None and f() != -1)
+
+
+def _decoder_prefix(names: Sequence[str]) -> Optional[str]:
+    """The ``<prefix>.layers`` module list that owns most of the adapter parameters: the decoder stack.  Vision / audio
+    encoders have ``...encoder.layers.N`` modules with the SAME indices; their parameters must not land in the decoder
+    layer's gradient group (that bucket ships when the DECODER layer has finished its backward)."""
+    count = {}
+    for n in names:
+        m = _LAYER_RE.search(n)
+        if m:
+            count[m.group(1)] = count.get(m.group(1), 0) + 1
+    return max(count, key=lambda k: (count[k], -len(k))) if count else None
 
 
 class AdapterDataParallel:
-    """What ``attach`` returns: the flat buffers of a model's adapter, the bucketed gradient all-reduce hooked to the
-    backward of its decoder layers, and the fused optimizer step.
+    """What ``attach`` returns: the flat buffers of a model's trainable parameters, the bucketed gradient all-reduce hooked to
+    the backward of its decoder layers, and the fused optimizer step.
 
         dp = moka_amd.parallel.attach(model)        # after get_peft_model / PeftMixedModel + set_adapter
         for batch in loader:
             loss = model(**batch).loss
             loss.backward()                         # weight-gradient kernels add into dp.bucket.flat; a finished bucket of
             dp.step()                               #   layers is all-reduced (RCCL, side stream) while the backward goes on
-    """
+
+    Gradient accumulation: ``with dp.no_sync(): ...backward of every micro-batch but the last...`` (as DDP's ``no_sync``);
+    a second backward with ``sync`` on and buckets already shipped raises instead of racing the collective.
+    Under HF ``Trainer``: ``MokaFlatOptimizer(dp)`` + ``MokaDPCallback(dp)`` (below)."""
 
     def __init__(self, model: nn.Module, bucket: FlatGradBucket, master: torch.Tensor, work: torch.Tensor, names: List[str],
-                 offsets: List[int], optimizer: Optional[FlatAdamW], handles: list):
+                 offsets: List[int], sizes: List[int], optimizer: Optional[FlatAdamW], handles: list):
         self.model, self.bucket, self.master, self.work = model, bucket, master, work
-        self.names, self.offsets, self.optimizer, self._handles = names, offsets, optimizer, handles
+        self.names, self.offsets, self.sizes, self.optimizer, self._handles = names, offsets, sizes, optimizer, handles
+        self.kernel_fed: List[str] = []              # parameters whose gradients the weight-gradient kernels write (sinks)
+        self.hooked: List[str] = []                  # the other trainable parameters: autograd gradients folded in by a hook
         self._done = set()
         self.sync = True                             # False while accumulating micro-batches: the hooks ship nothing (cf. DDP.no_sync)
 
+    # ---------------------------------------------------------------- backward side
     def _layer_done(self, l: int) -> None:
         if not self.sync or l in self._done:
             return
         self._done.add(l)
         self.bucket.layer_done(l)
 
+    def _forward_begins(self) -> None:
+        """Called from the decoder layers' forward pre-hooks.  A NEW forward while buckets of the previous backward are on their
+        way (or already summed) and no step() / finish() in between means gradient accumulation without ``no_sync``: the next
+        backward's kernels would add into memory an in-place all-reduce is working on, and those layers would not be shipped
+        again.  DDP is merely slower in that situation; here it would be silently wrong, so it is an error."""
+        if self.sync and (self._done or self.bucket._pending) and torch.is_grad_enabled() and not _in_backward():
+            raise RuntimeError("moka_amd.parallel: a new forward started while gradient buckets of the previous backward are in flight. "
+                               "Accumulate micro-batches under `with dp.no_sync():` (sync only on the last one), or call dp.step() / "
+                               "dp.finish() after every backward.")
+
+    def no_sync(self):
+        """Context manager: the backward hooks ship nothing (gradient accumulation); everything is shipped by the next
+        synchronised backward or by ``finish()``."""
+        dp = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                self_inner.prev, dp.sync = dp.sync, False
+
+            def __exit__(self_inner, *exc):
+                dp.sync = self_inner.prev
+                return False
+        return _NoSync()
+
     def finish(self, average: bool = True) -> None:
-        """Join the all-reduces (every bucket whose hook did not fire -- frozen layers, models without `.layers.N.` modules --
-        is shipped now).  With ``average`` the flat buffer then holds the mean gradient over the ranks."""
+        """Join the all-reduces (every bucket whose hook did not fire -- frozen layers, the parameters outside the decoder
+        stack, models without `.layers.N.` modules -- is shipped now).  With ``average`` the flat buffer then holds the mean
+        gradient over the ranks."""
         for l in range(self.bucket.n_layers - 1, -1, -1):
             if l not in self._done and (l % self.bucket.layers_per_bucket) == 0:
                 self.bucket.layer_done(l)
         self._done.clear()
         self.bucket.finish(average=average)
 
-    def step(self) -> None:
-        """finish() + the fused AdamW kernel (averaging folded into it, gradients left zeroed, bf16 parameters refreshed)."""
+    def step(self, max_grad_norm: Optional[float] = None) -> Optional[torch.Tensor]:
+        """finish() + the fused AdamW kernel (averaging folded into it, gradients left zeroed, working copies refreshed).
+        max_grad_norm: clip the l2 norm of the AVERAGED gradient (HF ``max_grad_norm`` / DeepSpeed ``gradient_clipping``,
+        ``VisualText/zero_stage2_config.json:36``); the coefficient is folded into the kernel's gradient scale (one host read
+        of the norm).  Returns the norm of the averaged gradient when clipping is on."""
         if self.optimizer is None:
             raise RuntimeError("attach(..., optimizer=False): call finish() and run your own optimizer on dp.master / dp.bucket.flat")
         self.finish(average=False)
-        self.optimizer.step(grad_scale=1.0 / self.bucket.world, zero_grad=True)
+        scale = 1.0 / self.bucket.world
+        norm = None
+        if max_grad_norm is not None and max_grad_norm > 0:
+            norm = self.bucket.flat.norm() * scale
+            scale *= min(1.0, float(max_grad_norm) / (float(norm) + 1e-6))
+        self.optimizer.step(grad_scale=scale, zero_grad=True)
+        return norm
 
     def grad_norm(self) -> torch.Tensor:
-        """l2 norm of the (summed, not yet averaged) flat gradient -- for clipping / logging."""
+        """l2 norm of the flat gradient AS IT STANDS: the local gradient before finish(), the sum over ranks after
+        ``finish(average=False)``, the mean after ``finish()``.  (``step(max_grad_norm=...)`` clips the mean.)"""
         return self.bucket.flat.norm()
+
+    # ---------------------------------------------------------------- parameters / state
+    def parameters(self) -> List[torch.nn.Parameter]:
+        by = dict(self.model.named_parameters())
+        return [by[n] for n in self.names]
+
+    def state_dict(self) -> dict:
+        """Everything a resume needs beyond the module's own state_dict: the fp32 master copy (the module parameters are its
+        bf16 rounding) and the AdamW moments.  Tensors are references; ``torch.save`` them or ``clone()`` first."""
+        return {"names": list(self.names), "offsets": list(self.offsets), "sizes": list(self.sizes), "master": self.master,
+                "optimizer": None if self.optimizer is None else self.optimizer.state_dict()}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if list(sd["names"]) != self.names or list(sd["offsets"]) != self.offsets:
+            raise ValueError("moka_amd.parallel: the checkpoint was taken from a different parameter layout")
+        self.master.copy_(sd["master"])
+        with torch.no_grad():
+            self.work.copy_(self.master)             # bf16 working copies (fp32 parameters are views of the master itself)
+        if self.optimizer is not None and sd.get("optimizer") is not None:
+            self.optimizer.load_state_dict(sd["optimizer"])
+
+    def detached_state_dict(self, state_dict: Optional[dict] = None) -> dict:
+        """``model.state_dict()`` (or the given one) with every tensor that is a view of the flat buffers cloned into its own
+        storage: what ``safetensors.torch.save_model`` / ``save_file`` want (they refuse tensors that share one storage)."""
+        sd = self.model.state_dict() if state_dict is None else state_dict
+        shared = {self.work.untyped_storage().data_ptr(), self.master.untyped_storage().data_ptr()}
+        return {k: (v.detach().clone() if isinstance(v, torch.Tensor) and v.untyped_storage().data_ptr() in shared else v)
+                for k, v in sd.items()}
 
     def detach(self) -> None:
         for h in self._handles:
@@ -219,32 +306,66 @@ class AdapterDataParallel:
 
 def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: bool = True, lr: float = 1e-4,
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-           comm_dtype: Optional[torch.dtype] = None) -> AdapterDataParallel:
+           comm_dtype: Optional[torch.dtype] = None, trainable=None) -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
-    base and the full adapter, batches are sharded by sample, and the only exchange is the adapter-gradient sum.
+    base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
-    * every trainable ``lora_`` parameter of ``model`` (the selection of the reference scripts: ``finetune.py:151-160``,
-      ``train.py:576``) is re-seated, in module order, into ONE flat bf16 working buffer (what the kernels read) with an fp32
-      master copy and ONE flat fp32 gradient buffer, grouped by decoder layer (``...layers.<i>...`` in the parameter name);
-    * the adapted projections get views of that gradient buffer as *sinks*: their weight-gradient kernels accumulate
-      straight into it (fp32, across micro-batches too) and autograd carries no adapter gradients at all;
+    * EVERY trainable parameter of ``model`` (``trainable(name, param)``, default ``param.requires_grad``) is re-seated, in
+      module order, into flat buffers: an fp32 master copy, ONE flat fp32 gradient buffer, and a bf16 working copy that bf16
+      parameters become views of (fp32 parameters -- the reference's adapters follow the base dtype, ``layer.py:124-132`` --
+      become views of the master itself).  Both reference scripts train more than the adapter: the Q-Former projectors
+      (``AudioVisualText/scripts/finetune/finetune.py:151-160``, ``VisualText/train/train.py:573-579``); they ride in the same
+      buffer, the same all-reduce and the same optimizer step;
+    * the adapter parameters of the decoder stack are grouped by decoder layer (the ``<prefix>.layers.<i>.`` module list
+      that owns most of them; an encoder's ``layers.<i>`` do not count); the adapted projections get views of the gradient
+      buffer as *sinks*: their weight-gradient kernels accumulate straight into it (fp32, across micro-batches too) and
+      autograd carries no adapter gradients at all;
+    * every other trainable parameter gets a post-accumulate-grad hook that adds its autograd gradient into its slice of the
+      flat buffer and drops ``.grad``; these sit in a group of their own that ``finish()`` ships (their gradients are the
+      last ones a backward produces);
     * a gradient hook on every decoder layer's input reports the layer as finished; ``FlatGradBucket`` starts the RCCL
       all-reduce of a finished bucket of layers on a side stream while the remaining layers' backward runs;
-    * ``step()`` joins, and one kernel (``moka_adamw_flat``) averages, applies AdamW, refreshes the bf16 parameters and
-      zeroes the gradients.
+    * ``step()`` joins, and one kernel (``moka_adamw_flat``) averages (and clips), applies AdamW, refreshes the working
+      copies and zeroes the gradients.
 
     Replaces DeepSpeed ZeRO-2's bucketed reduce-scatter + partitioned optimizer of the reference configurations
-    (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``) for the only trainable part."""
-    named = [(n, p) for n, p in model.named_parameters() if "lora_" in n and p.requires_grad]
+    (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``)."""
+    pick = trainable if trainable is not None else (lambda n, p: p.requires_grad)
+    named = [(n, p) for n, p in model.named_parameters() if pick(n, p)]
     if not named:
-        raise ValueError("attach: the model has no trainable lora_ parameters (call get_peft_model / set_adapter first)")
+        raise ValueError("attach: the model has no trainable parameters (call get_peft_model / set_adapter first)")
     dev = named[0][1].device
     if any(p.device != dev for _, p in named):
-        raise ValueError("attach: the adapter parameters must live on one device (one process per GPU)")
+        raise ValueError("attach: the trainable parameters must live on one device (one process per GPU)")
+    for n, p in named:
+        if p.dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError(f"attach: {n} is {p.dtype}; trainable parameters must be bf16 or fp32")
+    # which parameters do the kernels feed?  (the adapter matrices of the two mirrors' adapted projections)
+    sink_of = {}                                                                  # parameter name -> (module, "B" | index into "A")
+    for mod_name, mod in model.named_modules():
+        pre = mod_name + "." if mod_name else ""
+        if hasattr(mod, "lora_B0") and hasattr(mod, "_plan"):                    # AVT mirror: lora_A0.., lora_B0
+            sink_of[f"{pre}lora_B0.weight"] = (mod, "B")
+            for i in range(getattr(mod, "lora_num", 0)):
+                sink_of[f"{pre}lora_A{i}.weight"] = (mod, i)
+        elif hasattr(mod, "lora_A") and hasattr(mod, "_plan") and "text" in getattr(mod, "lora_A", {}):   # VT mirror
+            sink_of[f"{pre}lora_B.text.weight"] = (mod, "B")
+            sink_of[f"{pre}lora_A.text.weight"] = (mod, 0)
+            sink_of[f"{pre}lora_A.image.weight"] = (mod, 1)
+    picked = {n for n, _ in named}
+    # a projection is kernel-fed only if ALL its adapter matrices are trainable (otherwise autograd + hooks handle what is)
+    by_mod = {}
+    for n, (mod, slot) in sink_of.items():
+        by_mod.setdefault(id(mod), []).append(n)
+    fed = set()
+    for ns in by_mod.values():
+        if all(n in picked for n in ns):
+            fed.update(ns)
+    prefix = _decoder_prefix([n for n, _ in named if n in fed])
     layer_of = []
     for n, _ in named:
         m = _LAYER_RE.search(n)
-        layer_of.append(int(m.group(1)) if m else -1)
+        layer_of.append(int(m.group(2)) if (m and n in fed and m.group(1) == prefix) else -1)
     ids = sorted(set(layer_of))
     order = sorted(range(len(named)), key=lambda k: (layer_of[k], k))            # layer by layer, module order inside a layer
     names, offsets, sizes, ends = [], [], [], []
@@ -266,44 +387,128 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
     with torch.no_grad():
         for n, o, sz in zip(names, offsets, sizes):
             p = by_name[n]
-            if p.dtype != torch.bfloat16:
-                raise TypeError(f"attach: {n} is {p.dtype}; the flat working copy is bf16 (the HIP path stores the adapter in bf16)")
             master[o:o + sz].copy_(p.detach().reshape(-1))
             work[o:o + sz].copy_(p.detach().reshape(-1))
-            p.data = work[o:o + sz].view(p.shape)                                # the module parameter IS the working copy
+            # the module parameter IS the working copy (bf16) / the master (fp32 storage)
+            p.data = (work if p.dtype == torch.bfloat16 else master)[o:o + sz].view(p.shape)
             grad_view[n] = bucket.flat[o:o + sz].view(p.shape)
-    # sinks of the adapted projections (both mirrors)
-    for mod_name, mod in model.named_modules():
-        pre = mod_name + "." if mod_name else ""
-        if hasattr(mod, "lora_B0") and hasattr(mod, "_plan"):                    # AVT mirror: lora_A0.., lora_B0
-            a = [grad_view.get(f"{pre}lora_A{i}.weight") for i in range(getattr(mod, "lora_num", 0))]
-            b = grad_view.get(f"{pre}lora_B0.weight")
-            if b is not None and all(v is not None for v in a):
-                mod._moka_sinks = {"B": b, "A": a}
-        elif hasattr(mod, "lora_A") and hasattr(mod, "_plan") and "text" in getattr(mod, "lora_A", {}):   # VT mirror
-            a = [grad_view.get(f"{pre}lora_A.text.weight"), grad_view.get(f"{pre}lora_A.image.weight")]
-            b = grad_view.get(f"{pre}lora_B.text.weight")
-            if b is not None and all(v is not None for v in a):
-                mod._moka_sinks = {"B": b, "A": a}
     opt = FlatAdamW(master, bucket.flat, work, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if optimizer else None
-    dp = AdapterDataParallel(model, bucket, master, work, names, offsets, opt, [])
-    # backward hooks: bucket index l = position of the layer id among the layers that own adapter parameters
+    dp = AdapterDataParallel(model, bucket, master, work, names, offsets, sizes, opt, [])
+    # sinks of the adapted projections (both mirrors)
+    mods = {}
+    for n in fed:
+        mod, slot = sink_of[n]
+        sk = mods.setdefault(id(mod), (mod, {"B": None, "A": {}}))[1]
+        if slot == "B":
+            sk["B"] = grad_view[n]
+        else:
+            sk["A"][slot] = grad_view[n]
+    for mod, sk in mods.values():
+        mod._moka_sinks = {"B": sk["B"], "A": [sk["A"][i] for i in sorted(sk["A"])]}
+    dp.kernel_fed = [n for n in names if n in fed]
+    dp.hooked = [n for n in names if n not in fed]
+    # every other trainable parameter: fold the autograd gradient into the flat buffer the moment it has been accumulated
+    def fold(view):
+        def hook(p):
+            if p.grad is not None:
+                view.add_(p.grad.to(view.dtype).view_as(view))
+                p.grad = None
+        return hook
+    for n in dp.hooked:
+        dp._handles.append(by_name[n].register_post_accumulate_grad_hook(fold(grad_view[n])))
+    # backward hooks: bucket index l = position of the layer id among the groups that own parameters
     pos = {lid: i for i, lid in enumerate(ids)}
-    # "layer l has finished its backward" = the gradient w.r.t. the layer's INPUT has been formed (every backward node of the
-    # layer, the adapter kernels of its projections included, runs before that).  A tensor hook on the input says exactly that; a
-    # module full-backward hook does not (it fires at the START of the layer's backward when the input needs no gradient -- the
-    # first layer).  Layers whose input carries no gradient are shipped by finish().
+    # "layer l has finished its backward" = the gradient w.r.t. the layer's INPUT has been formed (every adapter node of the
+    # layer runs before that: q/k/v feed it, o / gate / up / down sit nearer the loss).  A tensor hook on the input says exactly
+    # that; a module full-backward hook does not (it fires at the START of the layer's backward when the input needs no
+    # gradient -- the first layer).  Layers whose input carries no gradient are shipped by finish().
     def pre_hook(l):
         def hook(_mod, args, kwargs=None):
+            dp._forward_begins()
             x = args[0] if args else None
             if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
                 x.register_hook(lambda _g, l=l: dp._layer_done(l))
         return hook
-    for mod_name, mod in model.named_modules():
-        m = re.search(r"(?:^|\.)layers\.(\d+)$", mod_name)
-        if m and int(m.group(1)) in pos:
-            dp._handles.append(mod.register_forward_pre_hook(pre_hook(pos[int(m.group(1))])))
+    if prefix is not None:
+        for mod_name, mod in model.named_modules():
+            if mod_name.startswith(prefix + ".") and mod_name[len(prefix) + 1:].isdigit() and int(mod_name[len(prefix) + 1:]) in pos:
+                dp._handles.append(mod.register_forward_pre_hook(pre_hook(pos[int(mod_name[len(prefix) + 1:])])))
     return dp
+
+
+class MokaFlatOptimizer(torch.optim.Optimizer):
+    """``torch.optim.Optimizer``-shaped handle on ``attach``'s flat buffers, so that training loops written around an optimizer
+    object -- HF ``Trainer`` (``AudioVisualText/trainer.py:163-218``, ``VisualText/train/train.py:601-617``), LR schedulers --
+    drive the data-parallel step:  ``Trainer(model=..., optimizers=(MokaFlatOptimizer(dp), scheduler), callbacks=[MokaDPCallback(dp)])``.
+
+    * ``step()`` = ``dp.step(max_grad_norm)``: join the gradient all-reduce, one fused kernel for averaging / clipping /
+      AdamW / working copies / gradient zeroing.  The hyper-parameters are read from ``param_groups[0]`` at every step, so
+      schedulers that rewrite ``group["lr"]`` work unchanged;
+    * ``zero_grad()`` is a no-op (the kernel leaves the flat gradient zeroed; ``param.grad`` is never populated -- set the
+      trainer's own ``max_grad_norm`` to 0 and pass the clip value here);
+    * ``state_dict()`` carries the fp32 master copy and the AdamW moments (``dp.state_dict()``)."""
+
+    def __init__(self, dp: AdapterDataParallel, lr: Optional[float] = None, betas=None, eps: Optional[float] = None,
+                 weight_decay: Optional[float] = None, max_grad_norm: Optional[float] = None):
+        if dp.optimizer is None:
+            raise ValueError("MokaFlatOptimizer needs attach(..., optimizer=True)")
+        o = dp.optimizer
+        defaults = dict(lr=o.lr if lr is None else float(lr), betas=tuple(o.betas if betas is None else betas),
+                        eps=o.eps if eps is None else float(eps), weight_decay=o.weight_decay if weight_decay is None else float(weight_decay))
+        super().__init__([{"params": dp.parameters()}], defaults)
+        self.dp, self.max_grad_norm = dp, max_grad_norm
+        self.last_grad_norm = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g, o = self.param_groups[0], self.dp.optimizer
+        o.lr, o.betas, o.eps, o.weight_decay = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"]), float(g["weight_decay"])
+        self.last_grad_norm = self.dp.step(max_grad_norm=self.max_grad_norm)
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        return None
+
+    def state_dict(self) -> dict:
+        sd = super().state_dict()
+        sd["moka_flat"] = self.dp.state_dict()
+        return sd
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        sd = dict(state_dict)
+        flat = sd.pop("moka_flat", None)
+        super().load_state_dict(sd)
+        if flat is not None:
+            self.dp.load_state_dict(flat)
+
+
+def trainer_callback(dp: AdapterDataParallel):
+    """``transformers.TrainerCallback`` that keeps ``dp.sync`` off for every micro-batch of a gradient-accumulation window but
+    the last (what ``accelerator.no_sync`` does for a DDP model), so that the bucketed all-reduce overlaps the LAST backward
+    and nothing is shipped twice.  Not needed for correctness -- with ``dp.sync = False`` throughout, ``step()`` ships
+    everything -- only for the overlap."""
+    from transformers import TrainerCallback
+
+    class MokaDPCallback(TrainerCallback):
+        def __init__(self):
+            self.k = 0
+
+        def on_train_begin(self, args, state, control, **kw):
+            dp.sync = args.gradient_accumulation_steps == 1
+
+        def on_step_begin(self, args, state, control, **kw):
+            self.k = 0
+            dp.sync = args.gradient_accumulation_steps == 1
+
+        def on_substep_end(self, args, state, control, **kw):
+            self.k += 1
+            dp.sync = self.k == args.gradient_accumulation_steps - 1
+
+    return MokaDPCallback()
 
 
 def bind_param_grads(params: Sequence[torch.nn.Parameter], bucket: FlatGradBucket, offsets: Sequence[int]):

@@ -1,0 +1,140 @@
+"""the data-parallel step behind a torch.optim.Optimizer-shaped handle that HF Trainer drives
+(AudioVisualText/trainer.py:163-218, VisualText/train/train.py:601-617 both call Trainer.train()), and fp32-storage adapters
+through attach().  World 1 on the one GPU: the machinery (sinks, hooks, fused AdamW, accumulation callback) is the N > 1 one."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+class TinyLM(torch.nn.Module):
+    """projector -> 2 adapted decoder layers -> frozen head, MSE loss; takes the AVT mask list as batch columns."""
+
+    def __init__(self, dev, dtype=torch.bfloat16, seed=13):
+        super().__init__()
+        from moka_amd.decoder import LlamaDims, MokaLlamaStack
+        from moka_amd.peft_hyper import Linear
+        self.dims = LlamaDims(hidden=128, ff=256, n_heads=4, n_kv_heads=4)
+        torch.manual_seed(seed)
+
+        def make(d_in, d_out):
+            m = Linear(d_in, d_out, r=(8, 8, 8), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.0,
+                       loramethod="train", bias=False)
+            torch.nn.init.normal_(m.weight, std=0.05)
+            torch.nn.init.normal_(m.lora_B0.weight, std=0.05)
+            return m
+        self.vl_projector = torch.nn.Linear(40, self.dims.hidden)
+        self.model = MokaLlamaStack(self.dims, 2, make)
+        self.head = torch.nn.Linear(self.dims.hidden, 8)
+        self.to(dev, dtype).train()
+        for n, p in self.named_parameters():
+            p.requires_grad = ("lora_" in n) or n.startswith("vl_projector")
+
+    def forward(self, feats, target, m_t, m_v, m_a, m_q):
+        h = self.vl_projector(feats)
+        out, _ = self.model(h, [m_t, m_v, m_a, m_q])
+        loss = (self.head(out).float() - target.float()).square().mean()
+        return {"loss": loss}
+
+
+def _data(S=64, n=2):
+    g = torch.Generator().manual_seed(3)
+    tok = torch.zeros(n, S, dtype=torch.int64)
+    tok[:, 4:20] = 1
+    tok[:, 24:36] = 2
+    q = torch.zeros(n, S, dtype=torch.bool)
+    q[:, 40:50] = True
+    rows = []
+    for b in range(n):
+        rows.append({"feats": torch.randn(S, 40, generator=g).to(torch.bfloat16), "target": torch.randn(S, 8, generator=g),
+                     **{k: (tok[b] == m).to(torch.int32).unsqueeze(-1) for k, m in (("m_t", 0), ("m_v", 1), ("m_a", 2))},
+                     "m_q": q[b].to(torch.int32).unsqueeze(-1)})
+    return rows
+
+
+def _collate(rows):
+    return {k: torch.stack([r[k] for r in rows]) for k in rows[0]}
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_hf_trainer_drives_the_flat_optimizer(tmp_path, accum):
+    from transformers import Trainer, TrainingArguments
+    from moka_amd.parallel import MokaFlatOptimizer, attach, trainer_callback
+    dev = torch.device("cuda:0")
+    rows = _data(n=2 * accum)
+    steps, lr = 4, 2e-3
+    # ---- the hand-written loop: every optimizer step sees all rows (accum micro-batches of 2 rows)
+    ref = TinyLM(dev)
+    dp_r = attach(ref, n_buckets=2, lr=lr, weight_decay=0.0)
+    ref_losses = []
+    for _ in range(steps):
+        tot = 0.0
+        for k in range(accum):
+            batch = {kk: v.to(dev) for kk, v in _collate(rows[2 * k:2 * k + 2]).items()}
+            ctx = dp_r.no_sync() if k < accum - 1 else torch.enable_grad()
+            with ctx:
+                loss = ref(**batch)["loss"] / accum
+                loss.backward()
+            tot += float(loss)
+        dp_r.step(max_grad_norm=1.0)
+        ref_losses.append(tot)
+    torch.cuda.synchronize()
+    # ---- the same under transformers.Trainer
+    m = TinyLM(dev)
+    dp = attach(m, n_buckets=2, lr=lr, weight_decay=0.0)
+    opt = MokaFlatOptimizer(dp, lr=lr, max_grad_norm=1.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0)
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, gradient_accumulation_steps=accum, max_steps=steps,
+                             learning_rate=lr, max_grad_norm=0.0, report_to=[], save_strategy="no", logging_steps=1,
+                             remove_unused_columns=False, dataloader_pin_memory=False, seed=1, data_seed=1,
+                             dataloader_drop_last=False, disable_tqdm=True)
+
+    class Seq(Trainer):                                           # fixed row order (the comparison is against a fixed-order loop)
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    tr = Seq(model=m, args=args, train_dataset=rows, data_collator=_collate, optimizers=(opt, sched), callbacks=[trainer_callback(dp)])
+    tr.train()
+    torch.cuda.synchronize()
+    losses = [e["loss"] for e in tr.state.log_history if "loss" in e]
+    assert len(losses) == steps and losses[-1] < losses[0], losses
+    assert ref_losses[-1] < ref_losses[0]
+    assert dp.optimizer.t == steps and all(p.grad is None for p in m.parameters())
+    err = ((dp.master - dp_r.master).norm() / dp_r.master.norm()).item()
+    assert err <= 2e-4, err                                       # same arithmetic; atomics order and bf16 activations differ in the last bits
+    o = dp.offsets[dp.names.index("vl_projector.weight")]
+    w0 = TinyLM(dev).vl_projector.weight.float().reshape(-1)
+    assert (dp.master[o:o + w0.numel()] - w0).abs().max().item() > 1e-4          # the projector trained too
+
+
+def test_fp32_storage_adapters_through_attach_and_the_fused_step():
+    """The reference's adapters follow the base dtype (layer.py:124-132): an fp32 model under attach() -- parameters are views of
+    the fp32 master, the kernels add into the flat buffer, the fused AdamW updates them in place -- against torch.optim.AdamW on
+    the plain autograd gradients of an identical model."""
+    from moka_amd.parallel import attach
+    dev = torch.device("cuda:0")
+    rows = _data(n=2)
+    batch = {k: v.to(dev) for k, v in _collate(rows).items()}
+    batch["feats"] = batch["feats"].float()
+    a, b = TinyLM(dev, torch.float32), TinyLM(dev, torch.float32)
+    dp = attach(a, n_buckets=2, lr=1e-3, weight_decay=0.01)
+    opt_b = torch.optim.AdamW([p for p in b.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01, eps=1e-8)
+    for _ in range(3):
+        a(**batch)["loss"].backward()
+        dp.step()
+        b(**batch)["loss"].backward()
+        opt_b.step()
+        opt_b.zero_grad()
+    torch.cuda.synchronize()
+    pb = dict(b.named_parameters())
+    worst = 0.0
+    for n, p in a.named_parameters():
+        if p.requires_grad:
+            assert p.dtype == torch.float32 and p.grad is None
+            worst = max(worst, ((p.detach() - pb[n].detach()).norm() / pb[n].detach().norm().clamp_min(1e-20)).item())
+    assert worst <= 2e-4, worst
