@@ -312,3 +312,27 @@ def test_projector_in_front_of_the_stack_is_synchronised_with_the_adapter():
         g = flat[o:o + ref[n].numel()].view_as(ref[n])
         err = ((g - ref[n]).norm() / ref[n].norm().clamp_min(1e-20)).item()
         assert err <= (2e-2 if n in hooked else 6e-3), (n, err)          # the reference went through bf16 autograd gradients
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must BECOME two ranks (run as the driver runs it,
+    it used to measure one GPU and print n_gpus 1).  Two gloo ranks share the one GPU: functional, never a measurement."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MOKA_BENCH_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-traffic"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["dist_world_size"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert out["value"] > 0 and abs(out["value"] - 2 * out["tokens_per_s_per_gpu"]) <= 1e-3 * out["value"]
+    assert out["aggregate_tokens_per_s"] == out["value"] and out["comm_exposed_ms"] >= 0.0
+    assert out["roofline"]["frac"] > 0 and "where" in out["roofline"]
+    # asking for more ranks than devices over RCCL is a loud error, not a silent single-GPU run
+    env["MOKA_BENCH_BACKEND"] = "nccl"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--layers", "1",
+                          "--steps", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "GPU(s) visible" in (res.stderr + res.stdout)
