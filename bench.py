@@ -113,10 +113,10 @@ class Unit:
             "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
                                                         BwT, AT, G, r, w, c)),
             "moka_up_fwd": ("moka_up_fwd_group", (hp_tok, Bw, tm, y, T, r, do, G, 0)),
-            "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0)),
+            "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0, None)),
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                      drop_p, sd, 0)),
+                                                      drop_p, sd, 0, None)),
         }
         # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
         # per-projection definition: a group that reads x once is still credited G reads -- the roofline

@@ -15,7 +15,10 @@
  *   - all work is enqueued on `stream` (the caller's current stream); no internal
  *     synchronisation, no default-stream use, no persistent device allocations: workspaces
  *     are owned by the caller.  Entry points are re-entrant and stateless (activation
- *     checkpointing re-runs the forward inside backward) and capture into hipGraphs as they are.
+ *     checkpointing re-runs the forward inside backward) and capture into hipGraphs as they are:
+ *     the library keeps NO mutable state between calls -- per-call options travel in `moka_opts`
+ *     (the deterministic-mode workspace), launch-heuristic overrides exist only in the
+ *     diagnostics build (moka_tune).
  *   - token-major layouts: T = B*S flattened tokens, row-major, contiguous.
  *       x  [T, d_in]  bf16      y / gy [T, d_out] bf16      dx [T, d_in] bf16
  *       A_m [r, d_in] bf16 (lora_A{m}.weight / lora_A[name].weight)
@@ -66,7 +69,8 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      410            /* 0.4.1: *_kmj pack layout, moka_ksplit_bwd at rank pad 64 */
+#define MOKA_VERSION      500            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+                                            removed, moka_tune() only in the diagnostics build */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
@@ -94,15 +98,26 @@ typedef struct moka_routing {
                                  chunks of 64 with a running softmax; only moka_cross_ws_bytes() grows with it */
 } moka_routing;
 
+/* Per-call options of the backward entry points (NULL = defaults).  Plain data owned by the caller; nothing is retained
+ * after the call returns, so two trainers -- or two streams -- in one process never interact through the library. */
+typedef struct moka_opts {
+    void*  det_ws;      /* != NULL: deterministic weight gradients (see "deterministic weight gradients" below); 16-byte aligned,
+                           used by this call's launches on `stream` -- concurrent calls on other streams need their own */
+    size_t det_bytes;   /* >= moka_deterministic_ws_bytes(T, C_max, r, G, M) for this call, checked before anything is launched */
+} moka_opts;
+
 int         moka_version(void);
 const char* moka_last_error(void);
 /* 0 when a gfx950 device is current, MOKA_ENODEV otherwise. */
 int         moka_device_check(void);
 
-/* Diagnostic: override a launch heuristic ("expand_bpc", "expand_depth", "expand_nq", "wgrad_nw", "wgrad_ct", "wgrad_bpc",
+/* Diagnostics build only (-DMOKA_DIAGNOSTICS: `python -m moka_amd.build --diag` -> libmoka_hip_diag.so, loaded through
+ * MOKA_HIP_LIB): override a launch heuristic ("expand_bpc", "expand_depth", "expand_nq", "wgrad_nw", "wgrad_ct", "wgrad_bpc",
  * "gy_ng", "xa_ng", "xa_form"; value 0 restores the default).  Results never depend on it (set "xa_form" before sizing `part`:
- * moka_ksplit() follows it). */
+ * moka_ksplit() follows it).  This is process-wide mutable state, which is why the PRODUCT library does not have it: there
+ * moka_tune() returns MOKA_EINVAL and moka_diagnostics() returns 0. */
 int moka_tune(const char* key, int value);
+int moka_diagnostics(void);
 
 /* Padded rank-space row length (16, 32 or 64) for rank r (1..64); <0 if unsupported. */
 int moka_rank_pad(int r);
@@ -155,7 +170,7 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
  * halves of moka_down_bwd) -- each reads gy once. */
 int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8_t* tok_mod,
                 const float* s_out /*host, M floats*/, float* g_part, float* dB_acc,
-                int T, int r, int d_out, int M, int dtype, moka_stream_t stream);
+                int T, int r, int d_out, int M, int dtype, const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
 
 /* Backward of the cross-modal interaction: sums the ks partials of g (= dL/dhp), applies the
  * softmax backward for query rows and scatters the key/value gradients back onto the question
@@ -172,7 +187,7 @@ size_t moka_cross_ws_bytes(int B, int S, int Lk_max, int r);
 int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* AT /*from moka_cross_fwd*/,
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
                   void* dx_inout, int T, int d_in, int r, int M,
-                  float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream);
+                  float dropout_p, unsigned long long seed, int dtype, const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
 
 /* ---- grouped entry points (the decoder-layer shim) -------------------------------
  * G (1..MOKA_MAX_GROUP) adapted projections that are fed by the SAME input x -- q/k/v of the attention
@@ -200,14 +215,14 @@ int moka_up_fwd_group(const void* const* hp_tok, const void* const* Bw, const ui
                       int T, int r, const int* d_out, int G, int dtype, moka_stream_t stream);
 int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const void* const* BwT, const uint8_t* tok_mod,
                       const float* s_out, float* const* g_part, float* const* dB_acc,
-                      int T, int r, const int* d_out, int M, int G, int dtype, moka_stream_t stream);
+                      int T, int r, const int* d_out, int M, int G, int dtype, const moka_opts* opts, moka_stream_t stream);
 int moka_cross_bwd_group(const float* const* g_part, int ks, const float* const* h, const moka_routing* rt, float s_in,
                          float* const* dh /*NULL or [G]*/, void* const* dh_tok, void* const* dh_kmj,
                          void* const* ws /*G distinct workspaces*/, int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
 int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, const void* x, const void* const* AT,
                         const uint8_t* tok_mod, float* const* dA_acc /*[G*M] or NULL*/, void* dx_inout /*or NULL*/,
                         int T, int d_in, int r, int M, int G, float dropout_p, const unsigned long long* seeds,
-                        int dtype, moka_stream_t stream);
+                        int dtype, const moka_opts* opts, moka_stream_t stream);
 
 /* The keep mask (1 byte per element of x, 1 = kept) the kernels derive from (dropout_p, seed): lets a
  * checker replay a dropout run exactly.  moka_dropout_scale returns 1/(1-p') (see moka_down_fwd). */
@@ -217,12 +232,12 @@ float moka_dropout_scale(float dropout_p);
 /* ---- deterministic weight gradients -------------------------------------------------- */
 
 /* By default dA_m / dB are summed over token runs with fp32 atomics (last bits depend on the arrival order, relative spread
- * ~1e-7).  With a workspace set (per device, from any thread), the weight-gradient kernels write one partial tile per token run into it with
- * plain stores and a second small launch adds the runs in index order: bitwise reproducible, independent of scheduling (and of
- * how a batch was split into launches only as far as the runs coincide).  ws == NULL switches back.  The workspace is the
- * caller's (no persistent device allocation here); moka_deterministic_ws_bytes() is an upper bound for launches of up to G
- * projections of width <= C_max on T tokens; a workspace that is too small makes the entry point return MOKA_EINVAL. */
-int    moka_deterministic(void* ws, size_t bytes);
+ * ~1e-7).  A backward call that carries a workspace (moka_opts.det_ws) has its weight-gradient kernels write one partial tile per
+ * token run into it with plain stores, and a second small launch adds the runs in index order: bitwise reproducible, independent
+ * of scheduling (and of how a batch was split into launches only as far as the runs coincide).  The workspace is the caller's and
+ * is used only by that call's launches on that call's stream (give concurrent streams their own); moka_deterministic_ws_bytes()
+ * is the size a call on T tokens with up to G projections of width <= C_max needs; a workspace that is too small makes the entry
+ * point return MOKA_EINVAL before it launches anything. */
 size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M);
 
 /* ---- data-parallel step on the flat adapter buffers ---------------------------------- */

@@ -26,6 +26,11 @@ class MokaRoutingStruct(Structure):
                 ("B", c_int32), ("S", c_int32), ("Lk_max", c_int32), ("M", c_int32)]
 
 
+class MokaOpts(ctypes.Structure):
+    """moka_opts of include/moka_hip.h: per-call options of the backward entry points (the deterministic-mode workspace)."""
+    _fields_ = [("det_ws", c_void_p), ("det_bytes", ctypes.c_size_t)]
+
+
 class MokaError(RuntimeError):
     pass
 
@@ -38,6 +43,7 @@ SYMBOLS = {
     "moka_last_error": (c_char_p, []),
     "moka_device_check": (c_int, []),
     "moka_tune": (c_int, [c_char_p, c_int]),
+    "moka_diagnostics": (c_int, []),
     "moka_rank_pad": (c_int, [c_int]),
     "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),
@@ -51,16 +57,16 @@ SYMBOLS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
     # hp_tok, Bw, tok_mod, y, T, r, d_out, dtype, stream
     "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    # gy, hp_kmj, BwT, tok_mod, s_out[], g_part, dB_acc, T, r, d_out, M, dtype, stream
+    # gy, hp_kmj, BwT, tok_mod, s_out[], g_part, dB_acc, T, r, d_out, M, dtype, opts, stream
     "moka_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                            c_int, c_int, c_int, c_int, c_int, POINTER(MokaOpts), c_void_p]),
     # g_part, ks, h, rt, s_in, dh, dh_tok, dh_kmj, ws, r, w, c, stream
     "moka_cross_bwd": (c_int, [c_void_p, c_int, c_void_p, POINTER(MokaRoutingStruct), c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
     "moka_cross_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
-    # dh_tok, dh_kmj, x, AT, tok_mod, dA_acc[], dx, T, d_in, r, M, dropout_p, seed, dtype, stream
+    # dh_tok, dh_kmj, x, AT, tok_mod, dA_acc[], dx, T, d_in, r, M, dropout_p, seed, dtype, opts, stream
     "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p,
-                              c_int, c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
+                              c_int, c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_int, POINTER(MokaOpts), c_void_p]),
     # ---- grouped entry points (host arrays of G pointers)
     # x, A[G*M], tok_mod, part[G], T, d_in, r, M, G, s_in, dropout_p, seeds[G], dtype, stream
     "moka_down_fwd_group": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p),
@@ -73,21 +79,21 @@ SYMBOLS = {
     # hp_tok[G], Bw[G], tok_mod, y[G], T, r, d_out[G], G, dtype, stream
     "moka_up_fwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p),
                                   c_int, c_int, POINTER(c_int), c_int, c_int, c_void_p]),
-    # gy[G], hp_kmj[G], BwT[G], tok_mod, s_out[], g_part[G], dB_acc[G], T, r, d_out[G], M, G, dtype, stream
+    # gy[G], hp_kmj[G], BwT[G], tok_mod, s_out[], g_part[G], dB_acc[G], T, r, d_out[G], M, G, dtype, opts, stream
     "moka_up_bwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_float),
-                                  POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, POINTER(c_int), c_int, c_int, c_int, c_void_p]),
+                                  POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, POINTER(c_int), c_int, c_int, c_int,
+                                  POINTER(MokaOpts), c_void_p]),
     # g_part[G], ks, h[G], rt, s_in, dh[G], dh_tok[G], dh_kmj[G], ws[G], G, r, w, c, stream
     "moka_cross_bwd_group": (c_int, [POINTER(c_void_p), c_int, POINTER(c_void_p), POINTER(MokaRoutingStruct), c_float,
                                      POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                      c_int, c_int, c_float, c_float, c_void_p]),
-    # dh_tok[G], dh_kmj[G], x, AT[G], tok_mod, dA_acc[G*M], dx, T, d_in, r, M, G, dropout_p, seeds[G], dtype, stream
+    # dh_tok[G], dh_kmj[G], x, AT[G], tok_mod, dA_acc[G*M], dx, T, d_in, r, M, G, dropout_p, seeds[G], dtype, opts, stream
     "moka_down_bwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
                                     POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                    POINTER(ctypes.c_ulonglong), c_int, c_void_p]),
+                                    POINTER(ctypes.c_ulonglong), c_int, POINTER(MokaOpts), c_void_p]),
     # dropout_p, seed, T, d_in, keep_out, stream
     "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
     "moka_dropout_scale": (c_float, [c_float]),
-    "moka_deterministic": (c_int, [c_void_p, ctypes.c_size_t]),
     "moka_deterministic_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     # master, work_bf16, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream
     "moka_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
@@ -114,7 +120,7 @@ def load():
     for item in filter(None, os.environ.get("MOKA_TUNE", "").split(",")):
         key, _, val = item.partition("=")
         if lib.moka_tune(key.strip().encode(), int(val)) != 0:
-            raise MokaError(f"MOKA_TUNE: unknown key {key!r}")
+            raise MokaError("MOKA_TUNE: " + lib.moka_last_error().decode("utf-8", "replace"))
     _lib = lib
     return lib
 

@@ -2445,13 +2445,18 @@ static int current_device() {
     return dev;
 }
 
-// moka_deterministic(): workspace of the two-stage weight-gradient sums, one per device (set from any thread: PyTorch runs
-// the backward on its autograd thread; launches of one device are assumed to come from one thread at a time, as in training)
-struct DetSlot { float* ws; size_t bytes; };
-static DetSlot g_det_slots[16] = {};
+// Deterministic weight gradients: the workspace arrives WITH the call (moka_opts); these thread-locals only carry it from the entry
+// point to its launch helpers and are cleared when the entry point returns (DetScope) -- nothing outlives a call, nothing is shared
+// between threads, streams or devices.
+struct DetCall { float* ws; size_t bytes; };
+static thread_local DetCall t_det = {nullptr, 0};
 static thread_local size_t g_det_need = 0;              // set by a launcher that found the workspace too small
-#define g_det_ws (g_det_slots[current_device() & 15].ws)
-#define g_det_bytes (g_det_slots[current_device() & 15].bytes)
+#define g_det_ws (t_det.ws)
+#define g_det_bytes (t_det.bytes)
+struct DetScope {
+    explicit DetScope(const moka_opts* o) { t_det.ws = o ? (float*)o->det_ws : nullptr; t_det.bytes = (o && o->det_ws) ? o->det_bytes : 0; g_det_need = 0; }
+    ~DetScope() { t_det.ws = nullptr; t_det.bytes = 0; g_det_need = 0; }
+};
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -2467,7 +2472,7 @@ static int check_launch(const char* what) {
     if (g_det_need) {                                    // the launch ran on atomics: loud, because the caller asked for determinism
         const size_t need = g_det_need;
         g_det_need = 0;
-        return fail(MOKA_EINVAL, "%s: the moka_deterministic() workspace is too small: %zu bytes needed, %zu given", what, need, g_det_bytes);
+        return fail(MOKA_EINVAL, "%s: the deterministic-mode workspace (moka_opts.det_ws) is too small: %zu bytes needed, %zu given", what, need, g_det_bytes);
     }
     return MOKA_OK;
 }
@@ -2491,8 +2496,14 @@ static void ensure_lds(const void* kernel, size_t lds) {
     if (nslots < 160) { slots[nslots].k = kernel; slots[nslots].dev = dev; slots[nslots].granted = want; ++nslots; }
 }
 
-// Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.
+// Diagnostic launch-heuristic overrides (moka_tune); 0 = built-in default.  Process-wide mutable state, so it exists only in the
+// diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
+// in the product library these are compile-time zeros and moka_tune() refuses.
+#ifdef MOKA_DIAGNOSTICS
 static int g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+#else
+static constexpr int g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+#endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
     static thread_local int cached[16] = {0};
@@ -2899,18 +2910,21 @@ static bool f32_det(F32Args& a, int planes, int nruns, SumRunsArgs* sr) {
     return true;
 }
 
+extern "C" size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M);
+// the workspace of a deterministic call is validated BEFORE the first launch: a failure must not leave half-updated accumulators
+static int check_det_opts(const char* fn, const moka_opts* o, bool wants_wgrad, int T, int Cmax, int r, int G, int M) {
+    if (!o || !o->det_ws || !wants_wgrad) return MOKA_OK;
+    if ((uintptr_t)o->det_ws & 15) return fail(MOKA_EINVAL, "%s: moka_opts.det_ws must be 16-byte aligned", fn);
+    const size_t need = moka_deterministic_ws_bytes(T, Cmax, r, G, M);
+    if (need == 0 || o->det_bytes < need)
+        return fail(MOKA_EINVAL, "%s: the deterministic-mode workspace (moka_opts.det_ws) is too small: %zu bytes needed (moka_deterministic_ws_bytes), %zu given",
+                    fn, need, o->det_bytes);
+    return MOKA_OK;
+}
+
 extern "C" {
 
 int moka_version(void) { return MOKA_VERSION; }
-
-int moka_deterministic(void* ws, size_t bytes) {
-    if (ws && (((uintptr_t)ws & 15) || bytes < 16)) return fail(MOKA_EINVAL, "moka_deterministic: the workspace must be 16-byte aligned and non-empty");
-    DetSlot& slot = g_det_slots[current_device() & 15];
-    slot.ws = (float*)ws;
-    slot.bytes = ws ? bytes : 0;
-    g_det_need = 0;
-    return MOKA_OK;
-}
 
 size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M) {
     if (T < 1 || C_max < 32 || rank_pad(r) < 0 || G < 1 || G > MOKA_MAX_GROUP || M < 1 || M > MOKA_MAX_MOD) return 0;
@@ -2931,6 +2945,7 @@ int moka_device_check(void) {
 
 int moka_tune(const char* key, int value) {
     if (!key) return fail(MOKA_EINVAL, "moka_tune: null key");
+#ifdef MOKA_DIAGNOSTICS
     if (!strcmp(key, "wgrad_nw")) g_tune_wgrad_nw = value;
     else if (!strcmp(key, "gy_ng")) g_tune_gy_ng = value;
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
@@ -2942,8 +2957,19 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_bpc")) g_tune_wgrad_bpc = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
+#else
+    (void)value;
+    return fail(MOKA_EINVAL, "moka_tune(%s): launch-heuristic overrides exist only in the diagnostics build (python -m moka_amd.build --diag, "
+                "MOKA_HIP_LIB=.../libmoka_hip_diag.so); the product library keeps no mutable state", key);
+#endif
 }
-
+int moka_diagnostics(void) {
+#ifdef MOKA_DIAGNOSTICS
+    return 1;
+#else
+    return 0;
+#endif
+}
 int moka_rank_pad(int r) { return rank_pad(r); }
 int moka_tok_pad(int T) { return T < 0 ? MOKA_EINVAL : (T + 31) / 32 * 32; }
 
@@ -3147,10 +3173,11 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
 
 int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const void* const* BwT, const uint8_t* tok_mod,
                       const float* s_out, float* const* g_part, float* const* dB_acc,
-                      int T, int r, const int* d_out, int M, int G, int dtype, moka_stream_t stream) {
+                      int T, int r, const int* d_out, int M, int G, int dtype, const moka_opts* opts, moka_stream_t stream) {
     GROUP_CHECK("moka_up_bwd");
     if (!gy || !tok_mod || !s_out || !d_out) return fail(MOKA_EINVAL, "moka_up_bwd: null pointer");
     const int RP = rank_pad(r);
+    DetScope det_scope(opts);
     int Cmax = 0;
     for (int g = 0; g < G; ++g) {
         int rc = check_common("moka_up_bwd", T, d_out[g], r, M, dtype);
@@ -3160,6 +3187,7 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
             return fail(MOKA_EINVAL, "moka_up_bwd: an output must be requested for every projection of the group or for none");
         Cmax = d_out[g] > Cmax ? d_out[g] : Cmax;
     }
+    if (int drc = check_det_opts("moka_up_bwd", opts, dB_acc && dB_acc[0], T, Cmax, r, G, M)) return drc;   // before anything is launched
     int rc = MOKA_OK;
     if (dtype == MOKA_F32) {
         // slices of the widest projection of the group (moka_ksplit_bwd): narrower members leave their upper slices zero
@@ -3229,14 +3257,16 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
 }
 
 int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8_t* tok_mod, const float* s_out,
-                float* g_part, float* dB_acc, int T, int r, int d_out, int M, int dtype, moka_stream_t stream) {
-    return moka_up_bwd_group(&gy, &hp_kmj, &BwT, tok_mod, s_out, &g_part, &dB_acc, T, r, &d_out, M, 1, dtype, stream);
+                float* g_part, float* dB_acc, int T, int r, int d_out, int M, int dtype, const moka_opts* opts, moka_stream_t stream) {
+    return moka_up_bwd_group(&gy, &hp_kmj, &BwT, tok_mod, s_out, &g_part, &dB_acc, T, r, &d_out, M, 1, dtype, opts, stream);
 }
 
 int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, const void* x, const void* const* AT,
                         const uint8_t* tok_mod, float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M, int G,
-                        float dropout_p, const unsigned long long* seeds, int dtype, moka_stream_t stream) {
+                        float dropout_p, const unsigned long long* seeds, int dtype, const moka_opts* opts, moka_stream_t stream) {
     GROUP_CHECK("moka_down_bwd");
+    DetScope det_scope(opts);
+    if (int drc = check_det_opts("moka_down_bwd", opts, dA_acc != nullptr, T, d_in, r, G, M)) return drc;         // before anything is launched
     int rc = check_common("moka_down_bwd", T, d_in, r, M, dtype);
     if (rc) return rc;
     if (!tok_mod) return fail(MOKA_EINVAL, "moka_down_bwd: null pointer");
@@ -3333,9 +3363,9 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
 
 int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* AT, const uint8_t* tok_mod,
                   float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M,
-                  float dropout_p, unsigned long long seed, int dtype, moka_stream_t stream) {
+                  float dropout_p, unsigned long long seed, int dtype, const moka_opts* opts, moka_stream_t stream) {
     return moka_down_bwd_group(dh_tok ? &dh_tok : nullptr, dh_kmj ? &dh_kmj : nullptr, x, AT ? &AT : nullptr, tok_mod,
-                               dA_acc, dx_inout, T, d_in, r, M, 1, dropout_p, &seed, dtype, stream);
+                               dA_acc, dx_inout, T, d_in, r, M, 1, dropout_p, &seed, dtype, opts, stream);
 }
 
 int moka_dropout_mask(float dropout_p, unsigned long long seed, int T, int d_in, uint8_t* keep_out, moka_stream_t stream) {

@@ -119,7 +119,8 @@ def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: torch.Tensor,
     _lib.check(lib.moka_up_bwd(gy2.data_ptr(), None if hp_kmj is None else hp_kmj.data_ptr(), BwT.data_ptr(),
                                rt.tok_mod.data_ptr(), _floats(s_out), g_part.data_ptr(),
                                None if dB_acc is None else dB_acc.data_ptr(),
-                               T, r, d_out, len(s_out), dtype, _stream_ptr(gy2.device)), "moka_up_bwd")
+                               T, r, d_out, len(s_out), dtype, _det_opts(gy2.device, T, d_out, r, 1, len(s_out)) if dB_acc is not None else None,
+                               _stream_ptr(gy2.device)), "moka_up_bwd")
     return g_part
 
 
@@ -153,6 +154,7 @@ def down_bwd_(bst: BwdState, x2: torch.Tensor, AT: Optional[torch.Tensor], rt: M
                                  None if AT is None else AT.data_ptr(), rt.tok_mod.data_ptr(),
                                  None if dA_acc is None else _ptrs(dA_acc), None if dx2 is None else dx2.data_ptr(),
                                  T, d_in, r, rt.M, float(dropout_p), int(seed), dtype,
+                                 _det_opts(x2.device, T, d_in, r, 1, rt.M) if dA_acc is not None else None,
                                  _stream_ptr(x2.device)), "moka_down_bwd")
 
 
@@ -234,7 +236,9 @@ def up_bwd_group(gys: Sequence[torch.Tensor], hp_kmjs: Sequence[torch.Tensor], B
     g_parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=gys[0].device) for _ in range(G)]
     _lib.check(lib.moka_up_bwd_group(_ptrs(gys), _ptrs(hp_kmjs), _ptrs(BwTs), rt.tok_mod.data_ptr(), _floats(s_out),
                                      _ptrs(g_parts), None if dB_accs is None else _ptrs(dB_accs),
-                                     T, r, _ints(d_outs), len(s_out), G, _lib.MOKA_BF16, _stream_ptr(gys[0].device)),
+                                     T, r, _ints(d_outs), len(s_out), G, _lib.MOKA_BF16,
+                                     _det_opts(gys[0].device, T, max(d_outs), r, G, len(s_out)) if dB_accs is not None else None,
+                                     _stream_ptr(gys[0].device)),
                "moka_up_bwd_group")
     return g_parts
 
@@ -271,7 +275,8 @@ def down_bwd_group_(bsts: Sequence[BwdState], x2: torch.Tensor, ATs: Optional[Se
                                        None if ATs is None else _ptrs(ATs), rt.tok_mod.data_ptr(),
                                        None if dA_accs is None else _ptrs([a for Ag in dA_accs for a in Ag]),
                                        None if dx2 is None else dx2.data_ptr(), T, d_in, r, rt.M, G, float(dropout_p),
-                                       _u64s(seeds if seeds is not None else [0] * G), _lib.MOKA_BF16, _stream_ptr(x2.device)),
+                                       _u64s(seeds if seeds is not None else [0] * G), _lib.MOKA_BF16,
+                                       _det_opts(x2.device, T, d_in, r, G, rt.M) if dA_accs is not None else None, _stream_ptr(x2.device)),
                "moka_down_bwd_group")
 
 
@@ -290,27 +295,48 @@ def _token_scale(rt: MokaRouting, s_out: Sequence[float], device) -> torch.Tenso
     return lut[rt.tok_mod[:rt.T].long()]
 
 
-_DET_WS = {}
+# Deterministic mode is HOST-side state of this Python module: the library itself keeps none (the workspace travels with every
+# backward call as `moka_opts`).  One workspace per (device, stream): calls that run concurrently on two streams never share one.
+_DET_ON = {}            # device -> True
+_DET_WS = {}            # (device, stream handle) -> uint8 workspace tensor
 
 
 def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G: int = 3, M: int = 3, device=None) -> None:
-    """Bitwise-reproducible weight gradients (``moka_deterministic``): the dA_m / dB kernels write one partial tile per token
-    run into a workspace and a second launch adds the runs in order, instead of fp32 atomics.  The workspace (sized for
-    launches of up to G projections of width <= C_max on T tokens) is allocated here and kept alive; the setting is per
-    device (it also holds for the autograd thread that runs the backward)."""
-    lib = _lib.load()
-    if not enabled:
-        _lib.check(lib.moka_deterministic(None, 0), "moka_deterministic")
-        return
+    """Bitwise-reproducible weight gradients: the dA_m / dB kernels write one partial tile per token run into a workspace and a
+    second launch adds the runs in order, instead of fp32 atomics.  The setting is per device and lives here, not in the library;
+    the workspace of a call is sized for THAT call (``moka_deterministic_ws_bytes``), allocated on first use per stream, kept
+    alive and handed to the backward entry points through ``moka_opts``.  The size arguments are optional pre-allocation hints
+    for the current stream."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    n = int(lib.moka_deterministic_ws_bytes(int(T), int(C_max), int(r), int(G), int(M)))
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if not enabled:
+        _DET_ON.pop(dev, None)
+        for k in [k for k in _DET_WS if k[0] == dev]:
+            del _DET_WS[k]
+        return
+    _DET_ON[dev] = True
+    if T and C_max:
+        if _det_opts(dev, int(T), int(C_max), int(r), int(G), int(M)) is None:
+            raise ValueError("set_deterministic: bad T / C_max / r / G / M")
+
+
+def _det_opts(device, T: int, C_max: int, r: int, G: int, M: int):
+    """moka_opts of one backward call: None (atomics) unless set_deterministic is on for the device."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if not _DET_ON.get(dev):
+        return None
+    n = int(_lib.load().moka_deterministic_ws_bytes(int(T), int(C_max), int(r), int(G), int(M)))
     if n == 0:
-        raise ValueError("set_deterministic: bad T / C_max / r / G / M")
-    ws = _DET_WS.get(dev)
+        return None
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _DET_WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(n, dtype=torch.uint8, device=dev)
-        _DET_WS[dev] = ws
-    _lib.check(lib.moka_deterministic(ws.data_ptr(), ws.numel()), "moka_deterministic")
+        _DET_WS[key] = ws
+    return ctypes.byref(_lib.MokaOpts(ws.data_ptr(), ws.numel()))
 
 
 def draw_seed() -> int:

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_rank_pad(lib):
-    assert lib.moka_version() == 410
+    assert lib.moka_version() == 500
     assert [lib.moka_tok_pad(t) for t in (1, 32, 33)] == [32, 32, 64]
     assert [lib.moka_rank_pad(r) for r in (1, 4, 8, 16, 17, 32, 33, 64)] == [16, 16, 16, 16, 32, 32, 64, 64]
     assert lib.moka_rank_pad(0) < 0 and lib.moka_rank_pad(65) < 0
@@ -70,6 +70,31 @@ def test_argument_validation_sets_error_message(lib):
     # null pointer
     rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 0, None)
     assert rc == -1 and b"null" in lib.moka_last_error()
+
+
+def test_the_product_library_keeps_no_mutable_state(lib):
+    """VERDICT r02 item 8 / SURVEY 8(b): launch-heuristic overrides exist only in the diagnostics build, the deterministic-mode
+    workspace travels with the call (moka_opts) and is validated before anything is launched."""
+    from moka_amd import _lib, build
+    assert lib.moka_diagnostics() == 0
+    assert lib.moka_tune(b"xa_ng", 4) == -1 and b"diagnostics build" in lib.moka_last_error()
+    assert not hasattr(lib, "moka_deterministic")
+    diag = ctypes.CDLL(build.build(verbose=False, diag=True))
+    diag.moka_tune.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert diag.moka_diagnostics() == 1 and diag.moka_tune(b"xa_ng", 4) == 0 and diag.moka_tune(b"xa_ng", 0) == 0
+    assert diag.moka_tune(b"nope", 1) == -1
+    # a deterministic call with a workspace that is too small / misaligned fails on the host, before any launch
+    dummy = ctypes.c_void_p(64)
+    arr = (ctypes.c_void_p * 3)(64, 64, 64)
+    need = lib.moka_deterministic_ws_bytes(256, 64, 4, 1, 3)
+    assert need == 2 * 3 * 64 * 4 * 4
+    small = _lib.MokaOpts(4096, need - 16)
+    rc = lib.moka_down_bwd(dummy, dummy, dummy, dummy, dummy, arr, None, 256, 64, 4, 3, 0.0, 0, 0, ctypes.byref(small), None)
+    assert rc == -1 and b"too small" in lib.moka_last_error()
+    odd = _lib.MokaOpts(4100, need)
+    so = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
+    rc = lib.moka_up_bwd(dummy, dummy, dummy, dummy, so, None, dummy, 256, 4, 64, 3, 0, ctypes.byref(odd), None)
+    assert rc == -1 and b"aligned" in lib.moka_last_error()
 
 
 def test_no_gpu_means_loud_failure():

@@ -925,16 +925,34 @@ def test_deterministic_weight_gradients_are_bitwise_reproducible():
         for a, b, d in zip(g1, g2, base):
             assert torch.equal(a, b), (dtype, group)
             assert rel(a, d) < (1e-2 if dtype == torch.bfloat16 else 1e-5)      # bf16: the returned gradient is cast to bf16
-    # a workspace that is too small fails loudly
+    # a workspace that is too small fails loudly -- BEFORE anything is launched: the accumulators of the failed call are untouched
+    import ctypes
     from moka_amd import _lib
+    from moka_amd import functional as F
     lib = _lib.load()
+    T, d_out = c.B * c.S, c.d_out
     tiny = torch.empty(4096, dtype=torch.uint8, device=dev)
-    _lib.check(lib.moka_deterministic(tiny.data_ptr(), tiny.numel()), "moka_deterministic")
+    gyb = cd.gy.reshape(T, d_out).to(dev, torch.bfloat16).contiguous()
+    dB = torch.zeros(d_out, c.r, device=dev)
+    pk = torch.zeros(2 * _lib.rank_pad(c.r) * ((T + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+    so = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
+    rc = lib.moka_up_bwd(gyb.data_ptr(), pk.data_ptr(), None, torch.zeros(T + 128, dtype=torch.uint8, device=dev).data_ptr(), so, None,
+                         dB.data_ptr(), T, c.r, d_out, 3, 0, ctypes.byref(_lib.MokaOpts(tiny.data_ptr(), tiny.numel())),
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == -1 and b"too small" in lib.moka_last_error() and float(dB.abs().max()) == 0.0
+    # two streams in deterministic mode get a workspace each (one per device was a race)
+    set_deterministic(True)
     try:
-        with pytest.raises(_lib.MokaError, match="workspace is too small"):
-            run(torch.bfloat16, False)
+        side = torch.cuda.Stream()
+        F._det_opts(dev, T, d_out, c.r, 1, 3)
+        with torch.cuda.stream(side):
+            F._det_opts(dev, T, d_out, c.r, 1, 3)
+        keys = [k for k in F._DET_WS if k[0] == torch.device("cuda", torch.cuda.current_device())]
+        assert len(keys) == 2 and len({F._DET_WS[k].data_ptr() for k in keys}) == 2
     finally:
         set_deterministic(False)
+    assert not F._DET_WS
 
 
 @pytest.mark.parametrize("r", [32, 64])

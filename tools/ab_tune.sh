@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: ab_tune.sh "<bench args>" tune1 tune2 ...   ("none" = defaults): entry-point split of bench.py per MOKA_TUNE string
+# moka_tune lives in the diagnostics build only (the product library keeps no mutable state)
+export MOKA_HIP_LIB=${MOKA_HIP_LIB:-$PWD/moka_amd/libmoka_hip_diag.so}
 BARGS=$1; shift
 mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/abtune.log
 for t in "$@"; do

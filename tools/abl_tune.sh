@@ -1,5 +1,7 @@
 #!/bin/bash
 # rocprof kernel-trace averages of selected kernels under MOKA_TUNE settings.  usage: abl_tune.sh "<grep pattern>" <setting> [<setting> ...]
+# moka_tune lives in the diagnostics build only (the product library keeps no mutable state)
+export MOKA_HIP_LIB=${MOKA_HIP_LIB:-$PWD/moka_amd/libmoka_hip_diag.so}
 PAT=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for t in "$@"; do

@@ -1,6 +1,8 @@
 """Design probe: the batched y-expand (moka_up_fwd_group) and gy (moka_up_bwd_group) launches for members of different width
 (grouped-query k / v beside q: d_out 8192 / 1024 / 1024) against the same shapes launched alone, per expand_bpc setting.
 Run on the GPU box from the repo root."""
+import os as _os
+_os.environ.setdefault("MOKA_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "moka_amd", "libmoka_hip_diag.so"))   # moka_tune: diagnostics build only
 import math, os, sys, torch
 sys.path.insert(0, os.getcwd())
 import bench

@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("MOKA_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "moka_amd", "libmoka_hip_diag.so"))   # moka_tune: diagnostics build only
 #!/usr/bin/env python3
 """Time the grouped C entry points (q/k/v: G = 3 at 4096 -> 4096; gate/up: G = 2 at 4096 -> 11008) at the
 bench shape, each half separately.  Run on the GPU box; prints a table.  Env: B (sequences), DROP."""

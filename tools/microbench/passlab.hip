@@ -4,6 +4,7 @@
 // when the first / last wave of a launch starts relative to the end of its predecessor (boundary + ramp), how long the waves
 // live, how long the tail is.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include tools/microbench/passlab.hip -o passlab
 #define MOKA_TRACE
+#define MOKA_DIAGNOSTICS
 #include "../../moka_amd/csrc/moka_kernels.hip"
 #include "passlab_cand.h"
 #include "passlab_xa2.h"
@@ -167,16 +168,16 @@ static void seq_xa3(int set, int C) {
 }
 static void seq_gy(int set, int C) {
     rmw_front(set, 4096);
-    MK(moka_up_bwd(L.x[set], L.pack_kmj, L.BwT, L.tok_mod, S_OUT, L.part, L.dB, L.T, L.r, C, L.M, MOKA_BF16, 0));
+    MK(moka_up_bwd(L.x[set], L.pack_kmj, L.BwT, L.tok_mod, S_OUT, L.part, L.dB, L.T, L.r, C, L.M, MOKA_BF16, nullptr, 0));
 }
 static void seq_da(int set, int C) {
     rmw_front(set, 4096);
     float* dAp[3] = {L.dA[0], L.dA[1], L.dA[2]};
-    MK(moka_down_bwd(L.pack_tok, L.pack_kmj, L.x[set], L.AT, L.tok_mod, dAp, nullptr, L.T, C, L.r, L.M, DROP, SEED, MOKA_BF16, 0));
+    MK(moka_down_bwd(L.pack_tok, L.pack_kmj, L.x[set], L.AT, L.tok_mod, dAp, nullptr, L.T, C, L.r, L.M, DROP, SEED, MOKA_BF16, nullptr, 0));
 }
 static void seq_dx(int set, int C) {
     rmw_front(set, 4096);
-    MK(moka_down_bwd(L.pack_tok, L.pack_kmj, L.x[set], L.AT, L.tok_mod, nullptr, L.x[set], L.T, C, L.r, L.M, DROP, SEED, MOKA_BF16, 0));
+    MK(moka_down_bwd(L.pack_tok, L.pack_kmj, L.x[set], L.AT, L.tok_mod, nullptr, L.x[set], L.T, C, L.r, L.M, DROP, SEED, MOKA_BF16, nullptr, 0));
 }
 
 template <class F>

@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("MOKA_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "moka_amd", "libmoka_hip_diag.so"))   # moka_tune: diagnostics build only
 #!/usr/bin/env python3
 """Time every C entry point at the bench shape (T = 8192, Llama-2-7B widths, r = 16, M = 3) under
 different diagnostic tuning settings (moka_tune).  Run on the GPU box; prints a table."""
@@ -74,13 +76,13 @@ def main():
             "cross_fwd": lambda i: lib.moka_cross_fwd(w["part"].data_ptr(), _lib.ksplit(T, d_in, r), byref(rt.struct), so, w["Bw"].data_ptr(), d_out, Ap, d_in,
                                                       w["h"].data_ptr(), None, w["hp_tok"].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), w["AT"].data_ptr(), r, 1.0, c, sp()),
             "up_fwd": lambda i: lib.moka_up_fwd(w["hp_tok"].data_ptr(), w["Bw"].data_ptr(), tm, w["ys"][i % NBUF].data_ptr(), T, r, d_out, 0, sp()),
-            "up_bwd(g only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), None, T, r, d_out, M, 0, sp()),
-            "up_bwd(dB only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), None, tm, so, None, w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
-            "up_bwd(g+dB)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), w["dB"].data_ptr(), T, r, d_out, M, 0, sp()),
+            "up_bwd(g only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), None, T, r, d_out, M, 0, None, sp()),
+            "up_bwd(dB only)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), None, tm, so, None, w["dB"].data_ptr(), T, r, d_out, M, 0, None, sp()),
+            "up_bwd(g+dB)": lambda i: lib.moka_up_bwd(w["ys"][i % NBUF].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), tm, so, w["part"].data_ptr(), w["dB"].data_ptr(), T, r, d_out, M, 0, None, sp()),
             "cross_bwd": lambda i: lib.moka_cross_bwd(w["part"].data_ptr(), _lib.ksplit_bwd(T, d_out, r), w["h"].data_ptr(), byref(rt.struct), 1.0, None,
                                                       w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), rt.cross_ws(r).data_ptr(), r, 1.0, c, sp()),
-            "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, dAp, None, T, d_in, r, M, DROP, 1234, 0, sp()),
-            "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, DROP, 1234, 0, sp()),
+            "down_bwd(dA only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, dAp, None, T, d_in, r, M, DROP, 1234, 0, None, sp()),
+            "down_bwd(dx only)": lambda i: lib.moka_down_bwd(w["dh_tok"].data_ptr(), w["dh_kmj"].data_ptr(), w["xs"][i % NBUF].data_ptr(), w["AT"].data_ptr(), tm, None, w["dxs"][i % NBUF].data_ptr(), T, d_in, r, M, DROP, 1234, 0, None, sp()),
         }
 
     def timeit(fn, iters=24):
