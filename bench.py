@@ -82,7 +82,7 @@ class Unit:
     """The projections of one decoder layer that are fed by the same input (q/k/v; o; gate/up; down) with the
     ctypes argument lists of the six (grouped) entry points pre-built.  G = 1 is the per-projection path."""
 
-    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds):
+    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None):
         from moka_amd import _lib
         G = len(members)
         self.label, self.G, self.T = label, G, T
@@ -101,7 +101,8 @@ class Unit:
         part = P([scratch[g]["part"] for g in range(G)])
         hp_tok = P([scratch[g]["hp_tok"] for g in range(G)])
         dh_tok = P([scratch[g]["dh_tok"] for g in range(G)])
-        dh_kmj = P([scratch[g]["dh_kmj"] for g in range(G)])
+        # (--defer-da: the dA launches run a layer later, beside the next layer's chain: their operand packs cannot sit in the shared scratch)
+        dh_kmj = P([(own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]) for g in range(G)])
         ws = P([rt.cross_ws(r, g) for g in range(G)])
         so = (c_float * M)(*s_out)
         sd = (ctypes.c_ulonglong * G)(*seeds)
@@ -117,6 +118,12 @@ class Unit:
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
                                                       drop_p, sd, 0, None)),
+            # the two halves of moka_down_bwd as separate calls (either output may be NULL): dx stays on the dependency chain,
+            # dA_m is needed by the optimizer only
+            "moka_down_bwd:dx": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, None, dx.data_ptr(), T, self.d_in, r, M, G,
+                                                         drop_p, sd, 0, None)),
+            "moka_down_bwd:dA": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, None, T, self.d_in, r, M, G,
+                                                         drop_p, sd, 0, None)),
         }
         # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
         # per-projection definition: a group that reads x once is still credited G reads -- the roofline
@@ -215,6 +222,8 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                         dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
                    for _ in range(3)]
         units = []
+        defer = getattr(args, "defer_da", "off") != "off"
+        own = [[[torch.empty(M, 2, RP, Tp, dtype=bf, device=dev) for _ in pis] for _, pis in unit_defs] for _ in range(2)] if defer else None
         for l in range(L):
             acts, dacts, ys = sets[l % nset]
             members = []
@@ -226,7 +235,8 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                 mem = [members[pi] for pi in pis]
                 units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch,
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
-                                  [1000003 * l + pi + 7919 * 104729 * ci for pi in pis]))      # every chain its own dropout masks
+                                  [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
+                                  own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None))
         chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc))
         keep.append((sets, masks, scratch))
     return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], chains=chain_list, master=master, work=work,
@@ -280,16 +290,47 @@ def run_forward(lib, wl, sp, rec=None):
         _call(lib, "moka_up_fwd", u, sp, rec)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0):
-    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued."""
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None):
+    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
+    defer = (mode, main_stream, side_stream): the dA_m halves of a layer's moka_down_bwd calls leave the dependency chain (only the
+    optimizer needs them) and are enqueued after the layer's chain -- "main": on the same stream; "side": on a second stream,
+    beside the NEXT layer's chain (whose rank-space kernels leave most of the chip idle), joined before the gradients are used."""
     units, per = wl["units"], wl["units_per_layer"]
+    if defer is None:
+        for l in range(n_layers - 1, lo - 1, -1):
+            for u in reversed(units[l * per:(l + 1) * per]):
+                _call(lib, "moka_up_bwd", u, sp, rec)
+                _call(lib, "moka_cross_bwd", u, sp, rec)
+                _call(lib, "moka_down_bwd", u, sp, rec)
+            if on_layer_done is not None:
+                on_layer_done(l)
+        return
+    mode, main, side = defer
+    sps = c_void_p(side.cuda_stream)
+    done = {}                                                    # layer -> event "its deferred dA launches have finished" (side mode)
     for l in range(n_layers - 1, lo - 1, -1):
+        if mode == "side" and (l + 2) in done:
+            main.wait_event(done.pop(l + 2))                     # layer l reuses the pack buffers of layer l + 2
         for u in reversed(units[l * per:(l + 1) * per]):
             _call(lib, "moka_up_bwd", u, sp, rec)
             _call(lib, "moka_cross_bwd", u, sp, rec)
-            _call(lib, "moka_down_bwd", u, sp, rec)
+            _call(lib, "moka_down_bwd:dx", u, sp, None)
+        if mode == "main":
+            for u in reversed(units[l * per:(l + 1) * per]):
+                _call(lib, "moka_down_bwd:dA", u, sp, None)
+        else:
+            side.wait_stream(main)
+            for u in reversed(units[l * per:(l + 1) * per]):
+                _call(lib, "moka_down_bwd:dA", u, sps, None)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            done[l] = ev
         if on_layer_done is not None:
+            if mode == "side":
+                main.wait_event(done[l])                         # (a bucket must not ship before its dA has landed)
             on_layer_done(l)
+    if mode == "side":
+        main.wait_stream(side)
 
 
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
@@ -512,6 +553,9 @@ def main():
                          "are independent, and the fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide "
                          "behind the streaming kernels of the other.  Single GPU with --graph all only; per-kernel durations (`roofline`, "
                          "`kernels`) are then taken with the chains back to back on one stream")
+    ap.add_argument("--defer-da", choices=("off", "main", "side"), default="off",
+                    help="take the dA_m halves of moka_down_bwd off the dependency chain (only the optimizer needs them): main = enqueue them "
+                         "after the layer's chain on the same stream; side = on a second stream beside the next layer's chain (--graph all / off, 1 GPU)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -558,6 +602,8 @@ def main():
     lib = _lib.load()
     _lib.check(lib.moka_device_check(), "moka_device_check")
     from moka_amd.parallel import FlatGradBucket
+    if args.defer_da != "off" and (world > 1 or args.graph == "bwd" or args.chains > 1):
+        raise SystemExit("--defer-da: single GPU, --graph all or off, one chain")
     if args.chains > 1 and (world > 1 or args.graph != "all"):
         raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")
     wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None),
@@ -597,6 +643,7 @@ def main():
                 assert world == 1, "--graph all: single GPU only"
                 fwd_bwd_graph = torch.cuda.CUDAGraph()
                 branch = [torch.cuda.Stream(device=dev) for _ in range(args.chains - 1)]
+                da_side = torch.cuda.Stream(device=dev)
                 with torch.cuda.graph(fwd_bwd_graph, stream=side):
                     cur = torch.cuda.current_stream()
                     for st in branch:
@@ -605,7 +652,7 @@ def main():
                         with torch.cuda.stream(st):
                             spg = c_void_p(st.cuda_stream)
                             run_forward(lib, ch, spg)
-                            run_backward(lib, ch, spg, L)
+                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side) if args.defer_da != "off" else None)
                     for st in branch:
                         cur.wait_stream(st)          # join
             else:
@@ -629,6 +676,8 @@ def main():
     # N > 1: how long the main stream stands still in bucket.finish() (the part of the all-reduce the backward did not hide)
     comm_ev = [] if world > 1 else None
 
+    live_side = torch.cuda.Stream(device=dev) if args.defer_da == "side" else None
+
     def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
         if opt is None:
@@ -646,7 +695,8 @@ def main():
                     for l in range(hi - 1, lo - 1, -1):
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
-                run_backward(lib, wl, sp, L, bucket.layer_done, rec)   # all-reduce of finished layer groups overlaps the rest
+                run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
+                             defer=(args.defer_da, main_stream, live_side) if args.defer_da != "off" else None)
         if comm_ev is not None and i >= args.warmup:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)

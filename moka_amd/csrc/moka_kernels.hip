@@ -2125,6 +2125,149 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// F (r <= 16, the default since round 3): the first form's decomposition (block = 8 waves x 64 columns of one 512-column slice,
+// weight fragments of all modalities / projections resident, per-wave partials summed through LDS) with the x stream taken off the
+// VGPRs: a tile of 16 tokens x 512 columns travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), ONE ROW SEGMENT OF 1 KB PER WAVE
+// INSTRUCTION -- row-contiguous requests are what streamed best in the per-wave timelines (tools/microbench/passlab.hip: 14.7 us for a
+// cold 67 MB matrix against 16.7 us in 16-row x 64-byte fragment shape) -- into a ring of NS stages; the waves read their MFMA
+// fragments out of the stage (row pitch 1040 B: the 64 lanes of a ds_read_b128 spread evenly over the banks).  Nothing a wave has in
+// flight occupies registers, so the kernel keeps 2-3 workgroups per CU resident, and that, not the depth of the ring, is what
+// pays: ring 2 beat ring 3 / 4 / 6 everywhere (profiles/r03_passlab_xs.txt).  One LDS-only barrier per tile: "tile k has landed
+// everywhere and everybody is done with tile k-1" -- the partials of tile k-1 are summed (waves 0..3) behind it while all waves
+// already multiply tile k.  Every VMEM operation of the loop is issued unconditionally and waited for by count (the compiler does
+// not see the LDS-DMA requests): re-requests behind the run's end hit L2 and keep the count constant.
+// Measured in the kernel sequence of a training step (behind a 134 MB read-modify-write launch, T = 8192): o 22.3 -> 18.7 us,
+// q+k+v 47.1 -> 34.4, gate+up 29.1 -> 24.9, down 49.5 -> 47.7; bit-identical slices.  Precondition: T % 16 == 0 (else the first form).
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+template <int G, int NS>
+__global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RP = 16, RPITCH = 1040, STAGE = 16 * RPITCH;   // bytes; pitch 260 dwords: the 64 lanes of a ds_read_b128 spread evenly over the banks
+    constexpr int SLOT = 16 * RP;                                // floats per (wave, projection) partial tile
+    unsigned char* ring = smem;                                  // [NS][16 rows][RPITCH]
+    float* slots = (float*)(smem + NS * STAGE);                  // [2][8][G][SLOT]
+    unsigned char* smod = (unsigned char*)(slots + 2 * 8 * G * SLOT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    TRACE_DECL(0);
+    TRACE(0);
+    const int ntile_all = a.T >> 4;                              // (T % 16 == 0: the launcher's precondition)
+    const int t0 = blockIdx.y * tiles_per_block;
+    const int nt = min(tiles_per_block, ntile_all - t0);
+    if (nt <= 0) return;
+    const int cb0 = blockIdx.x * 512, c0 = cb0 + 64 * wave;
+    const bool wactive = c0 < a.C;
+    for (int e = tid; e < nt * 16; e += 512) smod[e] = a.tok_mod[t0 * 16 + e];
+
+    // producer side: wave w brings rows 2w and 2w+1 of every tile; lane l the 16 bytes at column cb0 + 8 l (clamped into the row)
+    const int ccol = min(cb0 + 8 * lane, a.C - 8);
+    const unsigned ring_base = (unsigned)(size_t)ring;
+    auto issue = [&](int tile) {
+        const int tl = min(tile, nt - 1);                        // past the run: re-request its last tile (L2 hit) -- every iteration issues the same count
+        const int st = tile % NS;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            const unsigned char* src = a.x + ((size_t)((t0 + tl) * 16 + row) * a.C + ccol) * 2;
+            glds16(src, __builtin_amdgcn_readfirstlane(ring_base + st * STAGE + row * RPITCH));
+        }
+    };
+    // weights: the fragments of my 64 columns, all modalities / projections, resident (loads the compiler does not track: explicit
+    // waits).  Requested FIRST (a wave's loads return in order and the weights are needed first), then the first NS-1 tiles.
+    bf16x8 wfr[G][MOKA_MAX_MOD][2];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = min(c0 + 32 * kk + 8 * g, a.C - 8);
+                const int mm = min(m, a.M - 1);
+                const unsigned char* src = a.A[gi][mm] + ((size_t)min(i, a.r - 1) * a.C + c) * 2;
+                wfr[gi][m][kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(wfr[gi][m][kk]) : "v"(src) : "memory");
+            }
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t);
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wfr[gi][m][kk]) : "n"(2 * (NS - 1)) : "memory");     // the weights have landed, the tiles are still on their way
+                if (m >= a.M || c0 + 32 * kk + 8 * g >= a.C) wfr[gi][m][kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto reduce = [&](int k) {                                   // waves 0..3: sum the eight waves' partials of tile k, write the slice rows
+        if (tid < 256) {
+            const float* buf = slots + (size_t)(k & 1) * 8 * G * SLOT;
+            const int tl = tid >> 4, kr = tid & 15;
+            const int t = (t0 + k) * 16 + tl;
+            const int mrw = smod[k * 16 + tl];
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum += buf[((size_t)w * G + gi) * SLOT + tid];
+                a.part[gi][((size_t)blockIdx.x * a.T + t) * RP + kr] = (mrw < a.M && kr < a.r) ? sum * mod_scale(a.s_mod, mrw) : 0.f;
+            }
+        }
+    };
+    for (int k = 0; k < nt; ++k) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(2 * (NS - 2)) : "memory");
+        if (k == 1) TRACE(1);
+        if (k > 0) reduce(k - 1);
+        issue(k + NS - 1);
+        const unsigned char* stg = ring + (k % NS) * STAGE;
+        bf16x8 xf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = *(const bf16x8*)(stg + i * RPITCH + 128 * wave + 64 * kk + 16 * g);
+        const int mrow = smod[k * 16 + i];
+        float* myslot = slots + ((size_t)(k & 1) * 8 + wave) * G * SLOT;
+        unsigned pm = 0;
+#pragma unroll
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (wactive && pm) {
+                bf16x8 xg[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    xg[kk] = xf[kk];
+                    if (a.drop[gi].thr) {
+                        const unsigned trow = (unsigned)((t0 + k) * 16 + i);
+                        xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 32 * kk) >> 3) + (unsigned)g));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MOKA_MAX_MOD; ++m) {
+                    if (!(pm & (1u << m))) continue;
+                    const bool other = (pm != (1u << m)) && mrow != m;
+                    acc = MFMA16(wfr[gi][m][0], other ? z8 : xg[0], acc);
+                    acc = MFMA16(wfr[gi][m][1], other ? z8 : xg[1], acc);
+                }
+            }
+            MFMA_SETTLE(acc);
+            *(f32x4*)(myslot + (size_t)gi * SLOT + i * RP + 4 * g) = acc;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    reduce(nt - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the dummy re-requests behind the run must land before the LDS is released)
+    TRACE(7);
+}
+
+
+// ------------------------------------------------------------------------------------------
 // F (second form): the same down-projection with INDEPENDENT waves.  Block = 8 waves on a [16 * sub_per_block tokens x KW
 // columns] tile (KW = 512, or 256 for rank pad 64); a wave takes whole 16-token sub-tiles (all KW columns of the slice), so its
 // [RP x 16] result is complete in its accumulators and goes straight to the split-K slice -- no per-wave partials in LDS, no
@@ -2844,6 +2987,20 @@ static void launch_xa_t(const XaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((moka_xa_kernel<RP, G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
 }
 
+template <int G>
+static int launch_xs(const XaArgs& a, hipStream_t st) {
+    constexpr int NS = 2;
+    const int ncb = (a.C + 511) / 512, ntile = a.T >> 4;
+    // tiles per workgroup: long runs amortise the resident weights (G x 6 KB per wave), short ones give more workgroups
+    int tpb = (G == 3) ? 16 : 8;
+    // (three projections: one workgroup of 16 tiles per CU beat two of 8 -- 34.4 vs 40.0 us -- their 18 KB of weights per wave are the start-up)
+    while (tpb > 2 && (long)ncb * ((ntile + tpb - 1) / tpb) < (G == 3 ? 1L : 2L) * num_cu()) tpb >>= 1;
+    const size_t lds = (size_t)NS * 16 * 1040 + (size_t)2 * 8 * G * 256 * 4 + (size_t)tpb * 16;
+    ensure_lds((const void*)moka_xs_kernel<G, NS>, lds);
+    hipLaunchKernelGGL((moka_xs_kernel<G, NS>), dim3(ncb, (ntile + tpb - 1) / tpb), dim3(512), lds, st, a, tpb);
+    return check_launch("moka_xs_kernel");
+}
+
 template <int RP, int G>
 static int launch_xw(const XaArgs& a, hipStream_t st) {
     constexpr int KW = (RP == 64) ? 256 : 512;               // LDS budget: M x G x RP/16 x KW/32 KB of weight fragments
@@ -3035,7 +3192,9 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             if (RP == 16) rc = G == 1 ? launch_xw<16, 1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xw<16, 2>(xa, (hipStream_t)stream) : launch_xw<16, 3>(xa, (hipStream_t)stream));
             else rc = RP == 32 ? launch_xw<32, 1>(xa, (hipStream_t)stream) : launch_xw<64, 1>(xa, (hipStream_t)stream);
         } else
-        if (RP == 16) rc = G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
+        if (RP == 16 && (T & 15) == 0 && g_tune_xa_form != 1)    // LDS-DMA ring (whole 16-token tiles; "xa_form" 1 forces the first form)
+            rc = G == 1 ? launch_xs<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xs<2>(xa, (hipStream_t)stream) : launch_xs<3>(xa, (hipStream_t)stream));
+        else if (RP == 16) rc = G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
         else rc = RP == 32 ? launch_xa_wide<32>(xa, (hipStream_t)stream) : launch_xa_wide<64>(xa, (hipStream_t)stream);
         if (rc) return rc;
     }

@@ -8,6 +8,7 @@
 #include "../../moka_amd/csrc/moka_kernels.hip"
 #include "passlab_cand.h"
 #include "passlab_xa2.h"
+#include "passlab_xs.h"
 
 #include <algorithm>
 #include <string>
@@ -152,9 +153,11 @@ static float DROP = 0.05f;
 // the sequences: a read-modify-write launch in front (its dirty lines are what the next launch starts behind), then the pass under test
 static void rmw_front(int set, int C) { MK(moka_up_fwd(L.pack_tok, L.Bw, L.tok_mod, L.y[set], L.T, L.r, C, MOKA_BF16, 0)); }
 static int XA2_NG = 0, XA2_DP = 0;                        // != 0: the xa2 candidate instead of the library's kernel
+static int XS_NS = 0, XS_TPB = 0;                          // != 0: the xs candidate (LDS-DMA ring)
 static void seq_xa(int set, int C) {
     rmw_front(set, 4096);
     const void* Ap[3] = {L.A[0], L.A[1], L.A[2]};
+    if (XS_NS) { float* pp[1] = {L.part}; lab_down_fwd_xs(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 1, 1.f, DROP, &SEED, XS_NS, XS_TPB); return; }
     if (XA2_NG) { float* pp[1] = {L.part}; lab_down_fwd_xa2(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 1, 1.f, DROP, &SEED, XA2_NG, XA2_DP); return; }
     MK(moka_down_fwd(L.x[set], Ap, L.tok_mod, L.part, L.T, C, L.r, L.M, 1.f, DROP, SEED, MOKA_BF16, 0));
 }
@@ -163,8 +166,17 @@ static void seq_xa3(int set, int C) {
     const void* Ap[9] = {L.A[0], L.A[1], L.A[2], L.A[0], L.A[1], L.A[2], L.A[0], L.A[1], L.A[2]};
     float* pp[3] = {L.part, L.part + (size_t)8 * L.T * 16, L.part + (size_t)16 * L.T * 16};
     const unsigned long long seeds[3] = {1, 2, 3};
+    if (XS_NS) { lab_down_fwd_xs(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 3, 1.f, DROP, DROP > 0 ? seeds : nullptr, XS_NS, XS_TPB); return; }
     if (XA2_NG) { lab_down_fwd_xa2(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 3, 1.f, DROP, DROP > 0 ? seeds : nullptr, XA2_NG, XA2_DP); return; }
     MK(moka_down_fwd_group(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 3, 1.f, DROP, DROP > 0 ? seeds : nullptr, MOKA_BF16, 0));
+}
+static void seq_xa2g(int set, int C) {
+    rmw_front(set, 4096);
+    const void* Ap[6] = {L.A[0], L.A[1], L.A[2], L.A[0], L.A[1], L.A[2]};
+    float* pp[2] = {L.part, L.part + (size_t)8 * L.T * 16};
+    const unsigned long long seeds[2] = {1, 2};
+    if (XS_NS) { lab_down_fwd_xs(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 2, 1.f, DROP, DROP > 0 ? seeds : nullptr, XS_NS, XS_TPB); return; }
+    MK(moka_down_fwd_group(L.x[set], Ap, L.tok_mod, pp, L.T, C, L.r, L.M, 2, 1.f, DROP, DROP > 0 ? seeds : nullptr, MOKA_BF16, 0));
 }
 static void seq_gy(int set, int C) {
     rmw_front(set, 4096);
@@ -250,6 +262,51 @@ int main(int argc, char** argv) {
         }
         XA2_NG = 0;
     }
+    if (what == "xs") {
+        auto snapshot = [&](int C, int G, std::vector<float>& out) {
+            CK(hipDeviceSynchronize());
+            out.resize((size_t)(G == 3 ? 24 : (C + 511) / 512) * L.T * 16);
+            CK(hipMemcpy(out.data(), L.part, out.size() * 4, hipMemcpyDeviceToHost));
+        };
+        struct Cfg { int ns, tpb; };
+        for (int C : {4096, 11008}) {
+            std::vector<float> ref, got;
+            CK(hipMemset(L.part, 0xff, (size_t)32 * L.T * 16 * 4));
+            XS_NS = 0; seq_xa(0, C); snapshot(C, 1, ref);
+            run("front + down_fwd (library)", seq_xa, C);
+            for (Cfg c : {Cfg{2, 4}, Cfg{2, 8}, Cfg{3, 4}, Cfg{3, 8}, Cfg{4, 8}}) {
+                CK(hipMemset(L.part, 0xff, (size_t)32 * L.T * 16 * 4));
+                XS_NS = c.ns; XS_TPB = c.tpb;
+                seq_xa(0, C); snapshot(C, 1, got);
+                size_t bad = 0; for (size_t k = 0; k < ref.size(); ++k) if (memcmp(&ref[k], &got[k], 4)) ++bad;
+                char t[128]; snprintf(t, sizeof(t), "front + down_fwd xs<ring %d, %d tiles per block> (mismatching words: %zu)", c.ns, c.tpb, bad);
+                run(t, seq_xa, C);
+            }
+            XS_NS = 0;
+        }
+        {
+            std::vector<float> ref, got;
+            CK(hipMemset(L.part, 0xff, (size_t)32 * L.T * 16 * 4));
+            XS_NS = 0; seq_xa3(0, 4096); snapshot(4096, 3, ref);
+            run("front + down_fwd_group[q+k+v] (library)", seq_xa3, 4096);
+            for (Cfg c : {Cfg{2, 8}, Cfg{2, 16}, Cfg{3, 8}, Cfg{3, 16}}) {
+                CK(hipMemset(L.part, 0xff, (size_t)32 * L.T * 16 * 4));
+                XS_NS = c.ns; XS_TPB = c.tpb;
+                seq_xa3(0, 4096); snapshot(4096, 3, got);
+                size_t bad = 0; for (size_t k = 0; k < ref.size(); ++k) if (memcmp(&ref[k], &got[k], 4)) ++bad;
+                char t[128]; snprintf(t, sizeof(t), "front + down_fwd_group[q+k+v] xs<ring %d, %d tiles per block> (mismatching words: %zu)", c.ns, c.tpb, bad);
+                run(t, seq_xa3, 4096);
+            }
+            XS_NS = 0;
+            run("front + down_fwd_group[gate+up] (library)", seq_xa2g, 4096);
+            for (Cfg c : {Cfg{2, 8}, Cfg{3, 8}, Cfg{3, 16}}) {
+                XS_NS = c.ns; XS_TPB = c.tpb;
+                char t[128]; snprintf(t, sizeof(t), "front + down_fwd_group[gate+up] xs<ring %d, %d tiles per block>", c.ns, c.tpb);
+                run(t, seq_xa2g, 4096);
+            }
+            XS_NS = 0;
+        }
+    }
     if (what == "front") {
         struct Cf { int depth, bpc; };
         for (Cf c : {Cf{0, 0}, Cf{3, 0}, Cf{3, 1}, Cf{0, 4}})
@@ -262,9 +319,9 @@ int main(int argc, char** argv) {
     }
     if (what == "abl") {
         XA2_NG = 4; XA2_DP = 2;
-        for (int abl : {0, 1, 2, 4, 6, 7, 8, 16}) {
+        for (int abl : {0, 2, 32, 64, 96, 128, 256, 480}) {
             g_lab_xa_abl = abl;
-            char t[160]; snprintf(t, sizeof(t), "front + down_fwd xa2<4,2> ablation %d (1 no weights, 2 no dropout / MFMA, 4 no reduction, 8 barrier only, 16 no store)", abl);
+            char t[160]; snprintf(t, sizeof(t), "front + down_fwd xa2<4,2> ablation %d (1 no weights, 2 no dropout / MFMA, 4 no reduction, 8 barrier only, 16 no store, 32 no settle, 64 no MFMA, 128 no slot write, 256 no votes)", abl);
             run(t, seq_xa, 4096);
         }
         g_lab_xa_abl = 0; XA2_NG = 0;

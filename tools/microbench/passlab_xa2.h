@@ -84,8 +84,11 @@ __global__ void __launch_bounds__(512) moka_xa2_kernel(const XaArgs a) {
                 if ((ABL & 2) && live) { acc[0][0] = __builtin_bit_cast(float, (int)(Fd[st][0][0] ^ Fd[st][1][1])); }
                 if (!(ABL & 2) && live) {
                     unsigned pm = 0;
+                    if (ABL & 256) pm = 1u;
+                    else {
 #pragma unroll
                     for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrd[st] == m)) pm |= 1u << m;
+                    }
                     bf16x8 xg[2];
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
@@ -103,15 +106,18 @@ __global__ void __launch_bounds__(512) moka_xa2_kernel(const XaArgs a) {
                         const bf16x8 x1 = (other || c0 + 32 >= a.C) ? z8 : xg[1];   // branch-free second K step (see moka_xa_kernel)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
+                            if (ABL & 64) { acc[nt][0] += __builtin_bit_cast(float, (int)(x0[0] ^ x1[1] ^ wfr[gi][m][0][nt][0])); }
+                            else {
                             acc[nt] = MFMA16(wfr[gi][m][0][nt], x0, acc[nt]);
                             acc[nt] = MFMA16(wfr[gi][m][1][nt], x1, acc[nt]);
+                            }
                         }
                     }
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    MFMA_SETTLE(acc[nt]);
-                    *(f32x4*)(slot + (16 * st + i) * RP + nt * 16 + 4 * g) = acc[nt];      // [token][rank]: ranks 4g..4g+3 of token i
+                    if (!(ABL & 32)) MFMA_SETTLE(acc[nt]);
+                    if (!(ABL & 128) || acc[nt][1] == 1234.5f) *(f32x4*)(slot + (16 * st + i) * RP + nt * 16 + 4 * g) = acc[nt];      // [token][rank]: ranks 4g..4g+3 of token i
                 }
             }
         }
@@ -175,6 +181,12 @@ static void lab_launch_xa2(const XaArgs& a, int ng, int dp) {
             case 6: lab_launch_xa2_t<1, 4, 2, 6>(a); break;
             case 7: lab_launch_xa2_t<1, 4, 2, 7>(a); break;
             case 8: lab_launch_xa2_t<1, 4, 2, 8>(a); break;
+            case 32: lab_launch_xa2_t<1, 4, 2, 32>(a); break;
+            case 64: lab_launch_xa2_t<1, 4, 2, 64>(a); break;
+            case 96: lab_launch_xa2_t<1, 4, 2, 96>(a); break;
+            case 128: lab_launch_xa2_t<1, 4, 2, 128>(a); break;
+            case 256: lab_launch_xa2_t<1, 4, 2, 256>(a); break;
+            case 480: lab_launch_xa2_t<1, 4, 2, 480>(a); break;
             default: lab_launch_xa2_t<1, 4, 2, 16>(a); break;
         }
         return;
