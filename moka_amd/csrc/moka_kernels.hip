@@ -206,6 +206,15 @@ static __device__ __forceinline__ const unsigned short* kmj_frag(const unsigned 
     return pack + (((size_t)plane * (RP / 16) + nt) * (size_t)(Tp >> 5) + (size_t)grp) * 512 + (lane << 3);
 }
 
+// LDS-DMA: 16 bytes per lane straight from global memory into LDS at (wave-uniform base) + 16 * lane, no VGPR in between.  M0 carries
+// the base and is compiler-reserved: it is written in the same statement that reads it and restored.  The request counts in vmcnt
+// like a load, but the compiler does not see it: kernels that use it wait by explicit count.
+static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
 static __device__ __forceinline__ float mod_scale(const float* s_mod, int m) {
     float sc = 0.f;
     if (m == 0) sc = s_mod[0]; else if (m == 1) sc = s_mod[1]; else if (m == 2) sc = s_mod[2];
@@ -1968,6 +1977,162 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Y (r <= 16, the default since round 3): the same two contractions over ONE pass of gy, with the tile streamed HBM -> LDS by
+// LDS-DMA exactly as in moka_xs_kernel (one 1 KB row segment per wave instruction, ring of two stages of 32 tokens x 512 columns,
+// nothing in flight occupies registers, two workgroups per CU).  Taking both operand shapes out of the SAME LDS tile removes what
+// the first form paid per group: the g contraction reads row-major 16-byte fragments (wave (h, q): tokens 16h.., columns 128q..:
+// four K steps, so only four waves' partials meet per token half instead of eight), the dB contraction reads the tile transposed
+// (ds_read_b64_tr_b16) where it lies -- no VGPR -> LDS copy -- and the hp pack fragments of the group, which every one of the eight
+// waves used to fetch from L2 for itself (half as many bytes as the gy tile again), arrive once per workgroup by two more DMA
+// requests.  Two LDS-only barriers per 32-token tile ("tile k is in" / "the partials of tile k are in").
+// ------------------------------------------------------------------------------------------
+template <bool WITH_DB, bool DET>
+__global__ void __launch_bounds__(512) moka_gs_kernel(const GyBatch ab, int NG) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RP = 16, RPITCH = 1040, STAGE = 32 * RPITCH;
+    unsigned char* ring = smem;                                  // [2][32 rows][RPITCH]
+    float* slots = (float*)(smem + 2 * STAGE);                   // [8 waves][16 tokens][16 ranks]
+    unsigned char* pk = (unsigned char*)(slots + 8 * 256);       // [2][hi 1 KB | lo 1 KB]   (WITH_DB)
+    unsigned char* smod = pk + (WITH_DB ? 4096 : 0);             // [2][32] routing bytes of the tile in each stage
+    int zi = 0, xb = blockIdx.x;
+    while (zi + 1 < MOKA_MAX_GROUP && xb >= ab.xend[zi]) ++zi;
+    if (zi) xb -= ab.xend[zi - 1];
+    const GyArgs& a = ab.z[zi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    TRACE_DECL(1);
+    TRACE(0);
+    const int ngroups = a.Tp >> 5;
+    const int cb0 = xb * 512;
+    float* slice = a.g_part + (size_t)xb * a.T * RP;
+    const int grp0 = blockIdx.y * NG;                            // my tiles: groups grp0 .. grp0 + NG - 1
+    if (grp0 >= ngroups) return;
+    if (cb0 >= a.C) {                                            // the one extra block of a narrower member: zero its unwritten slices for my token run
+        const int g0 = grp0, gn = min(NG, ngroups - grp0);
+        for (int sl = xb; sl < ab.ncb_max; ++sl) {
+            float* zs = a.g_part + (size_t)sl * a.T * RP;
+            for (int e = tid; e < gn * 32 * RP / 4; e += 512) {
+                const int t = g0 * 32 + (4 * e) / RP;
+                if (t < a.T) *(f32x4*)(zs + (size_t)t * RP + (4 * e) % RP) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        return;
+    }
+    auto group_of = [&](int j) -> int {                          // group of my j-th tile, -1 behind the end
+        return (j < NG && grp0 + j < ngroups) ? grp0 + j : -1;
+    };
+
+    // producer: wave w brings rows 4w .. 4w+3 of a tile (lane l the 16 bytes at column cb0 + 8 l, clamped into the row); waves 0 / 1
+    // also the hi / lo fragments of the group's hp pack (1 KB each, already in lane order); threads 0..31 its routing bytes
+    const int ccol = min(cb0 + 8 * lane, a.C - 8);
+    const unsigned ring_base = (unsigned)(size_t)ring, pk_base = (unsigned)(size_t)pk;
+    int mnext = MOKA_MOD_NONE;
+    auto issue = [&](int j, int grp) {
+        const int st = j & 1;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * wave + rr;
+            const unsigned char* src = a.gy + ((size_t)min(grp * 32 + row, a.T - 1) * a.C + ccol) * 2;
+            glds16(src, __builtin_amdgcn_readfirstlane(ring_base + st * STAGE + row * RPITCH));
+        }
+        if (WITH_DB && wave < 2) {
+            const unsigned short* ph = kmj_frag<RP>(a.pack, 0, 0, grp, a.Tp, lane) + (wave ? (size_t)RP * a.Tp : 0);
+            glds16(ph, __builtin_amdgcn_readfirstlane(pk_base + st * 2048 + wave * 1024));
+        }
+        if (tid < 32) mnext = a.tok_mod[grp * 32 + tid];          // (padded past T with MOKA_MOD_NONE)
+    };
+    // weights of the g contraction: wave (h, q) multiplies tokens 16h .. 16h+15 by columns cb0 + 128q .. +127 (four K steps)
+    const int h = wave >> 2, q = wave & 3;
+    bf16x8 bw[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = min(cb0 + 128 * q + 32 * ks + 8 * g, a.C - 8);
+        const unsigned char* src = a.BwT + ((size_t)i * a.C + c) * 2;
+        bw[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(bw[ks]) : "v"(src) : "memory");
+    }
+    const int first = group_of(0);
+    if (first >= 0) issue(0, first);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bw[ks]) : : "memory");      // (start-up: the weights and the first tile)
+        if (cb0 + 128 * q + 32 * ks + 8 * g >= a.C) bw[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const int c0 = cb0 + 64 * wave;                              // my 64 columns of the dB contraction
+    const bool dbactive = WITH_DB && c0 < a.C;
+    f32x4 accW[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) accW[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k = 0;; ++k) {
+        // tile k is in (every VMEM operation of mine has completed); its routing bytes go to LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < 32) smod[(k & 1) * 32 + tid] = (unsigned char)mnext;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // ... and everybody is done with tile k-1
+        if (k == 1) TRACE(1);
+        const int gk = group_of(k);
+        if (gk < 0) break;                                       // (block uniform)
+        const int gn = group_of(k + 1);
+        if (gn >= 0) issue(k + 1, gn);
+        const unsigned char* stg = ring + (k & 1) * STAGE;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 xf = *(const bf16x8*)(stg + (16 * h + i) * RPITCH + (128 * q + 32 * ks + 8 * g) * 2);
+            acc = MFMA16(bw[ks], xf, acc);                       // D^T: lane (token i, ranks 4g .. 4g+3)
+        }
+        MFMA_SETTLE(acc);
+        *(f32x4*)(slots + wave * 256 + i * RP + 4 * g) = acc;
+        if (dbactive) {
+            const bf16x8 bh = *(const bf16x8*)(pk + (k & 1) * 2048 + lane * 16);
+            const bf16x8 bl = *(const bf16x8*)(pk + (k & 1) * 2048 + 1024 + lane * 16);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const unsigned char* base = stg + (4 * g + (i >> 2)) * RPITCH + (64 * wave + ct * 16 + 4 * (i & 3)) * 2;
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * RPITCH));
+                const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                accW[ct] = MFMA16(av, bh, accW[ct]);
+                accW[ct] = MFMA16(av, bl, accW[ct]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        // the partials of tile k are in
+        {
+            const int tl = tid >> 4, kr = tid & 15, hh = tl >> 4;
+            float sum = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) sum += slots[(4 * hh + qq) * 256 + (tl & 15) * RP + kr];
+            const int t = gk * 32 + tl;
+            if (t < a.T) {
+                const int mr = smod[(k & 1) * 32 + tl];
+                slice[(size_t)t * RP + kr] = (mr < a.M) ? sum * mod_scale(a.s_mod, mr) : 0.f;
+            }
+        }
+    }
+    TRACE(6);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the re-requests behind the run have landed: the ring is free)
+    if (WITH_DB) {
+        // dB leaves as [column][rank] rows: wave w's accumulators hold its 64 columns, disjoint from the other waves' -- a wave-private
+        // transposition through (its 4 KB of) the idle ring, then coalesced fp32 atomics (DET: plain stores of the run's partial tile)
+        float* mine = (float*)(ring + wave * 4096);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) mine[(ct * 16 + 4 * g + reg) * RP + i] = accW[ct][reg];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int e = lane; e < 64 * RP; e += 64) {
+            const int cl = e / RP, kk = e % RP;
+            const int c = c0 + cl;
+            if (c < a.C && kk < a.r) {
+                if (DET) a.det[((size_t)blockIdx.y * a.det_planes + zi) * a.det_stride + (size_t)c * a.r + kk] = mine[cl * RP + kk];
+                else atomicAdd(a.dB + (size_t)c * a.r + kk, mine[cl * RP + kk]);
+            }
+        }
+    }
+    TRACE(7);
+}
+
+// ------------------------------------------------------------------------------------------
 // F: down-projection for r <= 16 in the same block shape as the gy kernel:
 //      part_g[cb][t][k] = s_in * sum_{c in column block cb} drop_g(x)[t][c] A_{g,mod(t)}[k][c]
 // ------------------------------------------------------------------------------------------
@@ -2139,11 +2304,6 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
 // Measured in the kernel sequence of a training step (behind a 134 MB read-modify-write launch, T = 8192): o 22.3 -> 18.7 us,
 // q+k+v 47.1 -> 34.4, gate+up 29.1 -> 24.9, down 49.5 -> 47.7; bit-identical slices.  Precondition: T % 16 == 0 (else the first form).
 // ------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-}
 
 template <int G, int NS>
 __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_per_block) {
@@ -2643,9 +2803,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static int g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
 #else
-static constexpr int g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static constexpr int g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -2938,9 +3098,66 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
     }
 }
 
+// LDS-DMA form (r <= 16): same grid map, slices and deterministic-mode plumbing as launch_gy_t
+template <bool WITH_DB>
+static void launch_gs_t(const GyBatch& gb, int nz, int ncb, int ng, hipStream_t st) {
+    const int ngroups = gb.z[0].Tp >> 5;
+    const size_t lds = (size_t)2 * 32 * 1040 + 8 * 256 * 4 + (WITH_DB ? 4096 : 0) + 64;
+    GyBatch& gx = const_cast<GyBatch&>(gb);
+    int xtot = 0;
+    for (int z = 0; z < MOKA_MAX_GROUP; ++z) {
+        if (z < nz) {
+            const int nact = (gb.z[z].C + 511) / 512;
+            xtot += nact + (nact < ncb ? 1 : 0);
+        }
+        gx.xend[z] = xtot;
+    }
+    gx.ncb_max = ncb;
+    SumRunsArgs sr;
+    bool det = false;
+    const int ntb_static = (ngroups + ng - 1) / ng;
+    if (WITH_DB && g_det_ws) {
+        size_t stride = 0;
+        for (int z = 0; z < nz; ++z) stride = (size_t)gb.z[z].C * gb.z[z].r > stride ? (size_t)gb.z[z].C * gb.z[z].r : stride;
+        const size_t need = (size_t)ntb_static * nz * stride * 4;
+        if (need > g_det_bytes) g_det_need = need;
+        else {
+            det = true;
+            memset(&sr, 0, sizeof(sr));
+            sr.det = g_det_ws; sr.nruns = ntb_static; sr.planes = nz; sr.stride = stride;
+            for (int z = 0; z < nz; ++z) { gx.z[z].det = g_det_ws; gx.z[z].det_planes = nz; gx.z[z].det_stride = stride; sr.acc[z] = gx.z[z].dB; sr.n[z] = (size_t)gx.z[z].C * gx.z[z].r; }
+        }
+    }
+    if (det) {
+        ensure_lds((const void*)moka_gs_kernel<WITH_DB, WITH_DB>, lds);
+        hipLaunchKernelGGL((moka_gs_kernel<WITH_DB, WITH_DB>), dim3(xtot, ntb_static, 1), dim3(512), lds, st, gb, ng);
+        det_finish(sr, st);
+    } else {
+        ensure_lds((const void*)moka_gs_kernel<WITH_DB, false>, lds);
+        hipLaunchKernelGGL((moka_gs_kernel<WITH_DB, false>), dim3(xtot, ntb_static, 1), dim3(512), lds, st, gb, ng);
+    }
+}
+
 template <int RP, bool WITH_DB>
 static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) {
     GyBatch gb = gb_in;                                  // (launch_gy_t fills in the grid map)
+    if constexpr (RP == 16) {
+        // LDS-DMA ring, except for the widest batches (gate + up, 2 x 11008: 97.5 against 92.8 us for the first form in the step's kernel
+        // sequence; o / down 26.3 against 27.9, q + k + v 54 against 58); "gy_form" 1 / 2 forces the first / second form
+        if (g_tune_gy_form == 2 || (g_tune_gy_form == 0 && !(nz > 1 && Cmax > 8192))) {
+            const int ngroups = gb.z[0].Tp >> 5;
+            long active = 0;
+            for (int z = 0; z < nz; ++z) active += (gb.z[z].C + 511) / 512;
+            // token groups per workgroup: long runs keep the dB atomics (and the start-ups) down, as long as every CU still gets a workgroup
+            // (T = 8192, kernel sequence of a step: 4096 wide 4 / 8 / 16 groups -> 28.7 / 24.6 / 27.8 us, 11008 wide 64.1 / 58.8 / 51.0 us)
+            auto blocks = [&](int n) { return active * ((ngroups + n - 1) / n); };
+            int ng = (4 * blocks(16) >= 5L * num_cu()) ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
+            while (ng > 2 && blocks(ng) < (long)num_cu() / 2) ng >>= 1;
+            if (g_tune_gy_ng > 0) ng = g_tune_gy_ng;
+            launch_gs_t<WITH_DB>(gb, nz, (Cmax + 511) / 512, ng, st);
+            return check_launch("moka_gs_kernel");
+        }
+    }
     if constexpr (RP == 64 && !WITH_DB) {
         // rank pad 64: 128 columns per wave, one split-K slice per 1024 columns (bwd_kw): the rank-space backward reads half as many
         // slices (7.2 -> 6.3 ms per step); this pass itself is unchanged (150-166 VGPRs leave one block per CU where 95 left two,
@@ -3108,6 +3325,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
     else if (!strcmp(key, "xa_ng")) g_tune_xa_ng = value;
     else if (!strcmp(key, "xa_form")) g_tune_xa_form = value;
+    else if (!strcmp(key, "gy_form")) g_tune_gy_form = value;
     else if (!strcmp(key, "expand_nq")) g_tune_expand_nq = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;

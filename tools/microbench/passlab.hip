@@ -307,6 +307,31 @@ int main(int argc, char** argv) {
             XS_NS = 0;
         }
     }
+    if (what == "gs") {
+        // LDS-DMA form of the gy pass against the first form: g_part / dB within fp32 summation-order noise, then the timelines
+        auto snap = [&](int C, std::vector<float>& gp, std::vector<float>& db) {
+            CK(hipDeviceSynchronize());
+            gp.resize((size_t)((C + 511) / 512) * L.T * 16); db.resize((size_t)C * 16);
+            CK(hipMemcpy(gp.data(), L.part, gp.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(db.data(), L.dB, db.size() * 4, hipMemcpyDeviceToHost));
+        };
+        auto relerr = [](const std::vector<float>& a, const std::vector<float>& b) { double d = 0, n = 0; for (size_t k = 0; k < a.size(); ++k) { d += (double)(a[k] - b[k]) * (a[k] - b[k]); n += (double)b[k] * b[k]; } return sqrt(d / (n > 0 ? n : 1)); };
+        for (int C : {4096, 11008}) {
+            std::vector<float> g0, d0, g1, d1;
+            moka_tune("gy_form", 1); moka_tune("gy_ng", 0);
+            CK(hipMemset(L.dB, 0, 16 * L.cmax * 4)); CK(hipMemset(L.part, 0, (size_t)32 * L.T * 16 * 4));
+            seq_gy(0, C); snap(C, g0, d0);
+            run("front + up_bwd (first form)", seq_gy, C);
+            for (int ng : {4, 8, 16}) {
+                moka_tune("gy_form", 0); moka_tune("gy_ng", ng);
+                CK(hipMemset(L.dB, 0, 16 * L.cmax * 4)); CK(hipMemset(L.part, 0, (size_t)32 * L.T * 16 * 4));
+                seq_gy(0, C); snap(C, g1, d1);
+                char t[160]; snprintf(t, sizeof(t), "front + up_bwd gs<%d groups per workgroup> (rel. diff g_part %.2e, dB %.2e)", ng, relerr(g1, g0), relerr(d1, d0));
+                run(t, seq_gy, C);
+            }
+        }
+        moka_tune("gy_form", 0); moka_tune("gy_ng", 0);
+    }
     if (what == "front") {
         struct Cf { int depth, bpc; };
         for (Cf c : {Cf{0, 0}, Cf{3, 0}, Cf{3, 1}, Cf{0, 4}})
