@@ -238,7 +238,7 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
                                   own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None))
         chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc))
-        keep.append((sets, masks, scratch))
+        keep.append((sets, masks, scratch, own))
     return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], chains=chain_list, master=master, work=work,
                 gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
@@ -553,9 +553,11 @@ def main():
                          "are independent, and the fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide "
                          "behind the streaming kernels of the other.  Single GPU with --graph all only; per-kernel durations (`roofline`, "
                          "`kernels`) are then taken with the chains back to back on one stream")
-    ap.add_argument("--defer-da", choices=("off", "main", "side"), default="off",
-                    help="take the dA_m halves of moka_down_bwd off the dependency chain (only the optimizer needs them): main = enqueue them "
-                         "after the layer's chain on the same stream; side = on a second stream beside the next layer's chain (--graph all / off, 1 GPU)")
+    ap.add_argument("--defer-da", choices=("off", "main", "side"), default="side",
+                    help="the dA_m halves of moka_down_bwd are needed by the optimizer only: side (default, what moka_amd.parallel.attach does) = "
+                         "a layer's worth of them is enqueued on a second stream when the layer's chain is, and runs beside the next layer's chain "
+                         "(joined before a gradient bucket ships and before the optimizer step); main = the same launches on the one stream; "
+                         "off = dA_m and dx from one moka_down_bwd call inside the chain")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -602,8 +604,8 @@ def main():
     lib = _lib.load()
     _lib.check(lib.moka_device_check(), "moka_device_check")
     from moka_amd.parallel import FlatGradBucket
-    if args.defer_da != "off" and (world > 1 or args.graph == "bwd" or args.chains > 1):
-        raise SystemExit("--defer-da: single GPU, --graph all or off, one chain")
+    if args.chains > 1:
+        args.defer_da = "off"                                    # (the part-batch chains already overlap each other)
     if args.chains > 1 and (world > 1 or args.graph != "all"):
         raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")
     wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None),
@@ -656,6 +658,7 @@ def main():
                     for st in branch:
                         cur.wait_stream(st)          # join
             else:
+                da_side = torch.cuda.Stream(device=dev)
                 fwd_graph = torch.cuda.CUDAGraph()       # the forward has no hooks: one graph
                 with torch.cuda.graph(fwd_graph, stream=side):
                     run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -665,7 +668,8 @@ def main():
                     lo = max(0, (hi - 1) // lpb * lpb)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
-                        run_backward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), hi, lo=lo)
+                        cs = torch.cuda.current_stream()
+                        run_backward(lib, wl, c_void_p(cs.cuda_stream), hi, lo=lo, defer=(args.defer_da, cs, da_side) if args.defer_da != "off" else None)
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
@@ -676,7 +680,7 @@ def main():
     # N > 1: how long the main stream stands still in bucket.finish() (the part of the all-reduce the backward did not hide)
     comm_ev = [] if world > 1 else None
 
-    live_side = torch.cuda.Stream(device=dev) if args.defer_da == "side" else None
+    live_side = torch.cuda.Stream(device=dev) if args.defer_da != "off" else None
 
     def step(i, rec=None):
         sp = c_void_p(main_stream.cuda_stream)
@@ -811,6 +815,7 @@ def main():
                             "adapter_params": wl["n_params"]},
             "graph": args.graph,
             "chains": args.chains,
+            "defer_dA": args.defer_da,
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

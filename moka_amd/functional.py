@@ -387,10 +387,10 @@ def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[t
 class AdapterSpec:
     """Static description of one adapted projection (what varies between AVT and VT)."""
 
-    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed", "sinks")
+    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed", "sinks", "defer")
 
     def __init__(self, r: int, s_in: float, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
-                 dropout_p: float = 0.0, seed: Optional[int] = None, sinks=None):
+                 dropout_p: float = 0.0, seed: Optional[int] = None, sinks=None, defer=None):
         self.r, self.s_in, self.s_out, self.w, self.inv_sqrt_dk = int(r), float(s_in), [float(s) for s in s_out], float(w), float(inv_sqrt_dk)
         self.dropout_p = float(dropout_p)
         self.seed = (draw_seed() if seed is None else int(seed)) if self.dropout_p > 0.0 else 0
@@ -398,6 +398,10 @@ class AdapterSpec:
         # (moka_amd.parallel.attach) the weight-gradient kernels accumulate into DIRECTLY; the autograd node then returns no
         # gradient for lora_B / lora_A (the data-parallel step works on the flat buffer).  None: ordinary autograd gradients.
         self.sinks = sinks
+        # defer: callable(fn) installed with the sinks (moka_amd.parallel.attach(defer_dA=True)).  dA_m is needed by the optimizer
+        # only: the backward then runs the dx half of moka_down_bwd on the dependency chain and hands the dA_m half to `defer`,
+        # which launches it later on a side stream (beside the next layer's chain), before the gradients are used.
+        self.defer = defer
 
 
 class MokaLinearFn(torch.autograd.Function):
@@ -478,7 +482,13 @@ class MokaLinearFn(torch.autograd.Function):
                 AT = torch.stack(list(A)).contiguous()
             else:
                 bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
-            down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed, dtype=dt)
+            if spec.sinks is not None and spec.defer is not None and dA_acc is not None:
+                if dx2 is not None:
+                    down_bwd_(bst, x2, AT, rt, r, None, dx2, spec.dropout_p, spec.seed, dtype=dt)
+                spec.defer(lambda bst=bst, x2=x2, AT=AT, dA_acc=dA_acc: down_bwd_(bst, x2, AT, rt, r, dA_acc, None, spec.dropout_p, spec.seed, dtype=dt),
+                           [x2, bst.dh_tok, bst.dh_kmj, AT])
+            else:
+                down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed, dtype=dt)
         gB, gA = None, [None] * len(A)
         if flat is not None:
             cast = _split_like(flat.to(Bw.dtype), shapes)             # one cast kernel for all weight gradients
@@ -605,7 +615,14 @@ class MokaLinearGroupFn(torch.autograd.Function):
             if need_A:
                 a0 = G if need_B else 0
                 dA_accs = [acc[a0 + g * M:a0 + (g + 1) * M] for g in range(G)]
-            down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, [s_.seed for s_ in specs])
+            seeds_ = [s_.seed for s_ in specs]
+            if use_sinks and sp.defer is not None and dA_accs is not None:
+                if dx2 is not None:
+                    down_bwd_group_(bsts, x2, ATs, rt, r, None, dx2, sp.dropout_p, seeds_)
+                sp.defer(lambda: down_bwd_group_(bsts, x2, None, rt, r, dA_accs, None, sp.dropout_p, seeds_),
+                         [x2] + [b.dh_tok for b in bsts] + [b.dh_kmj for b in bsts])
+            else:
+                down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, seeds_)
         cast = _split_like(flat.to(x2.dtype), shapes) if flat is not None else []      # one cast kernel for all weight gradients
         grads = []
         for g in range(G):

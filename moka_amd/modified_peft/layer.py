@@ -228,6 +228,7 @@ class Linear(nn.Module, LoraLayer):
     # gradient sinks installed by moka_amd.parallel.attach(): {"B": fp32 view for lora_B['text'], "A": [views for lora_A['text'],
     # lora_A['image']]} of the flat data-parallel gradient buffer (None: ordinary autograd gradients)
     _moka_sinks = None
+    _moka_defer = None          # attach(defer_dA=True): callable that takes the dA_m half of the backward off the dependency chain
 
     def _sinks(self, n_adapters: int):
         sk = self._moka_sinks
@@ -253,12 +254,12 @@ class Linear(nn.Module, LoraLayer):
             A_i = self.lora_A["image"].weight
             rt = GLOBAL_ROUTING_CACHE.get("vt", [my_text_mask, my_image_mask, question_mask])
             spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r), dropout_p=p,
-                               sinks=self._sinks(2))
+                               sinks=self._sinks(2), defer=self._moka_defer)
             return (W, base.bias, B_t, [A_t, A_i], rt, spec)
         # masks None (cached decode steps): plain LoRA with the text adapter (layer.py:672-678)
         B_, S_ = (x.shape[0], x.shape[1]) if x.dim() == 3 else (1, x.shape[0])
         rt = GLOBAL_ROUTING_CACHE.plain(B_, S_, x.device, 1)
-        spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r), dropout_p=p, sinks=self._sinks(1))
+        spec = AdapterSpec(r, 1.0, [self.scaling["text"]], 0.0, 1.0 / math.sqrt(r), dropout_p=p, sinks=self._sinks(1), defer=self._moka_defer)
         return (W, base.bias, B_t, [A_t], rt, spec)
 
     def __repr__(self) -> str:

@@ -76,6 +76,7 @@ class Linear(nn.Linear, LoraLayer):
     # gradient sinks installed by moka_amd.parallel.attach(): {"B": fp32 [d_out, r] view, "A": [fp32 [r, d_in] views]} of the flat
     # data-parallel gradient buffer -- the weight-gradient kernels accumulate into them directly (None: autograd gradients)
     _moka_sinks = None
+    _moka_defer = None          # attach(defer_dA=True): callable that takes the dA_m half of the backward off the dependency chain
 
     def _sinks(self, n_adapters: int):
         sk = self._moka_sinks
@@ -85,7 +86,7 @@ class Linear(nn.Linear, LoraLayer):
         # lora_dropout acts on x before every A_m (lora.py:477); one counter-based mask per call
         p = self.lora_dropout_p if self.training else 0.0
         return AdapterSpec(self.d_k, self.scaling[0], [1.0] * self.lora_num, self.blc_weight, 1.0 / math.sqrt(self.d_k), dropout_p=p,
-                           sinks=self._sinks(self.lora_num))
+                           sinks=self._sinks(self.lora_num), defer=self._moka_defer)
 
     def _adapter_weights(self, dtype):
         A = [getattr(self, f"lora_A{i}").weight for i in range(self.lora_num)]
@@ -104,7 +105,7 @@ class Linear(nn.Linear, LoraLayer):
             # decode step: only the text adapter, no masks (lora.py:373-381)
             rt = GLOBAL_ROUTING_CACHE.plain(x.shape[0], x.shape[1], x.device, 1)
             return (W, self.bias, Bw, A[:1], rt,
-                    AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed, sinks=self._sinks(1)))
+                    AdapterSpec(spec.r, spec.s_in, [1.0], 0.0, spec.inv_sqrt_dk, spec.dropout_p, spec.seed, sinks=self._sinks(1), defer=self._moka_defer))
         if "test" in method or "train" in method:
             # prefill / train: token-routed adapters + cross-modal interaction (lora.py:385-532)
             if modality_mask is None:

@@ -336,3 +336,30 @@ def test_bench_launches_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--layers", "1",
                           "--steps", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert res.returncode != 0 and "GPU(s) visible" in (res.stderr + res.stdout)
+
+
+def test_deferred_dA_on_the_side_stream_gives_the_same_gradients():
+    """attach(defer_dA=True) (the default) launches the dA_m halves of a layer on a side stream when the layer's backward has been
+    enqueued; the flat gradient must equal the in-chain schedule's (same kernels, same operands: only the atomics' order may differ),
+    also with dropout (the mask is a function of (seed, token, column), not of the launch) and under gradient accumulation."""
+    dev = torch.device("cuda:0")
+    from moka_amd.parallel import attach
+    outs = []
+    for defer in (False, True):
+        st, dims = _build("avt", dev)
+        for m in st.modules():
+            if hasattr(m, "lora_dropout_p"):
+                m.lora_dropout_p = 0.1
+        dp = attach(st, n_buckets=3, defer_dA=defer)
+        h, gout, mask_args, sl = _batch("avt", dims, dev)
+        torch.manual_seed(123)                                    # the dropout seeds are drawn from torch's CPU generator
+        with dp.no_sync():
+            _run(st, dp, h[:1], gout[:1], sl(0, 1), 1.0)
+        _run(st, dp, h[1:], gout[1:], sl(1, 2), 1.0)
+        assert (len(dp._deferred) == 0) or defer
+        dp.finish(average=False)
+        torch.cuda.synchronize()
+        assert not dp._deferred and not dp._side_busy
+        outs.append(dp.bucket.flat.clone())
+    err = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
+    assert outs[0].norm().item() > 0 and err <= 1e-5, err
