@@ -334,9 +334,9 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
 
 
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
-# PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
+# PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
 # in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), never a constant in here.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic_per_launch(T, launches_per_layer):
