@@ -529,6 +529,22 @@ class MokaFlatOptimizer(torch.optim.Optimizer):
             self.dp.load_state_dict(flat)
 
 
+def keep_out_of_ddp(trainer, dp: AdapterDataParallel) -> None:
+    """Under ``torchrun`` HF ``Trainer`` hands the model to ``accelerator.prepare``, which wraps it in ``DistributedDataParallel``; DDP's
+    reducer then waits for autograd gradients of the trainable parameters -- gradients that never come, because the kernels write
+    them into ``dp``'s flat buffer and ``dp`` all-reduces that itself.  This makes ``accelerator.prepare_model`` return ``dp.model``
+    unwrapped (everything else -- device placement of the batches, the optimizer wrapper, gradient accumulation -- is untouched).
+    A no-op in a single process."""
+    acc = trainer.accelerator
+    orig = acc.prepare_model
+
+    def prepare_model(model, *a, **kw):
+        if model is dp.model or getattr(model, "module", None) is dp.model:
+            return model
+        return orig(model, *a, **kw)
+    acc.prepare_model = prepare_model
+
+
 def trainer_callback(dp: AdapterDataParallel):
     """``transformers.TrainerCallback`` that keeps ``dp.sync`` off for every micro-batch of a gradient-accumulation window but
     the last (what ``accelerator.no_sync`` does for a DDP model), so that the bucketed all-reduce overlaps the LAST backward

@@ -64,7 +64,7 @@ def _collate(rows):
 @pytest.mark.parametrize("accum", [1, 2])
 def test_hf_trainer_drives_the_flat_optimizer(tmp_path, accum):
     from transformers import Trainer, TrainingArguments
-    from moka_amd.parallel import MokaFlatOptimizer, attach, trainer_callback
+    from moka_amd.parallel import MokaFlatOptimizer, attach, keep_out_of_ddp, trainer_callback
     dev = torch.device("cuda:0")
     rows = _data(n=2 * accum)
     steps, lr = 4, 2e-3
@@ -99,6 +99,8 @@ def test_hf_trainer_drives_the_flat_optimizer(tmp_path, accum):
             return torch.utils.data.SequentialSampler(self.train_dataset)
 
     tr = Seq(model=m, args=args, train_dataset=rows, data_collator=_collate, optimizers=(opt, sched), callbacks=[trainer_callback(dp)])
+    keep_out_of_ddp(tr, dp)                                       # (what a torchrun launch needs; harmless in one process)
+    assert tr.accelerator.prepare_model(m) is m
     tr.train()
     torch.cuda.synchronize()
     losses = [e["loss"] for e in tr.state.log_history if "loss" in e]
