@@ -1986,14 +1986,14 @@ __global__ void __launch_bounds__(512) moka_gy_kernel(const GyBatch ab) {
 // waves used to fetch from L2 for itself (half as many bytes as the gy tile again), arrive once per workgroup by two more DMA
 // requests.  Two LDS-only barriers per 32-token tile ("tile k is in" / "the partials of tile k are in").
 // ------------------------------------------------------------------------------------------
-template <bool WITH_DB, bool DET>
+template <int RP, bool WITH_DB, bool DET>
 __global__ void __launch_bounds__(512) moka_gs_kernel(const GyBatch ab, int NG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RP = 16, RPITCH = 1040, STAGE = 32 * RPITCH;
+    constexpr int NT = RP / 16, RPITCH = 1040, STAGE = 32 * RPITCH, PKS = 2 * NT * 1024;
     unsigned char* ring = smem;                                  // [2][32 rows][RPITCH]
-    float* slots = (float*)(smem + 2 * STAGE);                   // [8 waves][16 tokens][16 ranks]
-    unsigned char* pk = (unsigned char*)(slots + 8 * 256);       // [2][hi 1 KB | lo 1 KB]   (WITH_DB)
-    unsigned char* smod = pk + (WITH_DB ? 4096 : 0);             // [2][32] routing bytes of the tile in each stage
+    float* slots = (float*)(smem + 2 * STAGE);                   // [8 waves][16 tokens][RP ranks]
+    unsigned char* pk = (unsigned char*)(slots + 8 * 16 * RP);   // [2][rank tile][hi 1 KB | lo 1 KB]   (WITH_DB)
+    unsigned char* smod = pk + (WITH_DB ? 2 * PKS : 0);          // [2][32] routing bytes of the tile in each stage
     int zi = 0, xb = blockIdx.x;
     while (zi + 1 < MOKA_MAX_GROUP && xb >= ab.xend[zi]) ++zi;
     if (zi) xb -= ab.xend[zi - 1];
@@ -2035,34 +2035,40 @@ __global__ void __launch_bounds__(512) moka_gs_kernel(const GyBatch ab, int NG) 
             const unsigned char* src = a.gy + ((size_t)min(grp * 32 + row, a.T - 1) * a.C + ccol) * 2;
             glds16(src, __builtin_amdgcn_readfirstlane(ring_base + st * STAGE + row * RPITCH));
         }
-        if (WITH_DB && wave < 2) {
-            const unsigned short* ph = kmj_frag<RP>(a.pack, 0, 0, grp, a.Tp, lane) + (wave ? (size_t)RP * a.Tp : 0);
-            glds16(ph, __builtin_amdgcn_readfirstlane(pk_base + st * 2048 + wave * 1024));
+        if (WITH_DB && wave < 2 * NT) {                           // wave w: rank tile w / 2, hi (even) or lo (odd) plane
+            const unsigned short* ph = kmj_frag<RP>(a.pack, 0, wave >> 1, grp, a.Tp, lane) + ((wave & 1) ? (size_t)RP * a.Tp : 0);
+            glds16(ph, __builtin_amdgcn_readfirstlane(pk_base + st * PKS + wave * 1024));
         }
         if (tid < 32) mnext = a.tok_mod[grp * 32 + tid];          // (padded past T with MOKA_MOD_NONE)
     };
     // weights of the g contraction: wave (h, q) multiplies tokens 16h .. 16h+15 by columns cb0 + 128q .. +127 (four K steps)
     const int h = wave >> 2, q = wave & 3;
-    bf16x8 bw[4];
+    bf16x8 bw[4][NT];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int c = min(cb0 + 128 * q + 32 * ks + 8 * g, a.C - 8);
-        const unsigned char* src = a.BwT + ((size_t)i * a.C + c) * 2;
-        bw[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(bw[ks]) : "v"(src) : "memory");
-    }
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = min(cb0 + 128 * q + 32 * ks + 8 * g, a.C - 8);
+            const unsigned char* src = a.BwT + ((size_t)(nt * 16 + i) * a.C + c) * 2;
+            bw[ks][nt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(bw[ks][nt]) : "v"(src) : "memory");
+        }
     const int first = group_of(0);
     if (first >= 0) issue(0, first);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bw[ks]) : : "memory");      // (start-up: the weights and the first tile)
-        if (cb0 + 128 * q + 32 * ks + 8 * g >= a.C) bw[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bw[ks][nt]) : : "memory");      // (start-up: the weights and the first tile)
+            if (cb0 + 128 * q + 32 * ks + 8 * g >= a.C) bw[ks][nt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
     const int c0 = cb0 + 64 * wave;                              // my 64 columns of the dB contraction
     const bool dbactive = WITH_DB && c0 < a.C;
-    f32x4 accW[4];
+    f32x4 accW[4][NT];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) accW[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accW[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int k = 0;; ++k) {
         // tile k is in (every VMEM operation of mine has completed); its routing bytes go to LDS
@@ -2075,33 +2081,46 @@ __global__ void __launch_bounds__(512) moka_gs_kernel(const GyBatch ab, int NG) 
         const int gn = group_of(k + 1);
         if (gn >= 0) issue(k + 1, gn);
         const unsigned char* stg = ring + (k & 1) * STAGE;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 xf = *(const bf16x8*)(stg + (16 * h + i) * RPITCH + (128 * q + 32 * ks + 8 * g) * 2);
-            acc = MFMA16(bw[ks], xf, acc);                       // D^T: lane (token i, ranks 4g .. 4g+3)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA16(bw[ks][nt], xf, acc[nt]);      // D^T: lane (token i, ranks 16 nt + 4g .. + 3)
         }
-        MFMA_SETTLE(acc);
-        *(f32x4*)(slots + wave * 256 + i * RP + 4 * g) = acc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            MFMA_SETTLE(acc[nt]);
+            *(f32x4*)(slots + wave * 16 * RP + i * RP + 16 * nt + 4 * g) = acc[nt];
+        }
         if (dbactive) {
-            const bf16x8 bh = *(const bf16x8*)(pk + (k & 1) * 2048 + lane * 16);
-            const bf16x8 bl = *(const bf16x8*)(pk + (k & 1) * 2048 + 1024 + lane * 16);
+            bf16x8 bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bh[nt] = *(const bf16x8*)(pk + (k & 1) * PKS + (2 * nt) * 1024 + lane * 16);
+                bl[nt] = *(const bf16x8*)(pk + (k & 1) * PKS + (2 * nt + 1) * 1024 + lane * 16);
+            }
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const unsigned char* base = stg + (4 * g + (i >> 2)) * RPITCH + (64 * wave + ct * 16 + 4 * (i & 3)) * 2;
                 const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base));
                 const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_TR_PTR(base + 16 * RPITCH));
                 const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                accW[ct] = MFMA16(av, bh, accW[ct]);
-                accW[ct] = MFMA16(av, bl, accW[ct]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    accW[ct][nt] = MFMA16(av, bh[nt], accW[ct][nt]);
+                    accW[ct][nt] = MFMA16(av, bl[nt], accW[ct][nt]);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        // the partials of tile k are in
-        {
-            const int tl = tid >> 4, kr = tid & 15, hh = tl >> 4;
+        for (int e = tid; e < 32 * RP; e += 512) {
+            const int tl = e / RP, kr = e % RP, hh = tl >> 4;
             float sum = 0.f;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) sum += slots[(4 * hh + qq) * 256 + (tl & 15) * RP + kr];
+            for (int qq = 0; qq < 4; ++qq) sum += slots[(4 * hh + qq) * 16 * RP + (tl & 15) * RP + kr];
             const int t = gk * 32 + tl;
             if (t < a.T) {
                 const int mr = smod[(k & 1) * 32 + tl];
@@ -2113,20 +2132,28 @@ __global__ void __launch_bounds__(512) moka_gs_kernel(const GyBatch ab, int NG) 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the re-requests behind the run have landed: the ring is free)
     if (WITH_DB) {
         // dB leaves as [column][rank] rows: wave w's accumulators hold its 64 columns, disjoint from the other waves' -- a wave-private
-        // transposition through (its 4 KB of) the idle ring, then coalesced fp32 atomics (DET: plain stores of the run's partial tile)
+        // transposition through (its 4 KB of) the idle ring, one 16-column tile (x RP ranks) at a time at the wider ranks, then
+        // coalesced fp32 atomics (DET: plain stores of the run's partial tile)
+        constexpr int CTB = (RP == 16) ? 4 : (RP == 32 ? 2 : 1);         // column tiles per round: CTB x 16 x RP floats <= 4 KB
         float* mine = (float*)(ring + wave * 4096);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int cb = 0; cb < 4; cb += CTB) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) mine[(ct * 16 + 4 * g + reg) * RP + i] = accW[ct][reg];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int e = lane; e < 64 * RP; e += 64) {
-            const int cl = e / RP, kk = e % RP;
-            const int c = c0 + cl;
-            if (c < a.C && kk < a.r) {
-                if (DET) a.det[((size_t)blockIdx.y * a.det_planes + zi) * a.det_stride + (size_t)c * a.r + kk] = mine[cl * RP + kk];
-                else atomicAdd(a.dB + (size_t)c * a.r + kk, mine[cl * RP + kk]);
+            for (int ct = 0; ct < CTB; ++ct)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) mine[(ct * 16 + 4 * g + reg) * RP + nt * 16 + i] = accW[cb + ct][nt][reg];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int e = lane; e < CTB * 16 * RP; e += 64) {
+                const int cl = e / RP, kk = e % RP;
+                const int c = c0 + cb * 16 + cl;
+                if (c < a.C && kk < a.r) {
+                    if (DET) a.det[((size_t)blockIdx.y * a.det_planes + zi) * a.det_stride + (size_t)c * a.r + kk] = mine[cl * RP + kk];
+                    else atomicAdd(a.dB + (size_t)c * a.r + kk, mine[cl * RP + kk]);
+                }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the next round rewrites the area)
         }
     }
     TRACE(7);
@@ -3098,11 +3125,11 @@ static void launch_gy_t(const GyBatch& gb, int nz, int ncb, hipStream_t st) {
     }
 }
 
-// LDS-DMA form (r <= 16): same grid map, slices and deterministic-mode plumbing as launch_gy_t
-template <bool WITH_DB>
+// LDS-DMA form: same grid map, slices and deterministic-mode plumbing as launch_gy_t
+template <int RP, bool WITH_DB>
 static void launch_gs_t(const GyBatch& gb, int nz, int ncb, int ng, hipStream_t st) {
     const int ngroups = gb.z[0].Tp >> 5;
-    const size_t lds = (size_t)2 * 32 * 1040 + 8 * 256 * 4 + (WITH_DB ? 4096 : 0) + 64;
+    const size_t lds = (size_t)2 * 32 * 1040 + (size_t)8 * 16 * RP * 4 + (WITH_DB ? (size_t)2 * 2 * (RP / 16) * 1024 : 0) + 64;
     GyBatch& gx = const_cast<GyBatch&>(gb);
     int xtot = 0;
     for (int z = 0; z < MOKA_MAX_GROUP; ++z) {
@@ -3129,34 +3156,37 @@ static void launch_gs_t(const GyBatch& gb, int nz, int ncb, int ng, hipStream_t 
         }
     }
     if (det) {
-        ensure_lds((const void*)moka_gs_kernel<WITH_DB, WITH_DB>, lds);
-        hipLaunchKernelGGL((moka_gs_kernel<WITH_DB, WITH_DB>), dim3(xtot, ntb_static, 1), dim3(512), lds, st, gb, ng);
+        ensure_lds((const void*)moka_gs_kernel<RP, WITH_DB, WITH_DB>, lds);
+        hipLaunchKernelGGL((moka_gs_kernel<RP, WITH_DB, WITH_DB>), dim3(xtot, ntb_static, 1), dim3(512), lds, st, gb, ng);
         det_finish(sr, st);
     } else {
-        ensure_lds((const void*)moka_gs_kernel<WITH_DB, false>, lds);
-        hipLaunchKernelGGL((moka_gs_kernel<WITH_DB, false>), dim3(xtot, ntb_static, 1), dim3(512), lds, st, gb, ng);
+        ensure_lds((const void*)moka_gs_kernel<RP, WITH_DB, false>, lds);
+        hipLaunchKernelGGL((moka_gs_kernel<RP, WITH_DB, false>), dim3(xtot, ntb_static, 1), dim3(512), lds, st, gb, ng);
     }
+}
+
+template <int RP, bool WITH_DB>
+static int launch_gs_auto(GyBatch& gb, int nz, int Cmax, hipStream_t st) {
+    const int ngroups = gb.z[0].Tp >> 5;
+    long active = 0;
+    for (int z = 0; z < nz; ++z) active += (gb.z[z].C + 511) / 512;
+    // token groups per workgroup: long runs keep the dB atomics (and the start-ups) down, as long as every CU still gets a workgroup
+    // (T = 8192, kernel sequence of a step: 4096 wide 4 / 8 / 16 groups -> 28.7 / 24.6 / 27.8 us, 11008 wide 64.1 / 58.8 / 51.0 us)
+    auto blocks = [&](int n) { return active * ((ngroups + n - 1) / n); };
+    int ng = (4 * blocks(16) >= 5L * num_cu()) ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
+    while (ng > 2 && blocks(ng) < (long)num_cu() / 2) ng >>= 1;
+    if (g_tune_gy_ng > 0) ng = g_tune_gy_ng;
+    launch_gs_t<RP, WITH_DB>(gb, nz, (Cmax + 511) / 512, ng, st);
+    return check_launch("moka_gs_kernel");
 }
 
 template <int RP, bool WITH_DB>
 static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) {
     GyBatch gb = gb_in;                                  // (launch_gy_t fills in the grid map)
-    if constexpr (RP == 16) {
-        // LDS-DMA ring, except for the widest batches (gate + up, 2 x 11008: 97.5 against 92.8 us for the first form in the step's kernel
-        // sequence; o / down 26.3 against 27.9, q + k + v 54 against 58); "gy_form" 1 / 2 forces the first / second form
-        if (g_tune_gy_form == 2 || (g_tune_gy_form == 0 && !(nz > 1 && Cmax > 8192))) {
-            const int ngroups = gb.z[0].Tp >> 5;
-            long active = 0;
-            for (int z = 0; z < nz; ++z) active += (gb.z[z].C + 511) / 512;
-            // token groups per workgroup: long runs keep the dB atomics (and the start-ups) down, as long as every CU still gets a workgroup
-            // (T = 8192, kernel sequence of a step: 4096 wide 4 / 8 / 16 groups -> 28.7 / 24.6 / 27.8 us, 11008 wide 64.1 / 58.8 / 51.0 us)
-            auto blocks = [&](int n) { return active * ((ngroups + n - 1) / n); };
-            int ng = (4 * blocks(16) >= 5L * num_cu()) ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
-            while (ng > 2 && blocks(ng) < (long)num_cu() / 2) ng >>= 1;
-            if (g_tune_gy_ng > 0) ng = g_tune_gy_ng;
-            launch_gs_t<WITH_DB>(gb, nz, (Cmax + 511) / 512, ng, st);
-            return check_launch("moka_gs_kernel");
-        }
+    // LDS-DMA ring; at r <= 16 except for the widest batches (gate + up, 2 x 11008: 97.5 against 92.8 us for the first form in the step's
+    // kernel sequence; o / down 26.3 against 27.9, q + k + v 54 against 58); "gy_form" 1 / 2 forces the first / second form
+    if constexpr (RP <= 32) {
+        if (g_tune_gy_form == 2 || (g_tune_gy_form == 0 && (RP == 32 || !(nz > 1 && Cmax > 8192)))) return launch_gs_auto<RP, WITH_DB>(gb, nz, Cmax, st);
     }
     if constexpr (RP == 64 && !WITH_DB) {
         // rank pad 64: 128 columns per wave, one split-K slice per 1024 columns (bwd_kw): the rank-space backward reads half as many
@@ -3190,9 +3220,14 @@ static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) 
 template <bool WITH_DB>
 static int launch_gy(const GyBatch& gb, int nz, int Cmax, int RP, hipStream_t st) {
     if (RP == 16) return launch_gy_rp<16, WITH_DB>(gb, nz, Cmax, st);
-    if (WITH_DB) return fail(MOKA_EINVAL, "moka_up_bwd: the one-pass g + dB kernel is built for r <= 16 only");
-    if (RP == 32) return launch_gy_rp<32, false>(gb, nz, Cmax, st);
-    return launch_gy_rp<64, false>(gb, nz, Cmax, st);
+    if constexpr (WITH_DB) {                             // rank pad 32: only the LDS-DMA form carries dB along
+        if (RP != 32) return fail(MOKA_EINVAL, "moka_up_bwd: the one-pass g + dB kernels are built for r <= 32 only");
+        GyBatch g2 = gb;
+        return launch_gs_auto<32, true>(g2, nz, Cmax, st);
+    } else {
+        if (RP == 32) return launch_gy_rp<32, false>(gb, nz, Cmax, st);
+        return launch_gy_rp<64, false>(gb, nz, Cmax, st);
+    }
 }
 
 template <int RP, int G, int NG>
@@ -3263,6 +3298,9 @@ static int fwd_kw(int r) { return (use_xw(rank_pad(r)) && rank_pad(r) == 64) ? 2
 static int fwd_ks(int /*T*/, int C, int r) { const int kw = fwd_kw(r); return (C + kw - 1) / kw; }
 
 // number of g_part slices moka_up_bwd writes for output width C
+// the LDS-DMA gy pass (g and dB out of one LDS tile) also at rank pad 32: 13B widths 12.0 -> 10.4 ms per pass.  At rank pad 64 it loses
+// (115 KB of LDS: one workgroup per CU, 48 MFMAs per tile and wave: 28.8 against 24.7 ms for the g-only pass + the wide dB kernel)
+static bool gs_wide(int RP) { return RP == 32 && g_tune_gy_form != 1; }
 static int bwd_kw(int r) { return rank_pad(r) == 64 ? 1024 : 512; }                              // columns per g_part slice
 static int bwd_ks(int /*T*/, int C, int r) { const int kw = bwd_kw(r); return (C + kw - 1) / kw; }
 
@@ -3603,7 +3641,9 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
         if (!BwT) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without BwT");
         // the dB half rides along only for r <= 16: with 32 / 64 ranks its atomics (64 x RP per wave and block) and the single
         // resident block per CU cost more than the second read of gy (measured: 47 vs 45 us at RP = 32, 97 vs 79 us at RP = 64)
-        const bool with_db = dB_acc && dB_acc[0] && RP == 16;
+        // (the first, register-staged form carried dB along only for r <= 16: 47 vs 45 us at RP = 32, 97 vs 79 us at RP = 64 against a second
+        //  read of gy; the LDS-DMA form takes both contractions out of one LDS tile and also pays at rank pad 32)
+        const bool with_db = dB_acc && dB_acc[0] && (RP == 16 || gs_wide(RP));
         if (with_db && !hp_kmj) return fail(MOKA_EINVAL, "moka_up_bwd: dB requested without hp_kmj");
         GyBatch gb;
         memset(&gb, 0, sizeof(gb));
