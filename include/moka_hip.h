@@ -123,8 +123,9 @@ int moka_diagnostics(void);
 int moka_rank_pad(int r);
 /* Token count rounded up to the pack granularity (32). */
 int moka_tok_pad(int T);
-/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C = d_in (one per 512 columns; one per 256 for
- * rank pad 64).  `part` holds ks * T * RP floats. */
+/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C = d_in (one per 512 columns; rank pad 64: a whole
+ * number of 256-column chunks per slice, chosen from T and the device's CU count so that the launch fills the chip -- at most one
+ * per 256 columns, so C / 256 rounded up is an upper bound for any T).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
  * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy (per 1024 columns for

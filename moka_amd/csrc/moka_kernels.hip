@@ -2583,6 +2583,140 @@ __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_ker
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// F (rank pad 64): independent waves as above, but a workgroup keeps its 8 sub-tiles (128 tokens, one per wave) and walks `cps`
+// consecutive 256-column chunks with the accumulators in registers: one split-K slice per cps chunks instead of one per chunk.  At
+// rank 64 a slice row is 256 bytes -- with one slice per 256 columns the forward WROTE half as many bytes as it read (and the
+// interaction kernel read them back: 20 slices of 2 MB per 5120-wide projection); with the slices sized so that the grid just fills the
+// chip (4 at 8192 tokens) that traffic is a tenth.  The weight fragments of a chunk are staged per chunk (two modality slots, 64 KB: two
+// workgroups per CU), requested from L2 one chunk ahead; a token run with three modalities takes a second walk for the third (rows are
+// independent: a row only accumulates in the chain of its own modality).  13B widths, r = 64, 8192 tokens: forward projection + interaction
+// 13.6 + 7.8 -> 11.0 + 4.8 ms per pass.
+// ------------------------------------------------------------------------------------------
+template <int RP>
+__global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK;
+    constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality slot, rank tile)
+    static_assert(NU == 2, "a chunk streams in two units");
+    bf16x8* wl = (bf16x8*)smem;                              // [2][NT][NKS][64]
+    __shared__ unsigned s_wpm[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int nsub = (a.T + 15) >> 4;
+    const int sub = blockIdx.y * 8 + wave;
+    const bool live = sub < nsub;
+    const int nch = (a.C + KW - 1) / KW;
+    const int ch0 = blockIdx.x * cps, ch1 = min(nch, ch0 + cps);
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const unsigned char* row = a.x + (size_t)min(16 * min(sub, nsub - 1) + i, a.T - 1) * a.C * 2;
+    bf16x8 xA[HK], xB[HK];
+    auto issue = [&](bf16x8 (&xb)[HK], int ch_, int half) {
+        const int cb = min(ch_, ch1 - 1) * KW;
+#pragma unroll
+        for (int q = 0; q < HK; ++q) xb[q] = *(const bf16x8*)(row + (size_t)min(cb + 32 * (HK * half + q) + 8 * g, a.C - 8) * 2);
+    };
+    issue(xA, ch0, 0);                                       // the x stream starts before anything else
+
+    int mrow = MOKA_MOD_NONE;
+    if (live) mrow = a.tok_mod[16 * sub + i];                // padded past T with MOKA_MOD_NONE
+    unsigned pm = 0;
+#pragma unroll
+    for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+    if (lane == 0) s_wpm[wave] = pm;
+    __syncthreads();
+    unsigned pmB = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
+    if (pmB == 0) return;                                    // a run of padding only: nothing to write (block uniform)
+    const bool mixed = (pm & (pm - 1)) != 0;                 // span boundary inside my 16 tokens (wave uniform)
+    const unsigned trow = (unsigned)min(16 * min(sub, nsub - 1) + i, a.T - 1);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    unsigned rest = pmB;
+    bool first = true;
+    while (rest) {                                           // block uniform: one walk per pair of modalities in the run
+        const int m0 = __ffs(rest) - 1;
+        rest &= rest - 1;
+        const int m1 = rest ? __ffs(rest) - 1 : -1;
+        if (m1 >= 0) rest &= rest - 1;
+        const unsigned mset = (1u << m0) | (m1 >= 0 ? (1u << m1) : 0u);
+        const bool mine = (pm & mset) != 0;                  // wave uniform
+        if (!first && mine) issue(xA, ch0, 0);
+        first = false;
+        // the fragments of the next chunk are requested (L2) before the current one is computed and go to LDS behind the barrier
+        bf16x8 wp[2][NT * FR / 512];
+        auto wload = [&](int ch) {
+            const int cbn = ch * KW, nkn = min(NKS, (a.C - cbn) >> 5);
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int m = sl ? m1 : m0;
+                if (m < 0) continue;
+#pragma unroll
+                for (int u = 0; u < NT * FR / 512; ++u) {
+                    const int e = tid + 512 * u;
+                    const int ln = e & 63, ks = (e >> 6) % NKS, nt = e / FR;
+                    // rank rows >= r do not exist: clamp the row, the result rows are zeroed when the slice is written
+                    wp[sl][u] = (ks < nkn) ? *(const bf16x8*)(a.A[0][m] + ((size_t)min(nt * 16 + (ln & 15), a.r - 1) * a.C + cbn + 32 * ks + 8 * (ln >> 4)) * 2) : z8;
+                }
+            }
+        };
+        wload(ch0);
+        for (int ch = ch0; ch < ch1; ++ch) {
+            const int cb0 = ch * KW;
+            const int nks = min(NKS, (a.C - cb0) >> 5);
+            __syncthreads();                                 // the previous chunk's fragments are no longer read
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                if ((sl ? m1 : m0) < 0) continue;
+#pragma unroll
+                for (int u = 0; u < NT * FR / 512; ++u) wl[(size_t)sl * NT * FR + tid + 512 * u] = wp[sl][u];
+            }
+            __syncthreads();
+            if (ch + 1 < ch1) wload(ch + 1);
+            if (!mine) continue;
+            auto compute = [&](bf16x8 (&xb)[HK], int half) {
+#pragma unroll
+                for (int q = 0; q < HK; ++q) {
+                    const int ks = HK * half + q;
+                    bf16x8 xg = (ks < nks) ? xb[q] : z8;
+                    if (a.drop[0].thr) xg = drop_apply(xg, drop_keep8(a.drop[0], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const int m = sl ? m1 : m0;
+                        if (m < 0 || !(pm & (1u << m))) continue;     // wave uniform
+                        const bf16x8 xm = (!mixed || mrow == m) ? xg : z8;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = MFMA16(wl[((size_t)sl * NT + nt) * FR + ks * 64 + lane], xm, acc[nt]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            issue(xB, ch, 1);
+            compute(xA, 0);
+            issue(xA, ch + 1, 0);
+            compute(xB, 1);
+        }
+    }
+    if (live && pm) {
+        const float sc = mod_scale(a.s_mod, mrow);           // 0 for tokens of no modality
+        const int t = 16 * sub + i;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            MFMA_SETTLE(acc[nt]);
+            f32x4 v;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) v[reg] = (16 * nt + 4 * g + reg < a.r && mrow < a.M) ? acc[nt][reg] * sc : 0.f;
+            if (t < a.T) *(f32x4*)(a.part[0] + ((size_t)blockIdx.x * a.T + t) * RP + 16 * nt + 4 * g) = v;
+        }
+    }
+}
+
 // Writes the keep mask the kernels use (1 byte per element) -- lets the oracle replay a dropout run.
 __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
     const size_t nchunk = (size_t)T * (C >> 3);
@@ -3293,9 +3427,19 @@ static int launch_xa(const XaArgs& a, hipStream_t st) {
 // which form of the down-projection runs: the weights-in-registers form for r <= 16 (q/k/v and gate/up as one launch), the
 // independent-wave form with the weights staged in LDS for the wider ranks (measured at 13B widths, r = 64, seq 4096: 21.5 -> 13.8 ms
 // per forward pass; at r = 16 the two forms are equal within 5 % and the first one groups).  moka_tune("xa_form", 1 | 2) forces one.
-static bool use_xw(int RP) { return g_tune_xa_form == 2 || (g_tune_xa_form == 0 && RP >= 32); }
-static int fwd_kw(int r) { return (use_xw(rank_pad(r)) && rank_pad(r) == 64) ? 256 : 512; }   // columns per split-K slice
-static int fwd_ks(int /*T*/, int C, int r) { const int kw = fwd_kw(r); return (C + kw - 1) / kw; }
+static bool use_xw(int RP) { return g_tune_xa_form == 2 || ((g_tune_xa_form == 0 || g_tune_xa_form == 3) && RP >= 32); }
+// columns per split-K slice of the forward: 512; rank pad 64: a whole number of 256-column chunks, as few slices as still give every CU a
+// workgroup of 128 tokens (moka_xwm_kernel)
+static int fwd_kw(int T, int C, int r) {
+    if (!(use_xw(rank_pad(r)) && rank_pad(r) == 64)) return 512;
+    if (g_tune_xa_form == 3) return 256;                                  // one chunk per slice (the first form of the kernel, A/B)
+    const int nch = (C + 255) / 256, ntb = (T + 127) / 128;
+    // three workgroups per CU (two resident): 13B widths, 8192 tokens: 13.2 / 12.7 / 11.1 / 11.2 ms per forward pass with 1 / 2 / 3 / 4
+    int want = ((g_tune_xa_ng > 0 ? g_tune_xa_ng : 3) * num_cu() + ntb - 1) / ntb;
+    want = want < 1 ? 1 : (want > nch ? nch : want);
+    return (nch + want - 1) / want * 256;
+}
+static int fwd_ks(int T, int C, int r) { const int kw = fwd_kw(T, C, r); return (C + kw - 1) / kw; }
 
 // number of g_part slices moka_up_bwd writes for output width C
 // the LDS-DMA gy pass (g and dB out of one LDS tile) also at rank pad 32: 13B widths 12.0 -> 10.4 ms per pass.  At rank pad 64 it loses
@@ -3425,7 +3569,7 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             f32_common(a, tok_mod, T, d_in, r, M);
             a.in = (const float*)x; a.out = part[g]; a.drop = drop[g];
             for (int m = 0; m < M; ++m) { a.W[m] = (const float*)A[g * M + m]; a.s_mod[m] = s_in * drop[g].inv_keep; }
-            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3(fwd_ks(T, d_in, r), (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, fwd_kw(r));
+            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3(fwd_ks(T, d_in, r), (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, fwd_kw(T, d_in, r));
             rc = check_launch("moka_f32_reduce_kernel");
             if (rc) return rc;
         }
@@ -3446,7 +3590,15 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
         }
         if (use_xw(RP)) {                                    // independent waves, weights staged in LDS
             if (RP == 16) rc = G == 1 ? launch_xw<16, 1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xw<16, 2>(xa, (hipStream_t)stream) : launch_xw<16, 3>(xa, (hipStream_t)stream));
-            else rc = RP == 32 ? launch_xw<32, 1>(xa, (hipStream_t)stream) : launch_xw<64, 1>(xa, (hipStream_t)stream);
+            else if (RP == 32) rc = launch_xw<32, 1>(xa, (hipStream_t)stream);
+            else if (fwd_kw(T, d_in, r) == 256 && g_tune_xa_form == 3) rc = launch_xw<64, 1>(xa, (hipStream_t)stream);
+            else {
+                const int kw = fwd_kw(T, d_in, r);
+                const size_t lds = (size_t)2 * 4 * 8 * 1024;
+                ensure_lds((const void*)moka_xwm_kernel<64>, lds);
+                hipLaunchKernelGGL((moka_xwm_kernel<64>), dim3((d_in + kw - 1) / kw, (T + 127) / 128), dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                rc = check_launch("moka_xwm_kernel");
+            }
         } else
         if (RP == 16 && (T & 15) == 0 && g_tune_xa_form != 1)    // LDS-DMA ring (whole 16-token tiles; "xa_form" 1 forces the first form)
             rc = G == 1 ? launch_xs<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xs<2>(xa, (hipStream_t)stream) : launch_xs<3>(xa, (hipStream_t)stream));

@@ -43,8 +43,10 @@ def test_ksplit_covers_width(lib):
     for T, C, r in [(8192, 4096, 16), (8192, 11008, 16), (2048, 4096, 16), (96, 64, 4), (4096, 5120, 64), (10, 64, 8)]:
         ks = lib.moka_ksplit(T, C, r)
         assert 1 <= ks <= 32
-    # slices per projection: one per 512 columns; rank pad 64: 256 in the forward (LDS budget of the staged weights), 1024 in the backward
-    assert lib.moka_ksplit(8192, 5120, 16) == 10 and lib.moka_ksplit(8192, 5120, 64) == 20
+    # slices per projection: one per 512 columns; rank pad 64: whole 256-column chunks in the forward, as few as still give every CU three
+    # workgroups of 128 tokens (no device here: 256 CUs assumed); 1024 columns in the backward
+    assert lib.moka_ksplit(8192, 5120, 16) == 10 and lib.moka_ksplit(8192, 5120, 64) == 10 and lib.moka_ksplit(8192, 13824, 64) == 11
+    assert lib.moka_ksplit(128, 5120, 64) == 20 and lib.moka_ksplit(65536, 5120, 64) == 2
     assert lib.moka_ksplit_bwd(8192, 5120, 16) == 10 and lib.moka_ksplit_bwd(8192, 5120, 64) == 5 and lib.moka_ksplit_bwd(8192, 13824, 64) == 14
     assert lib.moka_ksplit(8192, 16, 16) < 0          # width below one MFMA K step
     assert lib.moka_ksplit(8192, 4100, 16) < 0        # not a multiple of 32
