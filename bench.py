@@ -115,6 +115,10 @@ class Unit:
                                                         BwT, AT, G, r, w, c)),
             "moka_up_fwd": ("moka_up_fwd_group", (hp_tok, Bw, tm, y, T, r, do, G, 0)),
             "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0, None)),
+            # the two outputs of moka_up_bwd as separate calls (--defer-db: where dB is a pass of its own anyway, moka_up_bwd_passes() == 2,
+            # it leaves the dependency chain like dA_m)
+            "moka_up_bwd:g": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, None, T, r, do, M, G, 0, None)),
+            "moka_up_bwd:dB": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, None, dB, T, r, do, M, G, 0, None)),
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
                                                       drop_p, sd, 0, None)),
@@ -305,22 +309,28 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
             if on_layer_done is not None:
                 on_layer_done(l)
         return
-    mode, main, side = defer
+    mode, main, side = defer[:3]
+    split_db = len(defer) > 3 and defer[3]                       # dB off the chain too (where it is a pass of its own)
+    up = "moka_up_bwd:g" if split_db else "moka_up_bwd"
     sps = c_void_p(side.cuda_stream)
     done = {}                                                    # layer -> event "its deferred dA launches have finished" (side mode)
     for l in range(n_layers - 1, lo - 1, -1):
         if mode == "side" and (l + 2) in done:
             main.wait_event(done.pop(l + 2))                     # layer l reuses the pack buffers of layer l + 2
         for u in reversed(units[l * per:(l + 1) * per]):
-            _call(lib, "moka_up_bwd", u, sp, rec)
+            _call(lib, up, u, sp, rec)
             _call(lib, "moka_cross_bwd", u, sp, rec)
             _call(lib, "moka_down_bwd:dx", u, sp, None)
         if mode == "main":
             for u in reversed(units[l * per:(l + 1) * per]):
+                if split_db:
+                    _call(lib, "moka_up_bwd:dB", u, sp, None)
                 _call(lib, "moka_down_bwd:dA", u, sp, None)
         else:
             side.wait_stream(main)
             for u in reversed(units[l * per:(l + 1) * per]):
+                if split_db:
+                    _call(lib, "moka_up_bwd:dB", u, sps, None)
                 _call(lib, "moka_down_bwd:dA", u, sps, None)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -558,6 +568,8 @@ def main():
                          "a layer's worth of them is enqueued on a second stream when the layer's chain is, and runs beside the next layer's chain "
                          "(joined before a gradient bucket ships and before the optimizer step); main = the same launches on the one stream; "
                          "off = dA_m and dx from one moka_down_bwd call inside the chain")
+    ap.add_argument("--defer-db", choices=("auto", "on", "off"), default="auto",
+                    help="with --defer-da: dB also leaves the dependency chain (auto: where moka_up_bwd_passes() says dB is a pass of its own, r > 32)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -606,6 +618,8 @@ def main():
     from moka_amd.parallel import FlatGradBucket
     if args.chains > 1:
         args.defer_da = "off"                                    # (the part-batch chains already overlap each other)
+    # dB leaves the dependency chain with dA_m where the library computes it in a pass of its own anyway (r > 32)
+    args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
     if args.chains > 1 and (world > 1 or args.graph != "all"):
         raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")
     wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None),
@@ -654,7 +668,7 @@ def main():
                         with torch.cuda.stream(st):
                             spg = c_void_p(st.cuda_stream)
                             run_forward(lib, ch, spg)
-                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side) if args.defer_da != "off" else None)
+                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side, args.split_db) if args.defer_da != "off" else None)
                     for st in branch:
                         cur.wait_stream(st)          # join
             else:
@@ -669,7 +683,7 @@ def main():
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
                         cs = torch.cuda.current_stream()
-                        run_backward(lib, wl, c_void_p(cs.cuda_stream), hi, lo=lo, defer=(args.defer_da, cs, da_side) if args.defer_da != "off" else None)
+                        run_backward(lib, wl, c_void_p(cs.cuda_stream), hi, lo=lo, defer=(args.defer_da, cs, da_side, args.split_db) if args.defer_da != "off" else None)
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
@@ -700,7 +714,7 @@ def main():
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
                 run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
-                             defer=(args.defer_da, main_stream, live_side) if args.defer_da != "off" else None)
+                             defer=(args.defer_da, main_stream, live_side, args.split_db) if args.defer_da != "off" else None)
         if comm_ev is not None and i >= args.warmup:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
@@ -816,6 +830,7 @@ def main():
             "graph": args.graph,
             "chains": args.chains,
             "defer_dA": args.defer_da,
+            "defer_dB": bool(args.split_db),
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

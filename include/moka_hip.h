@@ -69,8 +69,9 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      500            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
-                                            removed, moka_tune() only in the diagnostics build */
+#define MOKA_VERSION      501            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+                                            removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
+                                            at rank pad 64 depends on T */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
@@ -131,6 +132,10 @@ int moka_ksplit(int T, int C, int r);
  * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy (per 1024 columns for
  * 32 < r <= 64). */
 int moka_ksplit_bwd(int T, int C, int r);
+/* How many passes over gy moka_up_bwd makes when both g_part and dB_acc are requested: 1 (r <= 32, bf16: both contractions come out
+ * of one tile) or 2 (32 < r <= 64, fp32 storage: dB is a kernel of its own).  With 2 a caller loses nothing by requesting the outputs
+ * in two calls, and may enqueue the dB call off its dependency chain -- only the optimizer needs dB (moka_amd.parallel does). */
+int moka_up_bwd_passes(int r, int dtype);
 
 /* ---- forward ----------------------------------------------------------------------- */
 

@@ -48,6 +48,7 @@ SYMBOLS = {
     "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),
     "moka_ksplit_bwd": (c_int, [c_int, c_int, c_int]),
+    "moka_up_bwd_passes": (c_int, [c_int, c_int]),
     # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, stream
     "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
@@ -150,6 +151,20 @@ def ksplit_bwd(T: int, C: int, r: int) -> int:
     if ks < 0:
         raise ValueError(f"unsupported shape for the HIP path: T={T} width={C} r={r} (width must be a multiple of 32)")
     return ks
+
+
+_PASSES = {}
+
+
+def up_bwd_passes(r: int, dtype: int = 0) -> int:
+    """1: moka_up_bwd takes g and dB out of one pass over gy; 2: dB is a pass of its own (it may then leave the dependency chain)."""
+    key = (int(r), int(dtype))
+    if key not in _PASSES:
+        n = load().moka_up_bwd_passes(*key)
+        if n < 0:
+            raise ValueError(f"unsupported rank / storage type for the HIP path: r={r} dtype={dtype}")
+        _PASSES[key] = n
+    return _PASSES[key]
 
 
 def tok_pad(T: int) -> int:

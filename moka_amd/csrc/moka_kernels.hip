@@ -3535,6 +3535,14 @@ int moka_ksplit_bwd(int T, int C, int r) {
     return bwd_ks(T, C, r);
 }
 
+// 1: moka_up_bwd takes g and dB out of ONE pass over gy; 2: dB is a pass of its own (rank pad 64, fp32 storage) -- a caller that asks
+// for the two outputs in separate calls loses nothing then, and may enqueue the dB call off its dependency chain (only the optimizer needs dB)
+int moka_up_bwd_passes(int r, int dtype) {
+    const int RP = rank_pad(r);
+    if (RP < 0 || (dtype != MOKA_BF16 && dtype != MOKA_F32)) return MOKA_EINVAL;
+    return (dtype == MOKA_BF16 && (RP == 16 || gs_wide(RP))) ? 1 : 2;
+}
+
 int moka_ksplit(int T, int C, int r) {
     if (rank_pad(r) < 0 || C < 32 || (C % 32) != 0 || T < 1) return MOKA_EINVAL;
     return fwd_ks(T, C, r);

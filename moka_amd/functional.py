@@ -108,16 +108,16 @@ def up_fwd_(y2: torch.Tensor, hp_tok: torch.Tensor, Bw: torch.Tensor, rt: MokaRo
     return y2
 
 
-def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: torch.Tensor, rt: MokaRouting, r: int,
-           s_out: Sequence[float], dB_acc: Optional[torch.Tensor], dtype: int = 0) -> torch.Tensor:
-    """gy2 [T,d_out] bf16 -> g_part [ks,T,RP]; dB_acc [d_out,r] fp32 += (may be None: skip)."""
+def up_bwd(gy2: torch.Tensor, hp_kmj: Optional[torch.Tensor], BwT: Optional[torch.Tensor], rt: MokaRouting, r: int,
+           s_out: Sequence[float], dB_acc: Optional[torch.Tensor], dtype: int = 0, want_g: bool = True) -> Optional[torch.Tensor]:
+    """gy2 [T,d_out] bf16 -> g_part [ks,T,RP] (want_g=False: skip); dB_acc [d_out,r] fp32 += (may be None: skip)."""
     lib = _lib.load()
     T, d_out = gy2.shape
     RP = _lib.rank_pad(r)
     ks = _lib.ksplit_bwd(T, d_out, r)
-    g_part = torch.empty((ks, T, RP), dtype=torch.float32, device=gy2.device)
-    _lib.check(lib.moka_up_bwd(gy2.data_ptr(), None if hp_kmj is None else hp_kmj.data_ptr(), BwT.data_ptr(),
-                               rt.tok_mod.data_ptr(), _floats(s_out), g_part.data_ptr(),
+    g_part = torch.empty((ks, T, RP), dtype=torch.float32, device=gy2.device) if want_g else None
+    _lib.check(lib.moka_up_bwd(gy2.data_ptr(), None if hp_kmj is None else hp_kmj.data_ptr(), None if BwT is None else BwT.data_ptr(),
+                               rt.tok_mod.data_ptr(), _floats(s_out), None if g_part is None else g_part.data_ptr(),
                                None if dB_acc is None else dB_acc.data_ptr(),
                                T, r, d_out, len(s_out), dtype, _det_opts(gy2.device, T, d_out, r, 1, len(s_out)) if dB_acc is not None else None,
                                _stream_ptr(gy2.device)), "moka_up_bwd")
@@ -226,16 +226,16 @@ def up_fwd_group_(ys: Sequence[torch.Tensor], hp_toks: Sequence[torch.Tensor], B
 
 
 def up_bwd_group(gys: Sequence[torch.Tensor], hp_kmjs: Sequence[torch.Tensor], BwTs: Sequence[torch.Tensor], rt: MokaRouting, r: int,
-                 s_out: Sequence[float], dB_accs: Optional[Sequence[torch.Tensor]]) -> List[torch.Tensor]:
+                 s_out: Sequence[float], dB_accs: Optional[Sequence[torch.Tensor]], want_g: bool = True) -> Optional[List[torch.Tensor]]:
     lib = _lib.load()
     G = len(gys)
     T = gys[0].shape[0]
     RP = _lib.rank_pad(r)
     d_outs = [g_.shape[1] for g_ in gys]
     ks = _lib.ksplit_bwd(T, max(d_outs), r)
-    g_parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=gys[0].device) for _ in range(G)]
+    g_parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=gys[0].device) for _ in range(G)] if want_g else None
     _lib.check(lib.moka_up_bwd_group(_ptrs(gys), _ptrs(hp_kmjs), _ptrs(BwTs), rt.tok_mod.data_ptr(), _floats(s_out),
-                                     _ptrs(g_parts), None if dB_accs is None else _ptrs(dB_accs),
+                                     None if g_parts is None else _ptrs(g_parts), None if dB_accs is None else _ptrs(dB_accs),
                                      T, r, _ints(d_outs), len(s_out), G, _lib.MOKA_BF16,
                                      _det_opts(gys[0].device, T, max(d_outs), r, G, len(s_out)) if dB_accs is not None else None,
                                      _stream_ptr(gys[0].device)),
@@ -471,7 +471,11 @@ class MokaLinearFn(torch.autograd.Function):
             dB_acc = acc[0] if need_B else None
             dA_acc = acc[(1 if need_B else 0):] if need_A else None
         dt = ctx.dt
-        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt)
+        # dB is needed by the optimizer only: where it is a pass of its own over gy anyway (r > 32), it leaves the dependency chain like dA_m
+        split_dB = spec.sinks is not None and spec.defer is not None and dB_acc is not None and _lib.up_bwd_passes(r, dt) == 2
+        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
+        if split_dB:
+            spec.defer(lambda: up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt, want_g=False), [gy2, hp_kmj])
         dx2 = None
         if need_x:                                                   # frozen base: dx only, never dW
             dx2 = torch.matmul(gy2, W) if W is not None else torch.zeros_like(x2)
@@ -603,7 +607,10 @@ class MokaLinearGroupFn(torch.autograd.Function):
             shapes = ([(Bws[g].shape[0], r) for g in range(G)] if need_B else []) + ([(r, x2.shape[1])] * (G * M) if need_A else [])
             flat, acc = _grad_accumulators(shapes, dev) if shapes else (None, [])
         dB_accs = acc[:G] if need_B else None
-        g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs)
+        split_dB = use_sinks and sp.defer is not None and dB_accs is not None and _lib.up_bwd_passes(r, _lib.MOKA_BF16) == 2
+        g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
+        if split_dB:                                                 # (see MokaLinearFn.backward)
+            sp.defer(lambda: up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs, want_g=False), list(gy2) + list(hp_kmjs))
         dx2 = None
         if need_x:
             dx2 = torch.matmul(gy2[0], Ws[0])                        # frozen base: dx only, never dW

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_rank_pad(lib):
-    assert lib.moka_version() == 500
+    assert lib.moka_version() == 501
     assert [lib.moka_tok_pad(t) for t in (1, 32, 33)] == [32, 32, 64]
     assert [lib.moka_rank_pad(r) for r in (1, 4, 8, 16, 17, 32, 33, 64)] == [16, 16, 16, 16, 32, 32, 64, 64]
     assert lib.moka_rank_pad(0) < 0 and lib.moka_rank_pad(65) < 0
@@ -48,6 +48,9 @@ def test_ksplit_covers_width(lib):
     assert lib.moka_ksplit(8192, 5120, 16) == 10 and lib.moka_ksplit(8192, 5120, 64) == 10 and lib.moka_ksplit(8192, 13824, 64) == 11
     assert lib.moka_ksplit(128, 5120, 64) == 20 and lib.moka_ksplit(65536, 5120, 64) == 2
     assert lib.moka_ksplit_bwd(8192, 5120, 16) == 10 and lib.moka_ksplit_bwd(8192, 5120, 64) == 5 and lib.moka_ksplit_bwd(8192, 13824, 64) == 14
+    # passes over gy of moka_up_bwd: one up to rank 32 in bf16 storage, dB on its own beyond and in fp32 storage
+    assert [lib.moka_up_bwd_passes(r, 0) for r in (4, 16, 32, 33, 64)] == [1, 1, 1, 2, 2] and lib.moka_up_bwd_passes(16, 1) == 2
+    assert lib.moka_up_bwd_passes(65, 0) < 0 and lib.moka_up_bwd_passes(16, 7) < 0
     assert lib.moka_ksplit(8192, 16, 16) < 0          # width below one MFMA K step
     assert lib.moka_ksplit(8192, 4100, 16) < 0        # not a multiple of 32
     assert lib.moka_ksplit(8192, 4096, 65) < 0

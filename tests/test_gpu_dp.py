@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(variant, dev):
+def _build(variant, dev, rank=8):
     from moka_amd.decoder import LlamaDims, MokaLlamaStack
     dims = LlamaDims(hidden=256, ff=512, n_heads=4, n_kv_heads=4)
     torch.manual_seed(11)
@@ -34,7 +34,7 @@ def _build(variant, dev):
         from moka_amd.peft_hyper import Linear
 
         def make(d_in, d_out):
-            m = Linear(d_in, d_out, r=(8, 8, 8), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.0,
+            m = Linear(d_in, d_out, r=(rank, rank, rank), lora_alpha=16, lora_nums=3, blc_weight=1.0, blc_alpha=1, lora_dropout=0.0,
                        loramethod="train", bias=False)
             torch.nn.init.normal_(m.weight, std=0.05)
             torch.nn.init.normal_(m.lora_B0.weight, std=0.05)
@@ -45,8 +45,8 @@ def _build(variant, dev):
         def make(d_in, d_out):
             base = torch.nn.Linear(d_in, d_out, bias=False)
             torch.nn.init.normal_(base.weight, std=0.05)
-            m = Linear(base, "image", r=8, lora_alpha=16, lora_dropout=0.0, attn_weight=0.05)
-            m.update_layer("text", 8, lora_alpha=16, lora_dropout=0.0, init_lora_weights=True, use_rslora=False)
+            m = Linear(base, "image", r=rank, lora_alpha=16, lora_dropout=0.0, attn_weight=0.05)
+            m.update_layer("text", rank, lora_alpha=16, lora_dropout=0.0, init_lora_weights=True, use_rslora=False)
             m.set_adapter(["image", "text"])
             for n in ("image", "text"):
                 torch.nn.init.normal_(m.lora_B[n].weight, std=0.05)
@@ -338,15 +338,19 @@ def test_bench_launches_its_own_ranks():
     assert res.returncode != 0 and "GPU(s) visible" in (res.stderr + res.stdout)
 
 
-def test_deferred_dA_on_the_side_stream_gives_the_same_gradients():
+@pytest.mark.parametrize("rank", [8, 40])
+def test_deferred_dA_on_the_side_stream_gives_the_same_gradients(rank):
     """attach(defer_dA=True) (the default) launches the dA_m halves of a layer on a side stream when the layer's backward has been
     enqueued; the flat gradient must equal the in-chain schedule's (same kernels, same operands: only the atomics' order may differ),
-    also with dropout (the mask is a function of (seed, token, column), not of the launch) and under gradient accumulation."""
+    also with dropout (the mask is a function of (seed, token, column), not of the launch) and under gradient accumulation.
+    rank 40 (rank pad 64): dB is a pass of its own there (moka_up_bwd_passes() == 2) and leaves the chain with dA_m."""
     dev = torch.device("cuda:0")
+    from moka_amd import _lib
     from moka_amd.parallel import attach
+    assert _lib.up_bwd_passes(8) == 1 and _lib.up_bwd_passes(32) == 1 and _lib.up_bwd_passes(40) == 2 and _lib.up_bwd_passes(8, _lib.MOKA_F32) == 2
     outs = []
     for defer in (False, True):
-        st, dims = _build("avt", dev)
+        st, dims = _build("avt", dev, rank=rank)
         for m in st.modules():
             if hasattr(m, "lora_dropout_p"):
                 m.lora_dropout_p = 0.1
