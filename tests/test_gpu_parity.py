@@ -379,6 +379,25 @@ def test_r64_13b_mlp_widths_seq4096(shape):
     _stage_check(_full_case(f"full_avt_r64_{d_in}_{d_out}", "avt", 1, 4096, d_in, d_out, 64, 80))
 
 
+def test_r64_forward_chunk_walk_with_three_modalities_per_token_run():
+    """Rank pad 64, 8192 tokens x 5120 columns: the forward workgroups walk two 256-column chunks per split-K slice with the
+    accumulators in registers (moka_xwm_kernel); short alternating spans put all three modalities -- and padding -- inside single 128-token
+    runs (the second walk for the third modality) and span boundaries inside 16-token sub-tiles; r = 48 does not fill its pad."""
+    lay, left, k = [("p", 3), ("t", 40)], 4096 - 43, 0
+    pattern = [("v", 37), ("a", 29), ("t", 41), ("v", 9), ("a", 70), ("t", 5), ("v", 130), ("t", 200), ("a", 11)]
+    while left > 600:
+        kind, n = pattern[k % len(pattern)]
+        lay.append((kind, n))
+        left -= n
+        k += 1
+    lay += [("q", 150), ("t", left - 150)]
+    assert sum(n for _, n in lay) == 4096
+    C._CASES["r48_chunk_walk"] = dict(variant="avt", B=2, S=4096, d_in=5120, d_out=96, r=48, alpha=16.0, w=1.0,
+                                      layouts=[lay, [("t", 3)] + lay[1:]], seed=83, big=True)
+    assert _lib_mod().ksplit(8192, 5120, 48) == 10                  # 20 chunks of 256 columns in 10 slices
+    _stage_check(C.make_case_data("r48_chunk_walk"))
+
+
 @pytest.mark.parametrize("shape", [(8192, 1024), (8192, 28672), (28672, 8192)])
 def test_70b_widths_r16(shape):
     """BASELINE.json configs[4]: Llama-2-70B widths (GQA k/v 8192 -> 1024, MLP 28672), r = 16."""
