@@ -45,3 +45,21 @@ def test_projection_units_follow_the_decoder():
 
 def test_usable_cpus_is_positive():
     assert bench.usable_cpus() >= 1
+
+
+def test_the_pmc_traffic_summary_of_this_round_is_committed():
+    """roofline.traffic of the default bench line is read from this file (bench.PMC_TRAFFIC_FILE, written by tools/pmc_traffic.sh on the
+    GPU box); without it the line carries traffic = null."""
+    import json
+    assert os.path.exists(bench.PMC_TRAFFIC_FILE), bench.PMC_TRAFFIC_FILE
+    d = json.load(open(bench.PMC_TRAFFIC_FILE))
+    assert d["tokens"] == 8192 and d["traffic_bytes_per_layer"] > 1.3e9          # >= the algorithmic 1392.5 MB of the four y launches
+    t, src = bench.pmc_traffic_per_launch(8192, 4)
+    assert src == "profiles/" + os.path.basename(bench.PMC_TRAFFIC_FILE) and 3.4e8 < t < 4.2e8
+
+
+def test_a_missing_traffic_summary_does_not_kill_the_line(monkeypatch, capsys):
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", os.path.join(ROOT, "profiles", "no_such_file.json"))
+    t, src = bench.pmc_traffic_per_launch(8192, 4)
+    assert t is None and src.startswith("missing: ")
+    assert "is missing" in capsys.readouterr().err
