@@ -129,8 +129,8 @@ int moka_tok_pad(int T);
  * per 256 columns, so C / 256 rounded up is an upper bound for any T).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
- * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy (per 1024 columns for
- * 32 < r <= 64). */
+ * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy; 32 < r <= 64: a whole number of
+ * 256-column chunks per slice chosen from T and the device's CU count, as in moka_ksplit (at most C / 256 rounded up). */
 int moka_ksplit_bwd(int T, int C, int r);
 /* How many passes over gy moka_up_bwd makes when both g_part and dB_acc are requested: 1 (r <= 32, bf16: both contractions come out
  * of one tile) or 2 (32 < r <= 64, fp32 storage: dB is a kernel of its own).  With 2 a caller loses nothing by requesting the outputs

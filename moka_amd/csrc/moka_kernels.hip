@@ -2593,10 +2593,11 @@ __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_ker
 // independent: a row only accumulates in the chain of its own modality).  13B widths, r = 64, 8192 tokens: forward projection + interaction
 // 13.6 + 7.8 -> 11.0 + 4.8 ms per pass.
 // ------------------------------------------------------------------------------------------
-template <int RP>
+// ONEW: one weight set for every modality (the gy pass of the backward: x = gy, A[0][0] = Bw^T, s_mod = s_out): one slot, no second walk.
+template <int RP, bool ONEW>
 __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK;
+    constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK, NSLOT = ONEW ? 1 : 2;
     constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality slot, rank tile)
     static_assert(NU == 2, "a chunk streams in two units");
     bf16x8* wl = (bf16x8*)smem;                              // [2][NT][NKS][64]
@@ -2622,15 +2623,18 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
     int mrow = MOKA_MOD_NONE;
     if (live) mrow = a.tok_mod[16 * sub + i];                // padded past T with MOKA_MOD_NONE
     unsigned pm = 0;
+    if (ONEW) { if (__any(mrow < a.M)) pm = 1u; }
+    else {
 #pragma unroll
-    for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+        for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+    }
     if (lane == 0) s_wpm[wave] = pm;
     __syncthreads();
     unsigned pmB = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
     if (pmB == 0) return;                                    // a run of padding only: nothing to write (block uniform)
-    const bool mixed = (pm & (pm - 1)) != 0;                 // span boundary inside my 16 tokens (wave uniform)
+    const bool mixed = !ONEW && (pm & (pm - 1)) != 0;        // span boundary inside my 16 tokens (wave uniform)
     const unsigned trow = (unsigned)min(16 * min(sub, nsub - 1) + i, a.T - 1);
 
     f32x4 acc[NT];
@@ -2642,18 +2646,18 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
     while (rest) {                                           // block uniform: one walk per pair of modalities in the run
         const int m0 = __ffs(rest) - 1;
         rest &= rest - 1;
-        const int m1 = rest ? __ffs(rest) - 1 : -1;
+        const int m1 = (!ONEW && rest) ? __ffs(rest) - 1 : -1;
         if (m1 >= 0) rest &= rest - 1;
         const unsigned mset = (1u << m0) | (m1 >= 0 ? (1u << m1) : 0u);
         const bool mine = (pm & mset) != 0;                  // wave uniform
         if (!first && mine) issue(xA, ch0, 0);
         first = false;
         // the fragments of the next chunk are requested (L2) before the current one is computed and go to LDS behind the barrier
-        bf16x8 wp[2][NT * FR / 512];
+        bf16x8 wp[NSLOT][NT * FR / 512];
         auto wload = [&](int ch) {
             const int cbn = ch * KW, nkn = min(NKS, (a.C - cbn) >> 5);
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
+            for (int sl = 0; sl < NSLOT; ++sl) {
                 const int m = sl ? m1 : m0;
                 if (m < 0) continue;
 #pragma unroll
@@ -2671,7 +2675,7 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
             const int nks = min(NKS, (a.C - cb0) >> 5);
             __syncthreads();                                 // the previous chunk's fragments are no longer read
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
+            for (int sl = 0; sl < NSLOT; ++sl) {
                 if ((sl ? m1 : m0) < 0) continue;
 #pragma unroll
                 for (int u = 0; u < NT * FR / 512; ++u) wl[(size_t)sl * NT * FR + tid + 512 * u] = wp[sl][u];
@@ -2686,10 +2690,10 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
                     bf16x8 xg = (ks < nks) ? xb[q] : z8;
                     if (a.drop[0].thr) xg = drop_apply(xg, drop_keep8(a.drop[0], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
 #pragma unroll
-                    for (int sl = 0; sl < 2; ++sl) {
+                    for (int sl = 0; sl < NSLOT; ++sl) {
                         const int m = sl ? m1 : m0;
                         if (m < 0 || !(pm & (1u << m))) continue;     // wave uniform
-                        const bf16x8 xm = (!mixed || mrow == m) ? xg : z8;
+                        const bf16x8 xm = (ONEW || !mixed || mrow == m) ? xg : z8;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[nt] = MFMA16(wl[((size_t)sl * NT + nt) * FR + ks * 64 + lane], xm, acc[nt]);
@@ -3314,6 +3318,7 @@ static int launch_gs_auto(GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     return check_launch("moka_gs_kernel");
 }
 
+static int bwd_kw(int T, int C, int r);
 template <int RP, bool WITH_DB>
 static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) {
     GyBatch gb = gb_in;                                  // (launch_gy_t fills in the grid map)
@@ -3323,6 +3328,28 @@ static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) 
         if (g_tune_gy_form == 2 || (g_tune_gy_form == 0 && (RP == 32 || !(nz > 1 && Cmax > 8192)))) return launch_gs_auto<RP, WITH_DB>(gb, nz, Cmax, st);
     }
     if constexpr (RP == 64 && !WITH_DB) {
+        if (g_tune_gy_form != 1) {
+            // the chunk-walk kernel of the forward with one weight set (moka_xwm_kernel<64, true>): a launch per projection
+            const int T = gb.z[0].T;
+            const int kw = bwd_kw(T, Cmax, gb.z[0].r), ks = (Cmax + kw - 1) / kw;
+            for (int z = 0; z < nz; ++z) {
+                const GyArgs& ga = gb.z[z];
+                XaArgs xa;
+                memset(&xa, 0, sizeof(xa));
+                xa.x = ga.gy; xa.tok_mod = ga.tok_mod; xa.T = T; xa.C = ga.C; xa.r = ga.r; xa.M = ga.M;
+                xa.part[0] = ga.g_part;
+                xa.drop[0].inv_keep = 1.f;
+                for (int m = 0; m < MOKA_MAX_MOD; ++m) { xa.s_mod[m] = ga.s_mod[m]; xa.A[0][m] = ga.BwT; }
+                const int ksg = (ga.C + kw - 1) / kw;
+                // (a narrower member of a group leaves its upper slices zero: the interaction backward sums ks slices for every member)
+                if (ksg < ks && hipMemsetAsync(ga.g_part + (size_t)ksg * T * 64, 0, (size_t)(ks - ksg) * T * 64 * 4, st) != hipSuccess)
+                    return fail(MOKA_ELAUNCH, "moka_up_bwd: memset");
+                const size_t lds = (size_t)4 * 8 * 1024;
+                ensure_lds((const void*)moka_xwm_kernel<64, true>, lds);
+                hipLaunchKernelGGL((moka_xwm_kernel<64, true>), dim3(ksg, (T + 127) / 128), dim3(512), lds, st, xa, kw / 256);
+            }
+            return check_launch("moka_xwm_kernel");
+        }
         // rank pad 64: 128 columns per wave, one split-K slice per 1024 columns (bwd_kw): the rank-space backward reads half as many
         // slices (7.2 -> 6.3 ms per step); this pass itself is unchanged (150-166 VGPRs leave one block per CU where 95 left two,
         // which cancels the halved eight-wave sums; capped at 128 registers it spills and loses 9 ms)
@@ -3445,8 +3472,17 @@ static int fwd_ks(int T, int C, int r) { const int kw = fwd_kw(T, C, r); return 
 // the LDS-DMA gy pass (g and dB out of one LDS tile) also at rank pad 32: 13B widths 12.0 -> 10.4 ms per pass.  At rank pad 64 it loses
 // (115 KB of LDS: one workgroup per CU, 48 MFMAs per tile and wave: 28.8 against 24.7 ms for the g-only pass + the wide dB kernel)
 static bool gs_wide(int RP) { return RP == 32 && g_tune_gy_form != 1; }
-static int bwd_kw(int r) { return rank_pad(r) == 64 ? 1024 : 512; }                              // columns per g_part slice
-static int bwd_ks(int /*T*/, int C, int r) { const int kw = bwd_kw(r); return (C + kw - 1) / kw; }
+// columns per g_part slice: 512; rank pad 64: the gy pass is the chunk-walk kernel of the forward (x = gy, one weight set = Bw^T): whole
+// 256-column chunks, as few slices as still give every CU two workgroups of 128 tokens ("gy_form" 1: the first form, 1024 columns)
+static int bwd_kw(int T, int C, int r) {
+    if (rank_pad(r) != 64) return 512;
+    if (g_tune_gy_form == 1) return 1024;
+    const int nch = (C + 255) / 256, ntb = (T + 127) / 128;
+    int want = (((g_tune_gy_ng >= 1 && g_tune_gy_ng <= 6) ? g_tune_gy_ng : 2) * num_cu() + ntb - 1) / ntb;
+    want = want < 1 ? 1 : (want > nch ? nch : want);
+    return (nch + want - 1) / want * 256;
+}
+static int bwd_ks(int T, int C, int r) { const int kw = bwd_kw(T, C, r); return (C + kw - 1) / kw; }
 
 // ---- fp32 storage launchers (one projection at a time)
 static void f32_common(F32Args& a, const uint8_t* tok_mod, int T, int C, int r, int M) {
@@ -3603,8 +3639,8 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             else {
                 const int kw = fwd_kw(T, d_in, r);
                 const size_t lds = (size_t)2 * 4 * 8 * 1024;
-                ensure_lds((const void*)moka_xwm_kernel<64>, lds);
-                hipLaunchKernelGGL((moka_xwm_kernel<64>), dim3((d_in + kw - 1) / kw, (T + 127) / 128), dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                ensure_lds((const void*)moka_xwm_kernel<64, false>, lds);
+                hipLaunchKernelGGL((moka_xwm_kernel<64, false>), dim3((d_in + kw - 1) / kw, (T + 127) / 128), dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
                 rc = check_launch("moka_xwm_kernel");
             }
         } else
@@ -3766,7 +3802,7 @@ int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const vo
     int rc = MOKA_OK;
     if (dtype == MOKA_F32) {
         // slices of the widest projection of the group (moka_ksplit_bwd): narrower members leave their upper slices zero
-        const int kw = bwd_kw(r), ks = (Cmax + kw - 1) / kw;
+        const int kw = bwd_kw(T, Cmax, r), ks = (Cmax + kw - 1) / kw;
         for (int g = 0; g < G; ++g) {
             if (g_part && g_part[g]) {
                 if (!BwT || !BwT[g]) return fail(MOKA_EINVAL, "moka_up_bwd: g_part requested without Bw (fp32: pass Bw as BwT)");
