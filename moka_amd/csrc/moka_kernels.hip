@@ -2594,13 +2594,15 @@ __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_ker
 // 13.6 + 7.8 -> 11.0 + 4.8 ms per pass.
 // ------------------------------------------------------------------------------------------
 // ONEW: one weight set for every modality (the gy pass of the backward: x = gy, A[0][0] = Bw^T, s_mod = s_out): one slot, no second walk.
-template <int RP, bool ONEW>
-__global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cps) {
+// G > 1: G projections that read the same x (q/k/v, gate/up), each through its own dropout mask, in ONE pass over x: G weight sets in
+// one modality slot (G x 32 KB), a walk per modality of the run.
+template <int RP, bool ONEW, int G>
+__global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaArgs a, int cps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK, NSLOT = ONEW ? 1 : 2;
+    constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK, NSLOT = (ONEW || G > 1) ? 1 : 2;
     constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality slot, rank tile)
     static_assert(NU == 2, "a chunk streams in two units");
-    bf16x8* wl = (bf16x8*)smem;                              // [2][NT][NKS][64]
+    bf16x8* wl = (bf16x8*)smem;                              // [NSLOT][G][NT][NKS][64]
     __shared__ unsigned s_wpm[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -2637,23 +2639,25 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
     const bool mixed = !ONEW && (pm & (pm - 1)) != 0;        // span boundary inside my 16 tokens (wave uniform)
     const unsigned trow = (unsigned)min(16 * min(sub, nsub - 1) + i, a.T - 1);
 
-    f32x4 acc[NT];
+    f32x4 acc[G][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[gi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     unsigned rest = pmB;
     bool first = true;
     while (rest) {                                           // block uniform: one walk per pair of modalities in the run
         const int m0 = __ffs(rest) - 1;
         rest &= rest - 1;
-        const int m1 = (!ONEW && rest) ? __ffs(rest) - 1 : -1;
+        const int m1 = (NSLOT == 2 && rest) ? __ffs(rest) - 1 : -1;
         if (m1 >= 0) rest &= rest - 1;
         const unsigned mset = (1u << m0) | (m1 >= 0 ? (1u << m1) : 0u);
         const bool mine = (pm & mset) != 0;                  // wave uniform
         if (!first && mine) issue(xA, ch0, 0);
         first = false;
         // the fragments of the next chunk are requested (L2) before the current one is computed and go to LDS behind the barrier
-        bf16x8 wp[NSLOT][NT * FR / 512];
+        bf16x8 wp[NSLOT][G][NT * FR / 512];
         auto wload = [&](int ch) {
             const int cbn = ch * KW, nkn = min(NKS, (a.C - cbn) >> 5);
 #pragma unroll
@@ -2661,12 +2665,14 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
                 const int m = sl ? m1 : m0;
                 if (m < 0) continue;
 #pragma unroll
-                for (int u = 0; u < NT * FR / 512; ++u) {
-                    const int e = tid + 512 * u;
-                    const int ln = e & 63, ks = (e >> 6) % NKS, nt = e / FR;
-                    // rank rows >= r do not exist: clamp the row, the result rows are zeroed when the slice is written
-                    wp[sl][u] = (ks < nkn) ? *(const bf16x8*)(a.A[0][m] + ((size_t)min(nt * 16 + (ln & 15), a.r - 1) * a.C + cbn + 32 * ks + 8 * (ln >> 4)) * 2) : z8;
-                }
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int u = 0; u < NT * FR / 512; ++u) {
+                        const int e = tid + 512 * u;
+                        const int ln = e & 63, ks = (e >> 6) % NKS, nt = e / FR;
+                        // rank rows >= r do not exist: clamp the row, the result rows are zeroed when the slice is written
+                        wp[sl][gi][u] = (ks < nkn) ? *(const bf16x8*)(a.A[gi][m] + ((size_t)min(nt * 16 + (ln & 15), a.r - 1) * a.C + cbn + 32 * ks + 8 * (ln >> 4)) * 2) : z8;
+                    }
             }
         };
         wload(ch0);
@@ -2678,7 +2684,9 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
             for (int sl = 0; sl < NSLOT; ++sl) {
                 if ((sl ? m1 : m0) < 0) continue;
 #pragma unroll
-                for (int u = 0; u < NT * FR / 512; ++u) wl[(size_t)sl * NT * FR + tid + 512 * u] = wp[sl][u];
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int u = 0; u < NT * FR / 512; ++u) wl[(size_t)(sl * G + gi) * NT * FR + tid + 512 * u] = wp[sl][gi][u];
             }
             __syncthreads();
             if (ch + 1 < ch1) wload(ch + 1);
@@ -2687,16 +2695,20 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
 #pragma unroll
                 for (int q = 0; q < HK; ++q) {
                     const int ks = HK * half + q;
-                    bf16x8 xg = (ks < nks) ? xb[q] : z8;
-                    if (a.drop[0].thr) xg = drop_apply(xg, drop_keep8(a.drop[0], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
+                    const bf16x8 xq = (ks < nks) ? xb[q] : z8;
 #pragma unroll
-                    for (int sl = 0; sl < NSLOT; ++sl) {
-                        const int m = sl ? m1 : m0;
-                        if (m < 0 || !(pm & (1u << m))) continue;     // wave uniform
-                        const bf16x8 xm = (ONEW || !mixed || mrow == m) ? xg : z8;
+                    for (int gi = 0; gi < G; ++gi) {
+                        bf16x8 xg = xq;
+                        if (a.drop[gi].thr) xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[nt] = MFMA16(wl[((size_t)sl * NT + nt) * FR + ks * 64 + lane], xm, acc[nt]);
+                        for (int sl = 0; sl < NSLOT; ++sl) {
+                            const int m = sl ? m1 : m0;
+                            if (m < 0 || !(pm & (1u << m))) continue;     // wave uniform
+                            const bf16x8 xm = (ONEW || !mixed || mrow == m) ? xg : z8;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[gi][nt] = MFMA16(wl[((size_t)(sl * G + gi) * NT + nt) * FR + ks * 64 + lane], xm, acc[gi][nt]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -2711,13 +2723,15 @@ __global__ void __launch_bounds__(512, 4) moka_xwm_kernel(const XaArgs a, int cp
         const float sc = mod_scale(a.s_mod, mrow);           // 0 for tokens of no modality
         const int t = 16 * sub + i;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            MFMA_SETTLE(acc[nt]);
-            f32x4 v;
+        for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) v[reg] = (16 * nt + 4 * g + reg < a.r && mrow < a.M) ? acc[nt][reg] * sc : 0.f;
-            if (t < a.T) *(f32x4*)(a.part[0] + ((size_t)blockIdx.x * a.T + t) * RP + 16 * nt + 4 * g) = v;
-        }
+            for (int nt = 0; nt < NT; ++nt) {
+                MFMA_SETTLE(acc[gi][nt]);
+                f32x4 v;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) v[reg] = (16 * nt + 4 * g + reg < a.r && mrow < a.M) ? acc[gi][nt][reg] * sc : 0.f;
+                if (t < a.T) *(f32x4*)(a.part[gi] + ((size_t)blockIdx.x * a.T + t) * RP + 16 * nt + 4 * g) = v;
+            }
     }
 }
 
@@ -3329,7 +3343,7 @@ static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) 
     }
     if constexpr (RP == 64 && !WITH_DB) {
         if (g_tune_gy_form != 1) {
-            // the chunk-walk kernel of the forward with one weight set (moka_xwm_kernel<64, true>): a launch per projection
+            // the chunk-walk kernel of the forward with one weight set (moka_xwm_kernel<64, true, 1>): a launch per projection
             const int T = gb.z[0].T;
             const int kw = bwd_kw(T, Cmax, gb.z[0].r), ks = (Cmax + kw - 1) / kw;
             for (int z = 0; z < nz; ++z) {
@@ -3345,8 +3359,8 @@ static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) 
                 if (ksg < ks && hipMemsetAsync(ga.g_part + (size_t)ksg * T * 64, 0, (size_t)(ks - ksg) * T * 64 * 4, st) != hipSuccess)
                     return fail(MOKA_ELAUNCH, "moka_up_bwd: memset");
                 const size_t lds = (size_t)4 * 8 * 1024;
-                ensure_lds((const void*)moka_xwm_kernel<64, true>, lds);
-                hipLaunchKernelGGL((moka_xwm_kernel<64, true>), dim3(ksg, (T + 127) / 128), dim3(512), lds, st, xa, kw / 256);
+                ensure_lds((const void*)moka_xwm_kernel<64, true, 1>, lds);
+                hipLaunchKernelGGL((moka_xwm_kernel<64, true, 1>), dim3(ksg, (T + 127) / 128), dim3(512), lds, st, xa, kw / 256);
             }
             return check_launch("moka_xwm_kernel");
         }
@@ -3621,8 +3635,9 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
     }
     const int RP = rank_pad(r);
     // r <= 16: the weights of all modalities (and of all G projections) are resident per wave -> one launch for the group;
-    // wider ranks: the same kernel with RP / 16 rank tiles, one launch per projection.  One split-K slice per 512 columns.
-    const int per_launch = (RP == 16) ? G : 1;
+    // rank pad 32: one launch per projection.  One split-K slice per 512 columns (rank pad 64: fwd_kw).
+    // rank pad 64: the chunk-walk kernel takes the whole group too (13B widths: x.A^T 11.05 -> 9.6 ms per pass: q/k/v 3 x 28 -> 70 us)
+    const int per_launch = (RP == 16 || (RP == 64 && use_xw(64) && g_tune_xa_form != 3)) ? G : 1;
     for (int g0 = 0; g0 < G; g0 += per_launch) {
         XaArgs xa;
         memset(&xa, 0, sizeof(xa));
@@ -3638,9 +3653,20 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             else if (fwd_kw(T, d_in, r) == 256 && g_tune_xa_form == 3) rc = launch_xw<64, 1>(xa, (hipStream_t)stream);
             else {
                 const int kw = fwd_kw(T, d_in, r);
-                const size_t lds = (size_t)2 * 4 * 8 * 1024;
-                ensure_lds((const void*)moka_xwm_kernel<64, false>, lds);
-                hipLaunchKernelGGL((moka_xwm_kernel<64, false>), dim3((d_in + kw - 1) / kw, (T + 127) / 128), dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                const dim3 grid((d_in + kw - 1) / kw, (T + 127) / 128);
+                if (per_launch == 1) {
+                    const size_t lds = (size_t)2 * 4 * 8 * 1024;
+                    ensure_lds((const void*)moka_xwm_kernel<64, false, 1>, lds);
+                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 1>), grid, dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                } else if (per_launch == 2) {
+                    const size_t lds = (size_t)2 * 4 * 8 * 1024;
+                    ensure_lds((const void*)moka_xwm_kernel<64, false, 2>, lds);
+                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 2>), grid, dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                } else {
+                    const size_t lds = (size_t)3 * 4 * 8 * 1024;
+                    ensure_lds((const void*)moka_xwm_kernel<64, false, 3>, lds);
+                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 3>), grid, dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                }
                 rc = check_launch("moka_xwm_kernel");
             }
         } else
