@@ -556,6 +556,26 @@ def test_group_matches_single_projection_nodes(cfg):
     _group_vs_singles(cfg)
 
 
+def _scrambled_layout(S=4096):
+    """Short alternating spans: all three modalities -- and padding -- inside single 128-token runs, span boundaries inside 16-token sub-tiles."""
+    lay, left, k = [("p", 3), ("t", 40)], S - 43, 0
+    pattern = [("v", 37), ("a", 29), ("t", 41), ("v", 9), ("a", 70), ("t", 5), ("v", 130), ("t", 200), ("a", 11)]
+    while left > 600:
+        kind, n = pattern[k % len(pattern)]
+        lay.append((kind, n))
+        left -= n
+        k += 1
+    return lay + [("q", 150), ("t", left - 150)]
+
+
+@pytest.mark.parametrize("d_outs", [(96, 64, 128), (160, 96)])
+def test_rank_pad_64_group_walks_chunks_with_three_modalities_per_run(d_outs):
+    """Rank pad 64, 8192 tokens x 5120 columns: the grouped forward (moka_xwm_kernel<64, false, G>: G weight sets in one modality slot, one
+    walk over the block's chunks per modality of its token run) against the same projections one at a time (two modality slots)."""
+    lay = _scrambled_layout()
+    _group_vs_singles(dict(variant="avt", B=2, S=4096, d_in=5120, d_outs=d_outs, r=48, p=0.1, layouts=[lay, [("t", 3)] + lay[1:]]))
+
+
 def _random_group_cfg(seed):
     import random
     rnd = random.Random(100 + seed)
