@@ -2587,8 +2587,8 @@ __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_ker
 // F (rank pad 64): independent waves as above, but a workgroup keeps its 8 sub-tiles (128 tokens, one per wave) and walks `cps`
 // consecutive 256-column chunks with the accumulators in registers: one split-K slice per cps chunks instead of one per chunk.  At
 // rank 64 a slice row is 256 bytes -- with one slice per 256 columns the forward WROTE half as many bytes as it read (and the
-// interaction kernel read them back: 20 slices of 2 MB per 5120-wide projection); with the slices sized so that the grid just fills the
-// chip (4 at 8192 tokens) that traffic is a tenth.  The weight fragments of a chunk are staged per chunk (two modality slots, 64 KB: two
+// interaction kernel read them back: 20 slices of 2 MB per 5120-wide projection); with the slices sized so that the grid gives every CU
+// three workgroups (fwd_kw: 10 slices at 8192 tokens x 5120 columns) that traffic is halved.  The weight fragments of a chunk are staged per chunk (two modality slots, 64 KB: two
 // workgroups per CU), requested from L2 one chunk ahead; a token run with three modalities takes a second walk for the third (rows are
 // independent: a row only accumulates in the chain of its own modality).  13B widths, r = 64, 8192 tokens: forward projection + interaction
 // 13.6 + 7.8 -> 11.0 + 4.8 ms per pass.
