@@ -1265,6 +1265,166 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 }
 
 // ------------------------------------------------------------------------------------------
+// E (rank pad 64, G > 1): dx += sum_g mask_g o (dh_g . A_g,m(t))  in ONE read-modify-write pass over dx.
+// The per-wave-resident weights of moka_expand_kernel do not fit three projections at this rank (250 registers, one wave per SIMD: it
+// lost), so the roles are turned round: a workgroup (8 waves) keeps 128 TOKENS -- wave w the 16-token tile w, its G x (hi, lo) pack
+// rows resident as MFMA B fragments (48 registers) -- and walks the columns in chunks of 128; the chunk's weights of all G projections
+// (G x 16 KB of A^T in fragment order) are staged in LDS for the eight waves, requested from L2 one step ahead into registers
+// (the moka_xwm_kernel scheme).  One walk step per (chunk, modality of the token run): every token is multiplied with the
+// staged modality's weights and the result counts only for the tokens OF that modality (selected on the output, tokens are MFMA
+// columns); then each projection's product passes its own dropout mask and joins the sum, and the dx tile is written once per chunk.
+// q/k/v (gate/up) cost one pass over dx instead of three (two).
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RP = 64, KH = 2, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 16 fragments (1 KB each) per projection and chunk
+    constexpr int PER = G * NF * 64 / 512;                                   // fragments per thread and step (2 G)
+    bf16x8* wl = (bf16x8*)smem;                                              // [G][NQ][2][KH][64]
+    __shared__ unsigned s_wpm[8];
+    const ExpandArgs& a = ab.z[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ntiles = (a.T + 15) >> 4;
+    const int tile = blockIdx.y * 8 + wave;
+    const bool live = tile < ntiles;
+    const int t = min((min(tile, ntiles - 1) << 4) + i, a.T - 1);
+    const bool valid = live && ((tile << 4) + i) < a.T;
+    const int nch = (a.C + CWK - 1) / CWK;
+    const int ch0 = blockIdx.x * chunks_per_block, ch1 = min(nch, ch0 + chunks_per_block);
+    if (ch0 >= ch1) return;
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // the dx tiles: two in flight (the next chunk's is requested before the current one is computed)
+    unsigned char* orow0 = a.out + ((size_t)t * a.C + 8 * g) * 2;
+    bf16x8 oA[NQ], oB[NQ];
+    auto issue_o = [&](bf16x8 (&o)[NQ], int ch_) {
+        const int cb = min(ch_, ch1 - 1) * CWK;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
+    };
+    issue_o(oA, ch0);
+
+    // my token's pack rows of the G projections: B fragments [hi | lo] x KH, resident
+    bf16x8 bh[G][KH], bl[G][KH];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const unsigned char* prp = (const unsigned char*)ab.z[gi].pack + (size_t)t * (2 * RP * 2);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+            bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+        }
+    }
+    const int mrow = live ? (int)a.tok_mod[(tile << 4) + i] : MOKA_MOD_NONE;     // padded past T with MOKA_MOD_NONE
+    unsigned pm = 0;
+#pragma unroll
+    for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+    if (lane == 0) s_wpm[wave] = pm;
+    __syncthreads();
+    unsigned pmB = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
+    if (pmB == 0) return;                                                    // a run of padding only (block uniform)
+
+    // walk steps: (chunk, modality of the run) pairs; the fragments of the next step are requested while the current one is multiplied
+    bf16x8 wp[PER];
+    auto wload = [&](int ch, int m) {
+        const int cb = ch * CWK;
+        const unsigned char* wm[G];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) wm[gi] = ab.z[gi].W[0] + (size_t)m * a.C * RP * 2;      // (the shadows of the modalities follow each other)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 512 * (u & 1);                               // (q, p, kh, lane) of projection u / 2: 1024 fragments each
+            const int ln = e & 63, kh = (e >> 6) & 1, p = (e >> 7) & 1, q = e >> 8;
+            const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);   // columns >= C are never stored
+            wp[u] = *(const bf16x8*)(wm[u >> 1] + ((size_t)c * RP + 32 * kh + 8 * (ln >> 4)) * 2);
+        }
+    };
+    auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+        const int cb = ch * CWK;
+        issue_o(onext, ch + 1);
+        float sum[NQ][8];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[q][e] = 0.f;
+        unsigned rest = pmB;
+        while (rest) {                                                       // block uniform
+            const int m = __builtin_ctz(rest);
+            rest &= rest - 1;
+            __syncthreads();                                                 // the previous step's fragments are no longer read
+#pragma unroll
+            for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+            __syncthreads();
+            if (rest) wload(ch, __builtin_ctz(rest));
+            else if (ch + 1 < ch1) wload(ch + 1, __builtin_ctz(pmB));
+            if (!(pm & (1u << m))) continue;                                 // none of my tokens has this modality (wave uniform)
+            const bool mine = mrow == m;
+            // (the keep masks do not depend on the modality: left alone the compiler computes the G x NQ masks of a chunk in front of
+            //  this loop and keeps 48 registers for them -- 62 spills at G = 3; opaque, they are made where they are used)
+            unsigned trow = (unsigned)t;
+            asm volatile("" : "+v"(trow));
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
+                const ExpandArgs& ag = ab.z[gi];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    // (one 32-column block at a time: 4 fragments from LDS, 8 MFMAs, its epilogue -- the fence keeps the compiler from
+                    //  fetching the fragments of all blocks first, which costs 77 spilled registers at G = 3)
+                    f32x4 d[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kh = 0; kh < KH; ++kh) {
+                            const bf16x8 wf = wl[(((size_t)gi * NQ + q) * 2 + p) * KH * 64 + kh * 64 + lane];
+                            d[p] = MFMA16(wf, bh[gi][kh], d[p]);
+                            d[p] = MFMA16(wf, bl[gi][kh], d[p]);
+                        }
+                    }
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = mine ? d[e >> 2][e & 3] : 0.f;
+                    float dsc = 1.f;
+                    if (ag.drop.thr) {
+                        const KeepMask keep = drop_keep8(ag.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+                        dsc = ag.drop.inv_keep;
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
+                            v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
+                            v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum[q][e] = fmaf(v[e], dsc, sum[q][e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (pm) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (cb + 32 * q >= a.C) continue;                            // C % 32 == 0
+                union { bf16x8 b; unsigned u[4]; } ou, res;
+                ou.b = o[q];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2)
+                    res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[q][2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[q][2 * w2 + 1]);
+                if (valid) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+            }
+        }
+    };
+    wload(ch0, __builtin_ctz(pmB));
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        step(oA, oB, ch);
+        if (ch + 1 < ch1) step(oB, oA, ch + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // G: wgrad  acc[m][c][k] += sum_t in[t][c] * pack_kmj[m][.][k][t]
 // ------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -2982,9 +3142,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
 #else
-static constexpr int g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -3127,8 +3287,24 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         else if (W_CK) { if (g_tune_expand_nq == 2) launch_expand_t<64, 2, true, 1, 2>(ab, nz, st); else launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); }
         else if (g_tune_expand_nq == 3) launch_expand_t<64, 2, false, 1, 2>(ab, nz, st);            // the per-tile form (A/B)
         else launch_expand_t<64, 4, false, 1, 2, true>(ab, nz, st);
+    } else if (RP == 64) {                               // projections sharing dx at rank pad 64: the token-owning form (moka_dxg_kernel)
+        const int T = ab.z[0].T, C = ab.z[0].C;
+        const int nch = (C + 127) / 128, ntb = (T + 127) / 128;
+        // column ranges: three workgroups per CU, one resident (13B widths, dx + dA per pass with 1 / 2 / 3 / 4 / 6: 29.4 / 28.3 / 27.7 / 28.1 / 28.4 ms; per-projection passes: 30.7)
+        int want = ((g_tune_dx_group >= 2 ? g_tune_dx_group - 1 : 3) * num_cu() + ntb - 1) / ntb;
+        want = want < 1 ? 1 : (want > nch ? nch : want);
+        const int cpb = (nch + want - 1) / want;
+        const dim3 grid((nch + cpb - 1) / cpb, ntb);
+        if (nz == 2) {
+            ensure_lds((const void*)moka_dxg_kernel<2>, (size_t)2 * 16 * 1024);
+            hipLaunchKernelGGL((moka_dxg_kernel<2>), grid, dim3(512), (size_t)2 * 16 * 1024, st, ab, cpb);
+        } else {
+            ensure_lds((const void*)moka_dxg_kernel<3>, (size_t)3 * 16 * 1024);
+            hipLaunchKernelGGL((moka_dxg_kernel<3>), grid, dim3(512), (size_t)3 * 16 * 1024, st, ab, cpb);
+        }
+        return check_launch("moka_dxg_kernel");
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
-        // (tried for rank pad 64 too: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass)
+        // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass)
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
         else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st);
     }
@@ -3557,6 +3733,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "expand_depth")) g_tune_expand_depth = value;
     else if (!strcmp(key, "xa_ng")) g_tune_xa_ng = value;
     else if (!strcmp(key, "xa_form")) g_tune_xa_form = value;
+    else if (!strcmp(key, "dx_group")) g_tune_dx_group = value;
     else if (!strcmp(key, "gy_form")) g_tune_gy_form = value;
     else if (!strcmp(key, "expand_nq")) g_tune_expand_nq = value;
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
@@ -3986,7 +4163,8 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
             for (int m = 0; m < M; ++m) a.W[m] = (const unsigned char*)AT[g] + (size_t)m * d_in * RP * 2;
             a.T = T; a.C = d_in; a.r = r; a.M = M; a.drop = drop[g];
         }
-        if (fused) {
+        // rank pad 64: the group's dx terms in one pass over dx too (moka_dxg_kernel; "dx_group" 1: one pass per projection)
+        if (fused || (RP == 64 && G > 1 && g_tune_dx_group != 1)) {
             rc = launch_expand<false>(eb, G, RP, (hipStream_t)stream);
         } else {
             for (int g = 0; g < G && !rc; ++g) {
