@@ -1425,6 +1425,107 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
 }
 
 // ------------------------------------------------------------------------------------------
+// E (rank pad 64): y += hp . Bw^T in the token-owning form of moka_dxg_kernel: a workgroup keeps 128 tokens (wave w the 16-token tile w,
+// its (hi, lo) pack row resident: 16 registers) and walks its column range in chunks of 128; the chunk's 16 KB of Bw are staged in LDS
+// for the eight waves, requested from L2 one chunk ahead.  ~100 registers instead of the 260 of the column-owning kernel (one wave per
+// SIMD, every wave reading its 256-byte pack rows and holding 64 registers of weights): four waves per SIMD.  blockIdx.z = problem.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RP = 64, KH = 2, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 16 fragments (1 KB each) per chunk
+    constexpr int PER = NF * 64 / 512;                                       // 2 fragments per thread and chunk
+    bf16x8* wl = (bf16x8*)smem;                                              // [NQ][2][KH][64]
+    const ExpandArgs& a = ab.z[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ntiles = (a.T + 15) >> 4;
+    const int tile = blockIdx.y * 8 + wave;
+    const bool live = tile < ntiles;
+    const int t = min((min(tile, ntiles - 1) << 4) + i, a.T - 1);
+    const bool valid = live && ((tile << 4) + i) < a.T;
+    const int nch = (a.C + CWK - 1) / CWK;
+    const int ch0 = blockIdx.x * chunks_per_block, ch1 = min(nch, ch0 + chunks_per_block);
+    if (ch0 >= ch1) return;                                                  // a narrower problem of the batch (block uniform)
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    unsigned char* orow0 = a.out + ((size_t)t * a.C + 8 * g) * 2;
+    bf16x8 oA[NQ], oB[NQ];
+    auto issue_o = [&](bf16x8 (&o)[NQ], int ch_) {
+        const int cb = min(ch_, ch1 - 1) * CWK;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
+    };
+    issue_o(oA, ch0);
+    bf16x8 bh[KH], bl[KH];
+    {
+        const unsigned char* prp = (const unsigned char*)a.pack + (size_t)t * (2 * RP * 2);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            bh[kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+            bl[kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+        }
+    }
+    const int wr = a.r;                                                      // row length of Bw
+    bf16x8 wp[PER];
+    auto wload = [&](int ch) {
+        const int cb = ch * CWK;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 512 * u;                                     // (q, p, kh, lane)
+            const int ln = e & 63, kh = (e >> 6) & 1, p = (e >> 7) & 1, q = e >> 8;
+            const int c = cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3);
+            const int k0 = 32 * kh + 8 * (ln >> 4);
+            bf16x8 v = z8;
+            if (c < a.C) {
+                const unsigned short* src = (const unsigned short*)a.W[0] + (size_t)c * wr;
+                if (wr == RP) v = *(const bf16x8*)(src + k0);
+                else {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) v[x] = (k0 + x < wr) ? (short)src[k0 + x] : (short)0;
+                }
+            }
+            wp[u] = v;
+        }
+    };
+    auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+        const int cb = ch * CWK;
+        issue_o(onext, ch + 1);
+        __syncthreads();                                                     // the previous chunk's fragments are no longer read
+#pragma unroll
+        for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+        __syncthreads();
+        if (ch + 1 < ch1) wload(ch + 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 d[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+                    const bf16x8 wf = wl[((size_t)q * 2 + p) * KH * 64 + kh * 64 + lane];
+                    d[p] = MFMA16(wf, bh[kh], d[p]);
+                    d[p] = MFMA16(wf, bl[kh], d[p]);
+                }
+            }
+            if (cb + 32 * q >= a.C) continue;                                // C % 32 == 0 (block uniform)
+            union { bf16x8 b; unsigned u[4]; } ou, res;
+            ou.b = o[q];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)
+                res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + d[(2 * w2) >> 2][(2 * w2) & 3],
+                                    __uint_as_float(ou.u[w2] & 0xffff0000u) + d[(2 * w2 + 1) >> 2][(2 * w2 + 1) & 3]);
+            if (valid) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+        }
+    };
+    wload(ch0);
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        step(oA, oB, ch);
+        if (ch + 1 < ch1) step(oB, oA, ch + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // G: wgrad  acc[m][c][k] += sum_t in[t][c] * pack_kmj[m][.][k][t]
 // ------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -3284,8 +3385,22 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
             else if (g_tune_expand_nq == 3) launch_expand_t<32, 2, false, 1, 2>(ab, nz, st);        // the per-tile form (A/B)
             else launch_expand_t<32, 4, false, 1, 2, true>(ab, nz, st);
         }
+        else if (W_CK && g_tune_expand_nq == 0) {        // rank pad 64: the token-owning y kernel ("expand_nq" 2 / 4: the column-owning forms)
+            int Cmax = 0;
+            for (int z = 0; z < nz; ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
+            const int T = ab.z[0].T, nch = (Cmax + 127) / 128, ntb = (T + 127) / 128;
+            // workgroups per CU (13B widths, up_fwd per pass with 2 / 3 / 4 / 6 / 8: 17.0 / 16.4 / 17.4 / 16.8 / 17.0 ms; single launches are best at 2, batches at 3)
+            int want = ((g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (nz > 1 ? 3 : 2)) * num_cu() + ntb * nz - 1) / (ntb * nz);
+            want = want < 1 ? 1 : (want > nch ? nch : want);
+            const int cpb = (nch + want - 1) / want;
+            ExpandBatch sb = ab;
+            ensure_lds((const void*)moka_yt_kernel, (size_t)16 * 1024);
+            hipLaunchKernelGGL(moka_yt_kernel, dim3((nch + cpb - 1) / cpb, ntb, nz), dim3(512), (size_t)16 * 1024, st, sb, cpb);
+            return check_launch("moka_yt_kernel");
+        }
         else if (W_CK) { if (g_tune_expand_nq == 2) launch_expand_t<64, 2, true, 1, 2>(ab, nz, st); else launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); }
         else if (g_tune_expand_nq == 3) launch_expand_t<64, 2, false, 1, 2>(ab, nz, st);            // the per-tile form (A/B)
+        // (the token-owning form of the groups, moka_dxg_kernel<1>, loses for a single projection: dx + dA of o / down 97 / 227 -> 109 / 253 us)
         else launch_expand_t<64, 4, false, 1, 2, true>(ab, nz, st);
     } else if (RP == 64) {                               // projections sharing dx at rank pad 64: the token-owning form (moka_dxg_kernel)
         const int T = ab.z[0].T, C = ab.z[0].C;
