@@ -793,8 +793,9 @@ def main():
             avg = ms / c_
             table[f"{n}[{label}: {di}->{'/'.join(str(v) for v in dos)}]"] = {"avg_ms": round(avg, 4), "algo_GBps": round(nb / (avg * 1e-3) / 1e9, 1)}
         # the dominant kernel: the largest entry point of a pass that is ONE kernel launch
-        # (moka_up_fwd -> moka_expand_kernel<.., true>; grouped units run their members in one launch, grid z)
-        single = {"moka_up_fwd": "moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
+        # (moka_up_fwd -> moka_yt_kernel<RP> for the batched launches, moka_expand_kernel<.., true> for single projections; grouped units
+        #  run their members in one launch, grid z)
+        single = {"moka_up_fwd": "moka_yt_kernel<RP> / moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
         dom = "moka_up_fwd"
         dom_bytes = byt[dom]
         dom_avg_ms = tot[dom] / cnt[dom]

@@ -1430,10 +1430,11 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
 // for the eight waves, requested from L2 one chunk ahead.  ~100 registers instead of the 260 of the column-owning kernel (one wave per
 // SIMD, every wave reading its 256-byte pack rows and holding 64 registers of weights): four waves per SIMD.  blockIdx.z = problem.
 // ------------------------------------------------------------------------------------------
+template <int RP>
 __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RP = 64, KH = 2, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 16 fragments (1 KB each) per chunk
-    constexpr int PER = NF * 64 / 512;                                       // 2 fragments per thread and chunk
+    constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 8 KH fragments (1 KB each) per chunk
+    constexpr int PER = NF * 64 / 512;                                       // KH fragments per thread and chunk
     bf16x8* wl = (bf16x8*)smem;                                              // [NQ][2][KH][64]
     const ExpandArgs& a = ab.z[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1461,8 +1462,11 @@ __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, i
         const unsigned char* prp = (const unsigned char*)a.pack + (size_t)t * (2 * RP * 2);
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
-            bh[kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
-            bl[kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            if (RP == 16) { bh[kh] = *(const bf16x8*)(prp + 16 * g); bl[kh] = bh[kh]; }      // K = 32 is [hi(16) | lo(16)]: one MFMA
+            else {
+                bh[kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+                bl[kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            }
         }
     }
     const int wr = a.r;                                                      // row length of Bw
@@ -1472,9 +1476,9 @@ __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, i
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int e = tid + 512 * u;                                     // (q, p, kh, lane)
-            const int ln = e & 63, kh = (e >> 6) & 1, p = (e >> 7) & 1, q = e >> 8;
+            const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
             const int c = cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3);
-            const int k0 = 32 * kh + 8 * (ln >> 4);
+            const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
             bf16x8 v = z8;
             if (c < a.C) {
                 const unsigned short* src = (const unsigned short*)a.W[0] + (size_t)c * wr;
@@ -1505,7 +1509,7 @@ __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, i
                 for (int kh = 0; kh < KH; ++kh) {
                     const bf16x8 wf = wl[((size_t)q * 2 + p) * KH * 64 + kh * 64 + lane];
                     d[p] = MFMA16(wf, bh[kh], d[p]);
-                    d[p] = MFMA16(wf, bl[kh], d[p]);
+                    if (RP != 16) d[p] = MFMA16(wf, bl[kh], d[p]);
                 }
             }
             if (cb + 32 * q >= a.C) continue;                                // C % 32 == 0 (block uniform)
@@ -3371,6 +3375,23 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     }
 }
 
+template <int RP>
+static int launch_yt(const ExpandBatch& ab, int nz, hipStream_t st) {
+    int Cmax = 0;
+    for (int z = 0; z < nz; ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
+    const int T = ab.z[0].T, nch = (Cmax + 127) / 128, ntb = (T + 127) / 128;
+    // workgroups per CU (13B widths, r = 64, up_fwd per pass with 2 / 3 / 4 / 6 / 8: 17.0 / 16.4 / 17.4 / 16.8 / 17.0 ms; single launches are best at 2, batches at 3)
+    // (r = 16, 7B widths: gate+up 150.3 / 146.8 / 146.0 / 154.2 us with 3 / 2 / 4 / 6, q+k+v 80.3 / 91.7 / 89.5 / 77.7)
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (RP == 64 ? (nz > 1 ? 3 : 2) : (Cmax > 8192 ? 4 : 6));
+    int want = (bpc * num_cu() + ntb * nz - 1) / (ntb * nz);
+    want = want < 1 ? 1 : (want > nch ? nch : want);
+    const int cpb = (nch + want - 1) / want;
+    constexpr size_t lds = (size_t)4 * 2 * ((RP + 31) / 32) * 1024;
+    ensure_lds((const void*)moka_yt_kernel<RP>, lds);
+    hipLaunchKernelGGL((moka_yt_kernel<RP>), dim3((nch + cpb - 1) / cpb, ntb, nz), dim3(512), lds, st, ab, cpb);
+    return check_launch("moka_yt_kernel");
+}
+
 // W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
 template <bool W_CK>
 static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) {
@@ -3378,6 +3399,15 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
     if (W_CK || nz == 1) {
         // RP == 16: the per-tile form (text set resident, the others fetched for the tiles that need them); contiguous runs with one
         // resident set lose there (dx pass 11.1 -> 11.8 ms), win at rank pad 32 (16.2 -> 15.9) and 64 (37.4 -> 30.7, with 128 columns per wave)
+        // r <= 32: the token-owning form for BATCHED launches of equal, moderate width (7B widths, r = 16: gate+up 155.8 -> 146.0 us, q+k+v 84.1 -> 77.7,
+        // step 34.14 -> 33.93 ms on one box, twice); single projections stay (32.0 -> 32.2-33.6 us), and so do the 70B batches (q / k / v of
+        // different width, 2 x 28672 gate / up: step 165.8 -> 167.6 ms).  "expand_nq" 5 / 6: always / never.
+        if (RP <= 32 && W_CK && g_tune_expand_nq != 6) {
+            bool uniform = true;
+            size_t cols = 0;
+            for (int z = 0; z < nz; ++z) { uniform = uniform && ab.z[z].C == ab.z[0].C; cols += (size_t)ab.z[z].C; }
+            if (g_tune_expand_nq == 5 || (nz > 1 && uniform && cols <= 32768)) return RP == 16 ? launch_yt<16>(ab, nz, st) : launch_yt<32>(ab, nz, st);
+        }
         if (RP == 16) { if (g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
         // wider ranks: the y kernel keeps 128 columns per wave (r = 64: 48 -> 34 us at 4096), the dx kernel 64
         else if (RP == 32) {
@@ -3386,17 +3416,7 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
             else launch_expand_t<32, 4, false, 1, 2, true>(ab, nz, st);
         }
         else if (W_CK && g_tune_expand_nq == 0) {        // rank pad 64: the token-owning y kernel ("expand_nq" 2 / 4: the column-owning forms)
-            int Cmax = 0;
-            for (int z = 0; z < nz; ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
-            const int T = ab.z[0].T, nch = (Cmax + 127) / 128, ntb = (T + 127) / 128;
-            // workgroups per CU (13B widths, up_fwd per pass with 2 / 3 / 4 / 6 / 8: 17.0 / 16.4 / 17.4 / 16.8 / 17.0 ms; single launches are best at 2, batches at 3)
-            int want = ((g_tune_expand_bpc > 0 ? g_tune_expand_bpc : (nz > 1 ? 3 : 2)) * num_cu() + ntb * nz - 1) / (ntb * nz);
-            want = want < 1 ? 1 : (want > nch ? nch : want);
-            const int cpb = (nch + want - 1) / want;
-            ExpandBatch sb = ab;
-            ensure_lds((const void*)moka_yt_kernel, (size_t)16 * 1024);
-            hipLaunchKernelGGL(moka_yt_kernel, dim3((nch + cpb - 1) / cpb, ntb, nz), dim3(512), (size_t)16 * 1024, st, sb, cpb);
-            return check_launch("moka_yt_kernel");
+            return launch_yt<64>(ab, nz, st);
         }
         else if (W_CK) { if (g_tune_expand_nq == 2) launch_expand_t<64, 2, true, 1, 2>(ab, nz, st); else launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); }
         else if (g_tune_expand_nq == 3) launch_expand_t<64, 2, false, 1, 2>(ab, nz, st);            // the per-tile form (A/B)
