@@ -1275,11 +1275,11 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
 // columns); then each projection's product passes its own dropout mask and joins the sum, and the dx tile is written once per chunk.
 // q/k/v (gate/up) cost one pass over dx instead of three (two).
 // ------------------------------------------------------------------------------------------
-template <int G>
+template <int RP, int G>
 __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RP = 64, KH = 2, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 16 fragments (1 KB each) per projection and chunk
-    constexpr int PER = G * NF * 64 / 512;                                   // fragments per thread and step (2 G)
+    constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 8 KH fragments (1 KB each) per projection and chunk
+    constexpr int PER = G * NF * 64 / 512, PG = NF * 64 / 512;               // fragments per thread and step: PG (= KH) per projection
     bf16x8* wl = (bf16x8*)smem;                                              // [G][NQ][2][KH][64]
     __shared__ unsigned s_wpm[8];
     const ExpandArgs& a = ab.z[0];
@@ -1312,8 +1312,11 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
         const unsigned char* prp = (const unsigned char*)ab.z[gi].pack + (size_t)t * (2 * RP * 2);
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
-            bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
-            bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            if (RP == 16) { bh[gi][kh] = *(const bf16x8*)(prp + 16 * g); bl[gi][kh] = bh[gi][kh]; }    // K = 32 is [hi(16) | lo(16)]: one MFMA
+            else {
+                bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+                bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            }
         }
     }
     const int mrow = live ? (int)a.tok_mod[(tile << 4) + i] : MOKA_MOD_NONE;     // padded past T with MOKA_MOD_NONE
@@ -1336,10 +1339,11 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
         for (int gi = 0; gi < G; ++gi) wm[gi] = ab.z[gi].W[0] + (size_t)m * a.C * RP * 2;      // (the shadows of the modalities follow each other)
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int e = tid + 512 * (u & 1);                               // (q, p, kh, lane) of projection u / 2: 1024 fragments each
-            const int ln = e & 63, kh = (e >> 6) & 1, p = (e >> 7) & 1, q = e >> 8;
+            const int e = tid + 512 * (u % PG);                              // (q, p, kh, lane) of projection u / PG: NF x 64 fragments each
+            const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
             const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);   // columns >= C are never stored
-            wp[u] = *(const bf16x8*)(wm[u >> 1] + ((size_t)c * RP + 32 * kh + 8 * (ln >> 4)) * 2);
+            const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
+            wp[u] = *(const bf16x8*)(wm[u / PG] + ((size_t)c * RP + k0) * 2);
         }
     };
     auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
@@ -1381,7 +1385,7 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
                         for (int kh = 0; kh < KH; ++kh) {
                             const bf16x8 wf = wl[(((size_t)gi * NQ + q) * 2 + p) * KH * 64 + kh * 64 + lane];
                             d[p] = MFMA16(wf, bh[gi][kh], d[p]);
-                            d[p] = MFMA16(wf, bl[gi][kh], d[p]);
+                            if (RP != 16) d[p] = MFMA16(wf, bl[gi][kh], d[p]);
                         }
                     }
                     float v[8];
@@ -3431,15 +3435,16 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         const int cpb = (nch + want - 1) / want;
         const dim3 grid((nch + cpb - 1) / cpb, ntb);
         if (nz == 2) {
-            ensure_lds((const void*)moka_dxg_kernel<2>, (size_t)2 * 16 * 1024);
-            hipLaunchKernelGGL((moka_dxg_kernel<2>), grid, dim3(512), (size_t)2 * 16 * 1024, st, ab, cpb);
+            ensure_lds((const void*)moka_dxg_kernel<64, 2>, (size_t)2 * 16 * 1024);
+            hipLaunchKernelGGL((moka_dxg_kernel<64, 2>), grid, dim3(512), (size_t)2 * 16 * 1024, st, ab, cpb);
         } else {
-            ensure_lds((const void*)moka_dxg_kernel<3>, (size_t)3 * 16 * 1024);
-            hipLaunchKernelGGL((moka_dxg_kernel<3>), grid, dim3(512), (size_t)3 * 16 * 1024, st, ab, cpb);
+            ensure_lds((const void*)moka_dxg_kernel<64, 3>, (size_t)3 * 16 * 1024);
+            hipLaunchKernelGGL((moka_dxg_kernel<64, 3>), grid, dim3(512), (size_t)3 * 16 * 1024, st, ab, cpb);
         }
         return check_launch("moka_dxg_kernel");
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
-        // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass)
+        // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass;
+        //  the token-owning form of rank pad 64, moka_dxg_kernel<16, G>, loses here: q+k+v dx + dA 88.9 -> 106.4 us, gate+up 70.3 -> 84.9)
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
         else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st);
     }
