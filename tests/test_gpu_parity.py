@@ -576,6 +576,18 @@ def test_rank_pad_64_group_walks_chunks_with_three_modalities_per_run(d_outs):
     _group_vs_singles(dict(variant="avt", B=2, S=4096, d_in=5120, d_outs=d_outs, r=48, p=0.1, layouts=[lay, [("t", 3)] + lay[1:]]))
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(variant="avt", B=3, S=700, d_in=160, d_outs=(352, 352), r=8, p=0.1),            # T % 16 != 0, width % 128 != 0, r < rank pad (16)
+    dict(variant="vt", B=2, S=333, d_in=96, d_outs=(96, 96, 96), r=16, p=0.0),           # one chunk, narrower than a chunk
+    dict(variant="avt", B=3, S=700, d_in=160, d_outs=(1376, 1376, 1376), r=24, p=0.05),  # rank pad 32, r < pad
+    dict(variant="avt", B=1, S=130, d_in=64, d_outs=(160, 160), r=40, p=0.0),            # rank pad 64, r < pad, tokens < one workgroup
+])
+def test_batched_up_projection_of_equal_widths_on_ragged_shapes(cfg):
+    """Batched y launches of EQUAL width run in the token-owning form (moka_yt_kernel) at every rank: ragged token counts, widths that
+    are not a multiple of its 128-column chunk, ranks that do not fill their pad (element-wise weight-fragment loads)."""
+    _group_vs_singles(cfg)
+
+
 def _random_group_cfg(seed):
     import random
     rnd = random.Random(100 + seed)
