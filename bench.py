@@ -571,6 +571,8 @@ def main():
                          "a layer's worth of them is enqueued on a second stream when the layer's chain is, and runs beside the next layer's chain "
                          "(joined before a gradient bucket ships and before the optimizer step); main = the same launches on the one stream; "
                          "off = dA_m and dx from one moka_down_bwd call inside the chain")
+    ap.add_argument("--chain-priority", choices=("high", "normal"), default="high",
+                    help="stream priority of the captured dependency chain (the deferred dA / dB stream stays at normal priority)")
     ap.add_argument("--defer-db", choices=("auto", "on", "off"), default="auto",
                     help="with --defer-da: dB also leaves the dependency chain (auto: where moka_up_bwd_passes() says dB is a pass of its own, r > 32)")
     ap.add_argument("--no-group", action="store_true",
@@ -651,7 +653,9 @@ def main():
     fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
     if args.graph != "off":
         try:
-            side = torch.cuda.Stream(device=dev)
+            # the chain's (capture) stream at high priority, the deferred dA / dB stream at normal: when both have workgroups waiting, the
+            # dependency chain goes first (7B r = 16, same box twice: 33.43-33.48 -> 33.16-33.18 ms; r = 64: no difference)
+            side = torch.cuda.Stream(device=dev, priority=-1 if args.chain_priority == "high" else 0)
             with torch.cuda.stream(side):
                 spw = c_void_p(side.cuda_stream)
                 for ch in wl["chains"]:
@@ -835,7 +839,7 @@ def main():
             "graph": args.graph,
             "chains": args.chains,
             "defer_dA": args.defer_da,
-            "defer_dB": bool(args.split_db),
+            "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority,
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
