@@ -294,7 +294,7 @@ def run_forward(lib, wl, sp, rec=None):
         _call(lib, "moka_up_fwd", u, sp, rec)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None):
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None):
     """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
     defer = (mode, main_stream, side_stream): the dA_m halves of a layer's moka_down_bwd calls leave the dependency chain (only the
     optimizer needs them) and are enqueued after the layer's chain -- "main": on the same stream; "side": on a second stream,
@@ -332,6 +332,14 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
                 if split_db:
                     _call(lib, "moka_up_bwd:dB", u, sps, None)
                 _call(lib, "moka_down_bwd:dA", u, sps, None)
+            if bucket_opt is not None and mode == "side":
+                # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the
+                # update of the finished layers overlaps the backward of the earlier ones (FlatAdamW.step_range, coefficients in device memory)
+                opt_, bucket_, scale_ = bucket_opt
+                if l % bucket_.layers_per_bucket == 0:
+                    blo, bhi = bucket_.bucket_bounds(l)
+                    with torch.cuda.stream(side):
+                        opt_.step_range(blo, bhi, grad_scale=scale_, zero_grad=True)
             ev = torch.cuda.Event()
             ev.record(side)
             done[l] = ev
@@ -571,6 +579,8 @@ def main():
                          "a layer's worth of them is enqueued on a second stream when the layer's chain is, and runs beside the next layer's chain "
                          "(joined before a gradient bucket ships and before the optimizer step); main = the same launches on the one stream; "
                          "off = dA_m and dx from one moka_down_bwd call inside the chain")
+    ap.add_argument("--opt-in-backward", choices=("on", "off"), default="on",
+                    help="the fused AdamW step per gradient bucket inside the backward (behind the bucket's deferred dA / its all-reduce) instead of one launch behind it")
     ap.add_argument("--chain-priority", choices=("high", "normal"), default="high",
                     help="stream priority of the captured dependency chain (the deferred dA / dB stream stays at normal priority)")
     ap.add_argument("--defer-db", choices=("auto", "on", "off"), default="auto",
@@ -641,6 +651,15 @@ def main():
         from moka_amd.parallel import FlatAdamW
         opt = FlatAdamW(wl["master"], bucket.flat, wl["work"], lr=1e-4)
     L = args.layers
+    # the optimizer step per gradient bucket INSIDE the backward (off: one launch behind it): needs the side stream of the deferred dA_m
+    # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
+    opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and args.chains == 1 and
+                  ((world == 1 and args.defer_da == "side" and args.graph in ("auto", "all", "off")) or (world > 1 and not args.comm_bf16)))
+    if opt_in_bwd:
+        opt.begin_step()
+        opt.t -= 1                                   # (allocates the coefficient buffers; no step counted)
+        if world > 1:
+            bucket.on_reduced = lambda blo, bhi: opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
 
     records = Recorder(only=LIVE, every=args.bracket_every)
     records.reserve(2 * len(wl["units"]) * args.steps + 16)
@@ -674,8 +693,11 @@ def main():
                     for ch, st in zip(wl["chains"], [cur] + branch):
                         with torch.cuda.stream(st):
                             spg = c_void_p(st.cuda_stream)
+                            if opt_in_bwd and ch is wl["chains"][0]:
+                                opt.upload_coef()            # (a copy from pinned memory: every replay reads this step's coefficients)
                             run_forward(lib, ch, spg)
-                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side, args.split_db) if args.defer_da != "off" else None)
+                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side, args.split_db) if args.defer_da != "off" else None,
+                                         bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None)
                     for st in branch:
                         cur.wait_stream(st)          # join
             else:
@@ -707,6 +729,10 @@ def main():
         sp = c_void_p(main_stream.cuda_stream)
         if opt is None:
             bucket.zero_()                           # (the optimizer kernel leaves the gradient buffer zeroed)
+        if opt_in_bwd:
+            opt.begin_step()                         # this step's coefficients -> pinned memory
+            if fwd_bwd_graph is None:
+                opt.upload_coef()                    # (captured in the one-graph mode)
         if fwd_bwd_graph is not None:
             fwd_bwd_graph.replay()
         else:
@@ -721,7 +747,8 @@ def main():
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
                 run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
-                             defer=(args.defer_da, main_stream, live_side, args.split_db) if args.defer_da != "off" else None)
+                             defer=(args.defer_da, main_stream, live_side, args.split_db) if args.defer_da != "off" else None,
+                             bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and world == 1) else None)
         if comm_ev is not None and i >= args.warmup:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
@@ -730,7 +757,7 @@ def main():
             comm_ev.append((e0, e1))
         else:
             bucket.finish(average=opt is None)       # join the all-reduces; the optimizer kernel averages (grad_scale)
-        if opt is not None:
+        if opt is not None and not opt_in_bwd:
             opt.step(grad_scale=1.0 / world, zero_grad=True)
 
     for i in range(args.warmup):
@@ -839,7 +866,7 @@ def main():
             "graph": args.graph,
             "chains": args.chains,
             "defer_dA": args.defer_da,
-            "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority,
+            "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority, "optimizer_in_backward": bool(opt_in_bwd),
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

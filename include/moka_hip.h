@@ -69,9 +69,9 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      501            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+#define MOKA_VERSION      502            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
-                                            at rank pad 64 depends on T */
+                                            at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef() */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
@@ -260,6 +260,13 @@ size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M);
 int moka_adamw_flat(float* master, void* work_bf16, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                     int zero_grad, moka_stream_t stream);
+/* The same step with its step-dependent coefficients {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 - lr * weight_decay} read from
+ * three floats in DEVICE memory instead of the launch arguments: a launch captured in a hipGraph (or enqueued per gradient bucket while the
+ * backward is still running) stays valid from step to step -- the caller computes them with moka_adamw_coef() on the host and copies them
+ * to coef_dev before the kernel runs (e.g. a captured copy from pinned memory).  A slice of the flat buffers is a call with offset pointers. */
+void moka_adamw_coef(float lr, float beta1, float beta2, float weight_decay, int step, float* coef3);
+int moka_adamw_flat_dev(float* master, void* work_bf16, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                        float beta1, float beta2, float eps, const float* coef_dev, float grad_scale, int zero_grad, moka_stream_t stream);
 
 #ifdef __cplusplus
 }

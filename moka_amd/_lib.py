@@ -99,6 +99,9 @@ SYMBOLS = {
     # master, work_bf16, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream
     "moka_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
                                 c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
+    "moka_adamw_coef": (None, [c_float, c_float, c_float, c_float, c_int, ctypes.POINTER(c_float)]),
+    "moka_adamw_flat_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
+                                    c_float, c_float, c_float, c_void_p, c_float, c_int, c_void_p]),
 }
 
 

@@ -3147,19 +3147,23 @@ struct AdamArgs {
     float step_size, inv_bc2_sqrt;           // lr / (1 - beta1^t),  1 / sqrt(1 - beta2^t)
     float grad_scale;
     int zero_grad;
+    const float* coef;                        // device: {step_size, inv_bc2_sqrt, decay} of THIS step (moka_adamw_flat_dev), or null
 };
 
 // 34 bytes of HBM traffic per parameter (p, g, m, v read; p, m, v, bf16 copy, zeroed g written), 16 bytes per lane and access.
 __global__ void __launch_bounds__(256) moka_adamw_kernel(const AdamArgs a) {
     const size_t n4 = a.n >> 2;
     const size_t stride = (size_t)gridDim.x * 256;
+    // the step-dependent coefficients: launch arguments, or three floats in device memory (a launch captured in a hipGraph: the host
+    // refreshes them before every replay)
+    const float step_size = a.coef ? a.coef[0] : a.step_size, inv_bc2_sqrt = a.coef ? a.coef[1] : a.inv_bc2_sqrt, decay = a.coef ? a.coef[2] : a.decay;
     auto upd = [&](float p, float g, float& m, float& v) -> float {
         g *= a.grad_scale;
-        p *= a.decay;
+        p *= decay;
         m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
         v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
-        const float denom = fmaf(sqrtf(v), a.inv_bc2_sqrt, a.eps);
-        return p - a.step_size * (m / denom);
+        const float denom = fmaf(sqrtf(v), inv_bc2_sqrt, a.eps);
+        return p - step_size * (m / denom);
     };
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const f32x4 p = ((const f32x4*)a.master)[i], g = ((const f32x4*)a.grad)[i];
@@ -4349,7 +4353,32 @@ int moka_adamw_flat(float* master, void* work_bf16, float* grad, float* exp_avg,
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.decay = 1.f - lr * weight_decay;
     a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
     a.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
-    a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+    a.grad_scale = grad_scale; a.zero_grad = zero_grad; a.coef = nullptr;
+    size_t blocks = ((n >> 2) + 255) / 256;
+    const size_t cap = (size_t)num_cu() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(moka_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("moka_adamw_kernel");
+}
+
+void moka_adamw_coef(float lr, float beta1, float beta2, float weight_decay, int step, float* coef3) {
+    coef3[0] = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    coef3[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    coef3[2] = 1.f - lr * weight_decay;
+}
+
+int moka_adamw_flat_dev(float* master, void* work_bf16, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                        float beta1, float beta2, float eps, const float* coef_dev, float grad_scale, int zero_grad, moka_stream_t stream) {
+    if (!master || !grad || !exp_avg || !exp_avg_sq || !coef_dev) return fail(MOKA_EINVAL, "moka_adamw_flat_dev: null pointer");
+    if (n == 0) return MOKA_OK;
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) return fail(MOKA_EINVAL, "moka_adamw_flat_dev: betas (%g, %g) not in [0, 1)", (double)beta1, (double)beta2);
+    if ((((uintptr_t)master | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) || ((uintptr_t)work_bf16 & 7) || ((uintptr_t)coef_dev & 3))
+        return fail(MOKA_EINVAL, "moka_adamw_flat_dev: buffers must be 16-byte aligned (bf16 copy: 8, coefficients: 4)");
+    AdamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.master = master; a.work = (unsigned short*)work_bf16; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale; a.zero_grad = zero_grad; a.coef = coef_dev;
     size_t blocks = ((n >> 2) + 255) / 256;
     const size_t cap = (size_t)num_cu() * 16;
     if (blocks > cap) blocks = cap;

@@ -48,6 +48,7 @@ class FlatGradBucket:
         self.layers_per_bucket = max(1, -(-self.n_layers // max(1, n_buckets)))
         self.is_cuda = self.flat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and self.world > 1) else None
+        self.on_reduced = None       # callable(lo, hi), run on the communication stream behind a bucket's all-reduce (fp32 payload only)
         self._pending: List = []
 
     # ---------------------------------------------------------------- views
@@ -81,7 +82,11 @@ class FlatGradBucket:
                     st.copy_(sl)                                   # fp32 -> bf16 on the side stream
                     self._pending.append((dist.all_reduce(st, group=self.group, async_op=True), lo, hi))
                 else:
-                    self._pending.append((dist.all_reduce(sl, group=self.group, async_op=True), lo, hi))
+                    wk = dist.all_reduce(sl, group=self.group, async_op=True)
+                    if self.on_reduced is not None:
+                        wk.wait()                                  # (the communication stream waits, not the host)
+                        self.on_reduced(lo, hi)                    # e.g. FlatAdamW.step_range: the bucket's update overlaps the rest of the backward
+                    self._pending.append((wk, lo, hi))
         else:
             if self._stage is not None:
                 st = self._stage[lo:hi]
@@ -146,6 +151,38 @@ class FlatAdamW:
                                        self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                        self.master.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                        self.t, float(grad_scale), 1 if zero_grad else 0, stream), "moka_adamw_flat")
+
+    # -- the same step in slices, with the step-dependent coefficients in device memory (``moka_adamw_flat_dev``): launches that can be
+    #    captured in a hipGraph, or enqueued per gradient bucket while the backward of the earlier layers is still running
+    def begin_step(self) -> None:
+        """Count the step and put its coefficients {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 - lr * wd} into pinned host memory."""
+        from . import _lib
+        import ctypes
+        if not self.master.is_cuda:
+            raise _lib.MokaError("moka_amd: FlatAdamW runs as a HIP kernel; the buffers live on %s" % self.master.device)
+        if getattr(self, "_coef_host", None) is None:
+            self._coef_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._coef_dev = torch.zeros(4, dtype=torch.float32, device=self.master.device)
+        self.t += 1
+        c = (ctypes.c_float * 3)()
+        _lib.load().moka_adamw_coef(self.lr, self.betas[0], self.betas[1], self.weight_decay, self.t, c)
+        self._coef_host[0], self._coef_host[1], self._coef_host[2] = float(c[0]), float(c[1]), float(c[2])
+
+    def upload_coef(self) -> None:
+        """Enqueue the copy of the coefficients to the device on the current stream (capturable: a replay reads the pinned buffer anew)."""
+        self._coef_dev.copy_(self._coef_host, non_blocking=True)
+
+    def step_range(self, lo: int, hi: int, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+        """The update of parameters [lo, hi) on the current stream, behind ``upload_coef()``; lo must be a multiple of 4."""
+        from . import _lib
+        if lo % 4 or not (0 <= lo <= hi <= self.master.numel()):
+            raise ValueError(f"FlatAdamW.step_range: bad range [{lo}, {hi})")
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(self.master.device).cuda_stream
+        _lib.check(lib.moka_adamw_flat_dev(self.master.data_ptr() + 4 * lo, None if self.work is None else self.work.data_ptr() + 2 * lo,
+                                           self.grad.data_ptr() + 4 * lo, self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo,
+                                           hi - lo, self.betas[0], self.betas[1], self.eps, self._coef_dev.data_ptr(), float(grad_scale),
+                                           1 if zero_grad else 0, stream), "moka_adamw_flat_dev")
 
     def state_dict(self) -> dict:
         return {"step": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,

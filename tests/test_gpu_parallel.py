@@ -72,3 +72,52 @@ def test_flat_adamw_rejects_bad_arguments():
         FlatAdamW(a, a.to(torch.bfloat16))
     with pytest.raises(_lib.MokaError):
         FlatAdamW(torch.zeros(8), torch.zeros(8)).step()
+
+
+def test_flat_adamw_in_slices_with_device_coefficients_equals_the_one_launch_step():
+    """``begin_step(); upload_coef(); step_range(lo, hi)`` per gradient bucket (moka_adamw_flat_dev: the step-dependent coefficients are read
+    from device memory) = ``step()`` bit for bit -- also when the slice launches are captured ONCE in a hipGraph and replayed: the host
+    refreshes the pinned coefficients before every replay."""
+    from moka_amd.parallel import FlatAdamW
+    dev = _dev()
+    n = 4096 * 5 + 64
+    g = torch.Generator(device="cpu").manual_seed(11)
+    p0 = torch.randn(n, generator=g)
+    grads = [(torch.randn(n, generator=g) * (0.1 + k)).to(dev) for k in range(4)]
+
+    def fresh():
+        master, grad = p0.to(dev).clone(), torch.zeros(n, device=dev)
+        work = torch.empty(n, device=dev, dtype=torch.bfloat16)
+        return master, grad, work, FlatAdamW(master, grad, work, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+
+    m0, g0, w0, ref = fresh()
+    for gk in grads:
+        g0.copy_(gk)
+        ref.step(grad_scale=0.25, zero_grad=True)
+    cuts = [0, 4096, 4096 * 3, n]
+    # live slices
+    m1, g1, w1, opt = fresh()
+    for gk in grads:
+        g1.copy_(gk)
+        opt.begin_step()
+        opt.upload_coef()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            opt.step_range(lo, hi, grad_scale=0.25, zero_grad=True)
+    assert torch.equal(m1, m0) and torch.equal(w1, w0) and torch.equal(opt.exp_avg_sq, ref.exp_avg_sq) and float(g1.abs().max()) == 0.0
+    # the same launches captured once
+    m2, g2, w2, opt2 = fresh()
+    opt2.begin_step()
+    opt2.t -= 1                                                   # (allocate the coefficient buffers without counting a step)
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=dev)
+    with torch.cuda.graph(graph, stream=side):
+        opt2.upload_coef()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            opt2.step_range(lo, hi, grad_scale=0.25, zero_grad=True)
+    for gk in grads:
+        g2.copy_(gk)
+        opt2.begin_step()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert opt2.t == ref.t and torch.equal(m2, m0) and torch.equal(w2, w0) and torch.equal(opt2.exp_avg, ref.exp_avg)
+    with pytest.raises(ValueError):
+        opt.step_range(2, 64)
