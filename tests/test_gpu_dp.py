@@ -367,3 +367,67 @@ def test_deferred_dA_on_the_side_stream_gives_the_same_gradients(rank):
         outs.append(dp.bucket.flat.clone())
     err = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
     assert outs[0].norm().item() > 0 and err <= 1e-5, err
+
+
+def _opt_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import FlatAdamW, FlatGradBucket
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    n_layers, per = 6, 1024
+    ends = [per * (l + 1) for l in range(n_layers)]
+    bucket = FlatGradBucket(ends[-1], ends, dev, n_buckets=3)
+    g = torch.Generator().manual_seed(3)
+    master = torch.randn(ends[-1], generator=g).to(dev)
+    work = torch.empty(ends[-1], device=dev, dtype=torch.bfloat16)
+    opt = FlatAdamW(master, bucket.flat, work, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    bucket.on_reduced = lambda lo, hi: opt.step_range(lo, hi, grad_scale=1.0 / world, zero_grad=True)
+    for step in range(3):
+        gr = torch.Generator().manual_seed(100 * step + rank)
+        bucket.flat.copy_(torch.randn(ends[-1], generator=gr).to(dev))          # this rank's gradient
+        opt.begin_step()
+        opt.upload_coef()
+        for l in range(n_layers - 1, -1, -1):
+            bucket.layer_done(l)          # a finished bucket: all-reduce on the communication stream, its AdamW slice right behind it
+        bucket.finish(average=False)
+        torch.cuda.synchronize()
+    q.put((rank, master.cpu().numpy(), float(bucket.flat.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimizer_slices_behind_the_bucket_all_reduce_on_two_ranks():
+    """FlatGradBucket.on_reduced: a bucket's AdamW update (FlatAdamW.step_range, coefficients in device memory) runs on the communication
+    stream right behind its all-reduce; after three steps both ranks hold what one process gets from the averaged gradients in one launch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, m, gmax = q.get(timeout=240)
+        got[r] = torch.from_numpy(m)
+        assert gmax == 0.0
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from moka_amd.parallel import FlatAdamW
+    dev = torch.device("cuda:0")
+    n = 6 * 1024
+    master = torch.randn(n, generator=torch.Generator().manual_seed(3)).to(dev)
+    grad, work = torch.zeros(n, device=dev), torch.empty(n, device=dev, dtype=torch.bfloat16)
+    ref = FlatAdamW(master, grad, work, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    for step in range(3):
+        gs = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(2))
+        grad.copy_(gs.to(dev))
+        ref.step(grad_scale=0.5, zero_grad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], got[1])
+    err = ((got[0] - master.cpu()).norm() / master.cpu().norm()).item()
+    assert err <= 1e-6, err
