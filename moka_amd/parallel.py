@@ -248,8 +248,22 @@ class AdapterDataParallel:
         self._deferred: list = []
         self._side = None
         self._side_busy = False
+        # attach(optimizer_in_backward=True): a finished bucket's AdamW slice is enqueued while the backward of the earlier layers is still
+        # running (one GPU: on the side stream behind the bucket's deferred dA_m; N > 1: on the communication stream behind its all-reduce)
+        self.opt_in_backward = False
+        self._opt_begun = False
+        self._opt_done: List = []                    # [lo, hi) ranges of the flat buffers already updated in this step
 
     # ---------------------------------------------------------------- backward side
+    def _opt_slice(self, lo: int, hi: int) -> None:
+        """AdamW on parameters [lo, hi) on the CURRENT stream (coefficients of the step uploaded on that stream the first time)."""
+        if not self._opt_begun:
+            self.optimizer.begin_step()
+            self.optimizer.upload_coef()
+            self._opt_begun = True
+        self.optimizer.step_range(lo, hi, grad_scale=1.0 / self.bucket.world, zero_grad=True)
+        self._opt_done.append((lo, hi))
+
     def _defer(self, fn, tensors) -> None:
         self._deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)]))
 
@@ -283,7 +297,15 @@ class AdapterDataParallel:
         self._done.add(l)
         if self.bucket.world > 1 and (l % self.bucket.layers_per_bucket) == 0:
             self._join_deferred()                    # a bucket must not ship before its dA_m have landed
-        self.bucket.layer_done(l)
+        self.bucket.layer_done(l)                    # (N > 1 with opt_in_backward: bucket.on_reduced runs the bucket's AdamW slice behind its all-reduce)
+        if self.opt_in_backward and self.bucket.world == 1 and (l % self.bucket.layers_per_bucket) == 0:
+            dev = self.bucket.flat.device
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(torch.cuda.current_stream(dev))      # the bucket's in-chain gradients (dB at r <= 32, dx-side sinks) are on the main stream
+            with torch.cuda.stream(self._side):
+                self._opt_slice(*self.bucket.bucket_bounds(l))
+            self._side_busy = True
 
     def _forward_begins(self) -> None:
         """Called from the decoder layers' forward pre-hooks.  A NEW forward while buckets of the previous backward are on their
@@ -327,6 +349,18 @@ class AdapterDataParallel:
         of the norm).  Returns the norm of the averaged gradient when clipping is on."""
         if self.optimizer is None:
             raise RuntimeError("attach(..., optimizer=False): call finish() and run your own optimizer on dp.master / dp.bucket.flat")
+        if self.opt_in_backward:
+            if max_grad_norm is not None and max_grad_norm > 0:
+                raise RuntimeError("attach(optimizer_in_backward=True) updates a bucket before the global gradient norm exists: no clipping in this mode")
+            self.finish(average=False)               # ships what the hooks did not; joins the side / communication streams (and their slices)
+            done, pos = sorted(self._opt_done), 0
+            for lo, hi in done + [(self.bucket.flat.numel(), self.bucket.flat.numel())]:
+                if lo > pos:
+                    self._opt_slice(pos, lo)         # whatever no bucket hook covered (parameters outside the decoder stack, frozen layers' groups)
+                pos = max(pos, hi)
+            self._opt_done.clear()
+            self._opt_begun = False
+            return None
         self.finish(average=False)
         scale = 1.0 / self.bucket.world
         norm = None
@@ -380,7 +414,8 @@ class AdapterDataParallel:
 
 def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: bool = True, lr: float = 1e-4,
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-           comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True) -> AdapterDataParallel:
+           comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True,
+           optimizer_in_backward: bool = False) -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
     base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
@@ -404,7 +439,11 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
       layer's backward has been enqueued -- they run beside the next layer's chain -- and joins before a bucket ships / before the
       optimizer step (adapter-only step of the 7B workload: 35.1 -> 34.4 ms);
     * ``step()`` joins, and one kernel (``moka_adamw_flat``) averages (and clips), applies AdamW, refreshes the working
-      copies and zeroes the gradients.
+      copies and zeroes the gradients;
+    * ``optimizer_in_backward``: the AdamW update of a finished bucket of layers is enqueued at once -- on the side stream behind the
+      bucket's deferred dA_m (one GPU) or on the communication stream behind its all-reduce (N > 1, fp32 payload) -- and overlaps the
+      backward of the earlier layers; ``step()`` then only updates what no bucket covered.  No gradient clipping in this mode (the
+      global norm does not exist yet when the first bucket is updated), and every synchronised backward must be followed by ``step()``.
 
     Replaces DeepSpeed ZeRO-2's bucketed reduce-scatter + partitioned optimizer of the reference configurations
     (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``)."""
@@ -472,6 +511,14 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
             grad_view[n] = bucket.flat[o:o + sz].view(p.shape)
     opt = FlatAdamW(master, bucket.flat, work, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if optimizer else None
     dp = AdapterDataParallel(model, bucket, master, work, names, offsets, sizes, opt, [])
+    if optimizer_in_backward:
+        if opt is None or dev.type != "cuda":
+            raise ValueError("attach(optimizer_in_backward=True) needs the built-in optimizer and a GPU")
+        if bucket.world > 1 and bucket.comm_dtype is not None:
+            raise ValueError("attach(optimizer_in_backward=True): the bucket update runs behind an fp32 all-reduce (no comm_dtype)")
+        dp.opt_in_backward = True
+        if bucket.world > 1:
+            bucket.on_reduced = dp._opt_slice
     # sinks of the adapted projections (both mirrors)
     mods = {}
     for n in fed:

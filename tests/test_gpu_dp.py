@@ -431,3 +431,74 @@ def test_optimizer_slices_behind_the_bucket_all_reduce_on_two_ranks():
     assert torch.equal(got[0], got[1])
     err = ((got[0] - master.cpu()).norm() / master.cpu().norm()).item()
     assert err <= 1e-6, err
+
+
+@pytest.mark.parametrize("defer", [True, False])
+def test_optimizer_in_backward_takes_the_same_steps(defer):
+    """attach(optimizer_in_backward=True): a finished bucket's AdamW slice runs on the side stream while the earlier layers' backward is
+    still being enqueued; after three steps (the second one after a no_sync micro-batch) the parameters equal those of the step() that
+    updates everything in one launch (same kernel arithmetic; the weight gradients' atomics may differ in order)."""
+    dev = torch.device("cuda:0")
+    from moka_amd.parallel import attach
+    outs = []
+    for inb in (False, True):
+        st, dims = _build("avt", dev)
+        dp = attach(st, n_buckets=3, lr=1e-2, weight_decay=0.01, defer_dA=defer, optimizer_in_backward=inb)
+        h, gout, mask_args, sl = _batch("avt", dims, dev)
+        for step in range(3):
+            if step == 1:
+                with dp.no_sync():
+                    _run(st, dp, h[:1], gout[:1], sl(0, 1), 1.0)
+                _run(st, dp, h[1:], gout[1:], sl(1, 2), 1.0)
+            else:
+                _run(st, dp, h, gout, mask_args, 0.5)
+            dp.step()
+        torch.cuda.synchronize()
+        assert float(dp.bucket.flat.abs().max()) == 0.0 and dp.optimizer.t == 3
+        outs.append((dp.master.clone(), dp.work.clone()))
+    err = ((outs[0][0] - outs[1][0]).norm() / outs[0][0].norm()).item()
+    assert err <= 1e-5, err
+    assert (outs[0][1].float() - outs[1][1].float()).abs().max().item() <= 2 ** -6      # bf16 copies: at most an ulp of rounding apart
+    with pytest.raises(RuntimeError):
+        dp.step(max_grad_norm=1.0)
+
+
+def _inb_worker(rank, world, port, inb, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import attach
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    st, dims = _build("avt", dev)
+    dp = attach(st, n_buckets=2, lr=1e-2, optimizer_in_backward=inb)
+    h, gout, _, sl = _batch("avt", dims, dev)
+    for _ in range(2):
+        _run(st, dp, h[rank:rank + 1], gout[rank:rank + 1], sl(rank, rank + 1), 1.0)
+        dp.step()
+    torch.cuda.synchronize()
+    q.put((rank, dp.master.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimizer_in_backward_on_two_ranks():
+    """N > 1: the bucket's update runs on the communication stream behind its all-reduce (FlatGradBucket.on_reduced); both ranks end with the
+    parameters the one-launch step gives."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for inb in (False, True):
+        q, port = ctx.Queue(), _free_port()
+        procs = [ctx.Process(target=_inb_worker, args=(r, 2, port, inb, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=240) for _ in range(2))
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert (got[0] == got[1]).all()
+        res[inb] = torch.from_numpy(got[0])
+    err = ((res[True] - res[False]).norm() / res[False].norm()).item()
+    assert err <= 1e-5, err
