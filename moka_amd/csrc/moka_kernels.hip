@@ -3408,13 +3408,14 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         // RP == 16: the per-tile form (text set resident, the others fetched for the tiles that need them); contiguous runs with one
         // resident set lose there (dx pass 11.1 -> 11.8 ms), win at rank pad 32 (16.2 -> 15.9) and 64 (37.4 -> 30.7, with 128 columns per wave)
         // r <= 32: the token-owning form for BATCHED launches of equal, moderate width (7B widths, r = 16: gate+up 155.8 -> 146.0 us, q+k+v 84.1 -> 77.7,
-        // step 34.14 -> 33.93 ms on one box, twice); single projections stay (32.0 -> 32.2-33.6 us), and so do the 70B batches (q / k / v of
-        // different width, 2 x 28672 gate / up: step 165.8 -> 167.6 ms).  "expand_nq" 5 / 6: always / never.
+        // step 34.14 -> 33.93 ms on one box, twice; 70B gate+up, 2 x 28672: up_fwd 48.7 -> 45.2 ms per pass, step 161.9 -> 160.7 ms); single
+        // projections stay (32.0 -> 32.2-33.6 us), and so do batches of different width (70B q / k / v = 8192 / 1024 / 1024: with them the
+        // step went 165.8 -> 167.6 ms).  "expand_nq" 5 / 6: always / never.
         if (RP <= 32 && W_CK && g_tune_expand_nq != 6) {
             bool uniform = true;
             size_t cols = 0;
             for (int z = 0; z < nz; ++z) { uniform = uniform && ab.z[z].C == ab.z[0].C; cols += (size_t)ab.z[z].C; }
-            if (g_tune_expand_nq == 5 || (nz > 1 && uniform && cols <= 32768)) return RP == 16 ? launch_yt<16>(ab, nz, st) : launch_yt<32>(ab, nz, st);
+            if (g_tune_expand_nq == 5 || (nz > 1 && uniform && cols <= 65536)) return RP == 16 ? launch_yt<16>(ab, nz, st) : launch_yt<32>(ab, nz, st);
         }
         if (RP == 16) { if (g_tune_expand_depth == 3) launch_expand_t<16, 4, W_CK, 1, 3>(ab, nz, st); else launch_expand_t<16, 4, W_CK, 1, 2>(ab, nz, st); }
         // wider ranks: the y kernel keeps 128 columns per wave (r = 64: 48 -> 34 us at 4096), the dx kernel 64
