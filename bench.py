@@ -82,9 +82,10 @@ class Unit:
     """The projections of one decoder layer that are fed by the same input (q/k/v; o; gate/up; down) with the
     ctypes argument lists of the six (grouped) entry points pre-built.  G = 1 is the per-projection path."""
 
-    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None):
+    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False):
         from moka_amd import _lib
         G = len(members)
+        self.fused = fused
         self.label, self.G, self.T = label, G, T
         self.d_in = members[0]["d_in"]
         self.d_outs = [m["d_out"] for m in members]
@@ -114,6 +115,13 @@ class Unit:
             "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
                                                         BwT, AT, G, r, w, c)),
             "moka_up_fwd": ("moka_up_fwd_group", (hp_tok, Bw, tm, y, T, r, do, G, 0)),
+            # --fuse-fwd (default): the up-projection computes the interaction itself from the slices (moka_up_fwd_fused); the rank-space
+            # launch only writes what the BACKWARD reads (h, hp_kmj, BwT, AT: hp_tok = NULL) and leaves the dependency chain
+            "moka_up_fwd:fused": ("moka_up_fwd_fused_group", (part, ks_in, byref(rt.struct), so, Bw, y, do, h, hp_kmj, G, r, w, c, 0)),
+            "moka_cross_fwd:state": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, None, hp_kmj,
+                                                              BwT, AT, G, r, w, c)),
+            # the weight shadows the backward reads (BwT, AT): functions of the weights alone -> once per step, off the chain
+            "moka_weight_shadows": ("moka_weight_shadows_group", (Bw, do, A, self.d_in, BwT, AT, G, r, M)),
             "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0, None)),
             # the two outputs of moka_up_bwd as separate calls (--defer-db: where dB is a pass of its own anyway, moka_up_bwd_passes() == 2,
             # it leaves the dependency chain like dA_m)
@@ -136,7 +144,8 @@ class Unit:
         #   up_bwd  : read gy E*T*d_out     down_bwd: read x, r+w dx  3*E*T*d_in
         sdo = sum(self.d_outs)
         self.algo = {"moka_down_fwd": E * T * self.d_in * G, "moka_up_fwd": 2 * E * T * sdo, "moka_up_bwd": E * T * sdo,
-                     "moka_down_bwd": 3 * E * T * self.d_in * G, "moka_cross_fwd": 3 * 4 * T * r * G, "moka_cross_bwd": 3 * 4 * T * r * G}
+                     "moka_down_bwd": 3 * E * T * self.d_in * G, "moka_cross_fwd": 3 * 4 * T * r * G, "moka_cross_bwd": 3 * 4 * T * r * G,
+                     "moka_weight_shadows": 2 * E * r * (sdo + M * self.d_in * G)}
 
 
 def build_workload(args, dev, lib, bucket_factory, chains=1):
@@ -159,6 +168,8 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
     RP = _lib.rank_pad(r)
     bf, f32 = torch.bfloat16, torch.float32
     width = lambda k: dims[k]          # noqa: E731
+    fused = getattr(args, "fuse_fwd", "off") == "on" and _lib.up_fwd_fused_ok(r)
+    args.fused = fused
 
     # flat parameter / gradient buckets (fp32 master, bf16 working copy, fp32 grads)
     per_layer = sum(M * r * width(di) + r * width(do) for _, di, do, _ in PROJS)
@@ -222,9 +233,12 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
             ys = [torch.randn(Tc, width(do), device=dev, dtype=bf) for _, _, do, _ in PROJS]
             sets.append((acts, dacts, ys))
         # scratch shared by all units of the chain (consumed before the next unit overwrites it), one slot per group member
-        scratch = [dict(part=torch.empty(max_ks, Tc, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
-                        dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
-                   for _ in range(3)]
+        # (two sets, alternating from unit to unit: with --fuse-fwd the state launch of unit u reads its slices on a side stream while
+        #  unit u + 1 already writes its own)
+        scratch2 = [[dict(part=torch.empty(max_ks, Tc, RP, dtype=f32, device=dev), hp_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev),
+                          dh_tok=torch.empty(Tp, 2 * RP, dtype=bf, device=dev), dh_kmj=torch.empty(M, 2, RP, Tp, dtype=bf, device=dev))
+                     for _ in range(3)] for _ in range(2)]
+        scratch = scratch2[0]
         units = []
         defer = getattr(args, "defer_da", "off") != "off"
         own = [[[torch.empty(M, 2, RP, Tp, dtype=bf, device=dev) for _ in pis] for _, pis in unit_defs] for _ in range(2)] if defer else None
@@ -237,17 +251,17 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                                     BwT=torch.empty(RP, pr["d_out"], dtype=bf, device=dev), AT=torch.empty(M, pr["d_in"], RP, dtype=bf, device=dev)))
             for src, pis in unit_defs:
                 mem = [members[pi] for pi in pis]
-                units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch,
+                units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch2[len(units) & 1],
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
-                                  own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None))
+                                  own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None, fused=fused))
         chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc))
-        keep.append((sets, masks, scratch, own))
+        keep.append((sets, masks, scratch2, own))
     return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], chains=chain_list, master=master, work=work,
                 gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
-ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd"]
+ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd", "moka_weight_shadows"]
 
 
 LIVE = ("moka_up_fwd",)     # the dominant single-kernel entry point, bracketed inside the timed region
@@ -272,29 +286,51 @@ class Recorder:
         self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(n))
 
 
-def _call(lib, name, u, sp, rec):
-    """Launch one entry point of unit `u`; bracket it with HIP events when the recorder asks for it."""
+def _call(lib, name, u, sp, rec, stream=None):
+    """Launch one entry point of unit `u`; bracket it with HIP events (on `stream`, default: torch's current stream, which is the
+    launch stream of the bracketed passes) when the recorder asks for it.  "entry:variant" is recorded as "entry"."""
     sym, args = u.calls[name]
-    if rec is None or (rec.only is not None and name not in rec.only) or rec.skip():
+    base = name.split(":")[0]
+    if rec is None or (rec.only is not None and base not in rec.only) or rec.skip():
         rc = getattr(lib, sym)(*args, sp)
     else:
         e0, e1 = rec.event(), rec.event()
-        e0.record()
+        e0.record(stream) if stream is not None else e0.record()
         rc = getattr(lib, sym)(*args, sp)
-        e1.record()
-        rec.items.append((name, u, e0, e1))
+        e1.record(stream) if stream is not None else e1.record()
+        rec.items.append((base, u, e0, e1))
     if rc:
         raise RuntimeError(lib.moka_last_error().decode())
 
 
-def run_forward(lib, wl, sp, rec=None):
-    for u in wl["units"]:
+def run_forward(lib, wl, sp, rec=None, shadows=False):
+    """Per unit: down-projection, interaction, up-projection.  Fused units (--fuse-fwd): down-projection -> up-projection with the
+    interaction inside (it also writes h and the rank-major hp pack for the backward).  The weight shadows the backward reads (BwT, AT)
+    are functions of the weights alone: they are rewritten where the weights change (run_shadows behind the optimizer step), not in
+    the forward -- unless `shadows` asks for them in front of every unit (--shadows main)."""
+    units = wl["units"]
+    if not units[0].fused:
+        for u in units:
+            _call(lib, "moka_down_fwd", u, sp, rec)
+            _call(lib, "moka_cross_fwd", u, sp, rec)
+            _call(lib, "moka_up_fwd", u, sp, rec)
+        return
+    for u in units:
+        if shadows:
+            _call(lib, "moka_weight_shadows", u, sp, rec)
         _call(lib, "moka_down_fwd", u, sp, rec)
-        _call(lib, "moka_cross_fwd", u, sp, rec)
-        _call(lib, "moka_up_fwd", u, sp, rec)
+        _call(lib, "moka_up_fwd:fused", u, sp, rec)
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None):
+def run_shadows(lib, wl, sp, layers, rec=None):
+    """BwT / AT of the given layers (all chains share the parameters: the first chain's units carry the buffers)."""
+    units, per = wl["units"], wl["units_per_layer"]
+    for l in layers:
+        for u in units[l * per:(l + 1) * per]:
+            _call(lib, "moka_weight_shadows", u, sp, rec)
+
+
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False):
     """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
     defer = (mode, main_stream, side_stream): the dA_m halves of a layer's moka_down_bwd calls leave the dependency chain (only the
     optimizer needs them) and are enqueued after the layer's chain -- "main": on the same stream; "side": on a second stream,
@@ -340,6 +376,9 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
                     blo, bhi = bucket_.bucket_bounds(l)
                     with torch.cuda.stream(side):
                         opt_.step_range(blo, bhi, grad_scale=scale_, zero_grad=True)
+                        if shadows_after_opt:
+                            # the bucket's weights have just changed: their shadows for the NEXT step's backward, still off the chain
+                            run_shadows(lib, wl, sps, range(l, min(n_layers, l + bucket_.layers_per_bucket)))
             ev = torch.cuda.Event()
             ev.record(side)
             done[l] = ev
@@ -585,6 +624,13 @@ def main():
                     help="stream priority of the captured dependency chain (the deferred dA / dB stream stays at normal priority)")
     ap.add_argument("--defer-db", choices=("auto", "on", "off"), default="auto",
                     help="with --defer-da: dB also leaves the dependency chain (auto: where moka_up_bwd_passes() says dB is a pass of its own, r > 32)")
+    ap.add_argument("--fuse-fwd", choices=("on", "off"), default="on",
+                    help="on (default, r <= 32): the up-projection computes the cross-modal interaction itself (moka_up_fwd_fused) and the rank-space "
+                         "launch, which then only writes the backward's operands, runs on a side stream off the dependency chain; off: three launches per unit")
+    ap.add_argument("--shadows", choices=("opt", "main"), default="opt",
+                    help="with --fuse-fwd on: where the weight-shadow launches (BwT / AT, functions of the weights alone, read by the backward) run: "
+                         "opt = where the weights change, behind the optimizer update (per gradient bucket on the side / communication stream with "
+                         "--opt-in-backward); main = in front of every unit on the forward's chain")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -655,11 +701,26 @@ def main():
     # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and args.chains == 1 and
                   ((world == 1 and args.defer_da == "side" and args.graph in ("auto", "all", "off")) or (world > 1 and not args.comm_bf16)))
+    # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
+    # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
+    shadows_main = bool(args.fused and args.shadows == "main")
+    shadows_opt = bool(args.fused and args.shadows == "opt")
+    shadows_in_cb = False
     if opt_in_bwd:
         opt.begin_step()
         opt.t -= 1                                   # (allocates the coefficient buffers; no step counted)
         if world > 1:
-            bucket.on_reduced = lambda blo, bhi: opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
+            ends = wl["layer_end"]
+
+            def _reduced(blo, bhi):
+                opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
+                if shadows_opt:                      # (on the communication stream, behind the bucket's update)
+                    run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), [l for l in range(L) if blo < ends[l] <= bhi])
+            bucket.on_reduced = _reduced
+            shadows_in_cb = shadows_opt
+    if args.fused:
+        run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), range(L))     # the initial weights' shadows
+        torch.cuda.synchronize()
 
     records = Recorder(only=LIVE, every=args.bracket_every)
     records.reserve(2 * len(wl["units"]) * args.steps + 16)
@@ -695,16 +756,17 @@ def main():
                             spg = c_void_p(st.cuda_stream)
                             if opt_in_bwd and ch is wl["chains"][0]:
                                 opt.upload_coef()            # (a copy from pinned memory: every replay reads this step's coefficients)
-                            run_forward(lib, ch, spg)
+                            run_forward(lib, ch, spg, shadows=shadows_main)
                             run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side, args.split_db) if args.defer_da != "off" else None,
-                                         bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None)
+                                         bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None,
+                                         shadows_after_opt=shadows_opt and opt_in_bwd and ch is wl["chains"][0])
                     for st in branch:
                         cur.wait_stream(st)          # join
             else:
                 da_side = torch.cuda.Stream(device=dev)
                 fwd_graph = torch.cuda.CUDAGraph()       # the forward has no hooks: one graph
                 with torch.cuda.graph(fwd_graph, stream=side):
-                    run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream))
+                    run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), shadows=shadows_main)
                 lpb = bucket.layers_per_bucket
                 bwd_graphs = []
                 for hi in range(L, 0, -lpb):             # buckets are aligned groups of layers, walked last -> first
@@ -739,7 +801,7 @@ def main():
             if fwd_graph is not None:
                 fwd_graph.replay()
             else:
-                run_forward(lib, wl, sp, rec)
+                run_forward(lib, wl, sp, rec, shadows=shadows_main)
             if bwd_graphs is not None:
                 for g, lo, hi in bwd_graphs:
                     g.replay()
@@ -748,7 +810,8 @@ def main():
             else:
                 run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
                              defer=(args.defer_da, main_stream, live_side, args.split_db) if args.defer_da != "off" else None,
-                             bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and world == 1) else None)
+                             bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and world == 1) else None,
+                             shadows_after_opt=shadows_opt and opt_in_bwd and world == 1)
         if comm_ev is not None and i >= args.warmup:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
@@ -759,6 +822,8 @@ def main():
             bucket.finish(average=opt is None)       # join the all-reduces; the optimizer kernel averages (grad_scale)
         if opt is not None and not opt_in_bwd:
             opt.step(grad_scale=1.0 / world, zero_grad=True)
+        if shadows_opt and opt is not None and not (opt_in_bwd and world == 1) and not shadows_in_cb:
+            run_shadows(lib, wl, sp, range(L))       # (every weight has changed: the shadows of the whole stack, behind the step)
 
     for i in range(args.warmup):
         step(i)
@@ -807,15 +872,17 @@ def main():
             # launch, as in the live mode) in extra live passes right behind it, same buffers, same kernel sequence
             for _ in range(min(args.steps, 3)):
                 for ch in wl["chains"]:
-                    run_forward(lib, ch, sp_, records)
+                    run_forward(lib, ch, sp_, records, shadows=shadows_main)
                     run_backward(lib, ch, sp_, L, None, None)
             torch.cuda.synchronize()
         tot, cnt, byt, per_shape = collect(records.items)         # the dominant entry point (LIVE)
         # every entry point, in one extra untimed pass (full bracketing would perturb the timed region)
         extra = Recorder()
         for ch in wl["chains"]:
-            run_forward(lib, ch, sp_, extra)
+            run_forward(lib, ch, sp_, extra, shadows=shadows_main)
             run_backward(lib, ch, sp_, L, None, extra)
+        if shadows_opt:
+            run_shadows(lib, wl, sp_, range(L), extra)
         torch.cuda.synchronize()
         tot_x, cnt_x, byt_x, per_shape_x = collect(extra.items)
         live_items = records.items
@@ -826,7 +893,8 @@ def main():
         # the dominant kernel: the largest entry point of a pass that is ONE kernel launch
         # (moka_up_fwd -> moka_yt_kernel<RP> for the batched launches, moka_expand_kernel<.., true> for single projections; grouped units
         #  run their members in one launch, grid z)
-        single = {"moka_up_fwd": "moka_yt_kernel<RP> / moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
+        single = {"moka_up_fwd": ("moka_yx_kernel<%d> (moka_up_fwd_fused: interaction + up-projection)" % _lib.rank_pad(args.rank)) if args.fused
+                  else "moka_yt_kernel<RP> / moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
         dom = "moka_up_fwd"
         dom_bytes = byt[dom]
         dom_avg_ms = tot[dom] / cnt[dom]
@@ -864,6 +932,7 @@ def main():
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
                             "adapter_params": wl["n_params"]},
             "graph": args.graph,
+            "fused_forward": bool(args.fused),
             "chains": args.chains,
             "defer_dA": args.defer_da,
             "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority, "optimizer_in_backward": bool(opt_in_bwd),

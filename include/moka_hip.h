@@ -69,9 +69,10 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      502            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+#define MOKA_VERSION      600            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
-                                            at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef() */
+                                            at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
+                                            0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
@@ -156,7 +157,7 @@ int moka_down_fwd(const void* x, const void* const* A /*host array of M device p
  * s_out[mod(t)] * hp[t] for the up-projection (hp_tok) and for dB (hp_kmj), plus the weight
  * shadows BwT / AT the backward kernels read (the weights do not change before the backward).
  * Replaces the per-sample Python loops lora.py:485-521 / layer.py:627-653.
- * hp (fp32), BwT and AT may be NULL (not written). */
+ * hp (fp32), hp_tok (when the up-projection is moka_up_fwd_fused), BwT and AT may be NULL (not written). */
 int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const float* s_out /*host, M floats*/,
                    const void* Bw, int d_out, const void* const* A /*host array, may be NULL with AT*/, int d_in,
                    float* h, float* hp, void* hp_tok, void* hp_kmj, void* BwT, void* AT,
@@ -166,6 +167,23 @@ int moka_cross_fwd(const float* part, int ks, const moka_routing* rt, const floa
  * base output).  Replaces lora.py:524-530 and layer.py:656-669 (gather, GEMM, scatter-add). */
 int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void* y_inout,
                 int T, int r, int d_out, int dtype, moka_stream_t stream);
+
+/* The up-projection WITH the interaction inside (round 4): y[t] += (s_out[mod(t)] hp[t]) Bw^T computed straight from the split-K
+ * slices of moka_down_fwd -- every workgroup of the token-owning y kernel sums the slices of its own 128 rows and of its sample's
+ * key rows and runs the rank-space softmax for its query rows itself (same arithmetic, same bits as moka_cross_fwd + moka_up_fwd),
+ * so the rank-space launch leaves the forward: down_fwd -> up_fwd_fused.  What only the BACKWARD reads comes out of the same launch
+ * when asked for -- h and hp_kmj (the workgroups of the first column range write the rows they computed anyway; the bits of
+ * moka_cross_fwd) -- and from moka_weight_shadows (BwT, AT: functions of the weights alone).
+ * Replaces lora.py:485-530 / layer.py:627-669.
+ * bf16 storage, r <= 32 (moka_up_fwd_fused_ok() == 1); otherwise MOKA_EINVAL -- use moka_cross_fwd + moka_up_fwd. */
+int moka_up_fwd_fused_ok(int r, int dtype);
+int moka_up_fwd_fused(const float* part, int ks, const moka_routing* rt, const float* s_out /*host, M floats*/,
+                      const void* Bw, void* y_inout, int d_out, float* h /*or NULL*/, void* hp_kmj /*or NULL*/,
+                      int r, float w, float inv_sqrt_dk, int dtype, moka_stream_t stream);
+/* BwT / AT alone (either may be NULL): the weight shadows depend on the weights only, so a trainer may write them once per
+ * optimizer step on any stream that is joined before the backward, instead of once per forward inside moka_cross_fwd. */
+int moka_weight_shadows(const void* Bw, int d_out, const void* const* A /*host array of M device ptrs*/, int d_in,
+                        void* BwT, void* AT, int r, int M, moka_stream_t stream);
 
 /* ---- backward ---------------------------------------------------------------------- */
 
@@ -219,6 +237,12 @@ int moka_cross_fwd_group(const float* const* part, int ks, const moka_routing* r
                          int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream);
 int moka_up_fwd_group(const void* const* hp_tok, const void* const* Bw, const uint8_t* tok_mod, void* const* y_inout,
                       int T, int r, const int* d_out, int G, int dtype, moka_stream_t stream);
+int moka_up_fwd_fused_group(const float* const* part /*[G]*/, int ks, const moka_routing* rt, const float* s_out,
+                            const void* const* Bw, void* const* y_inout, const int* d_out,
+                            float* const* h /*NULL or [G]*/, void* const* hp_kmj /*NULL or [G]*/,
+                            int G, int r, float w, float inv_sqrt_dk, int dtype, moka_stream_t stream);
+int moka_weight_shadows_group(const void* const* Bw, const int* d_out, const void* const* A /*[G*M]*/, int d_in,
+                              void* const* BwT /*NULL or [G]*/, void* const* AT /*NULL or [G]*/, int G, int r, int M, moka_stream_t stream);
 int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const void* const* BwT, const uint8_t* tok_mod,
                       const float* s_out, float* const* g_part, float* const* dB_acc,
                       int T, int r, const int* d_out, int M, int G, int dtype, const moka_opts* opts, moka_stream_t stream);

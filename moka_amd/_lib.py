@@ -58,6 +58,19 @@ SYMBOLS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
     # hp_tok, Bw, tok_mod, y, T, r, d_out, dtype, stream
     "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "moka_up_fwd_fused_ok": (c_int, [c_int, c_int]),
+    # part, ks, rt, s_out, Bw, y_inout, d_out, h, hp_kmj, r, w, inv_sqrt_dk, dtype, stream
+    "moka_up_fwd_fused": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), POINTER(c_float), c_void_p, c_void_p,
+                                  c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
+    # part[], ks, rt, s_out, Bw[], y_inout[], d_out[], h[], hp_kmj[], G, r, w, inv_sqrt_dk, dtype, stream
+    "moka_up_fwd_fused_group": (c_int, [POINTER(c_void_p), c_int, POINTER(MokaRoutingStruct), POINTER(c_float), POINTER(c_void_p),
+                                        POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+                                        c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    # Bw, d_out, A[], d_in, BwT, AT, r, M, stream
+    "moka_weight_shadows": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    # Bw[], d_out[], A[], d_in, BwT[], AT[], G, r, M, stream
+    "moka_weight_shadows_group": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                          c_int, c_int, c_int, c_void_p]),
     # gy, hp_kmj, BwT, tok_mod, s_out[], g_part, dB_acc, T, r, d_out, M, dtype, opts, stream
     "moka_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, POINTER(MokaOpts), c_void_p]),
@@ -168,6 +181,17 @@ def up_bwd_passes(r: int, dtype: int = 0) -> int:
             raise ValueError(f"unsupported rank / storage type for the HIP path: r={r} dtype={dtype}")
         _PASSES[key] = n
     return _PASSES[key]
+
+
+_FUSED = {}
+
+
+def up_fwd_fused_ok(r: int, dtype: int = 0) -> bool:
+    """True when moka_up_fwd_fused (the interaction inside the up-projection) exists for this rank / storage type."""
+    key = (int(r), int(dtype))
+    if key not in _FUSED:
+        _FUSED[key] = load().moka_up_fwd_fused_ok(*key) == 1
+    return _FUSED[key]
 
 
 def tok_pad(T: int) -> int:

@@ -253,8 +253,10 @@ template <int RP>
 static __device__ __forceinline__ void write_packs_fwd(const CrossArgs& a, int t, int k, float v_scaled) {
     unsigned short hi, lo;
     split_hi_lo(v_scaled, hi, lo);
-    a.pack_tok[(size_t)t * (2 * RP) + k] = hi;
-    a.pack_tok[(size_t)t * (2 * RP) + RP + k] = lo;
+    if (a.pack_tok) {                                   // (null when the up-projection computes the interaction itself: moka_up_fwd_fused)
+        a.pack_tok[(size_t)t * (2 * RP) + k] = hi;
+        a.pack_tok[(size_t)t * (2 * RP) + RP + k] = lo;
+    }
     a.pack_kmj[kmj_off<RP>(0, k, t, a.Tp)] = hi;
     a.pack_kmj[kmj_off<RP>(1, k, t, a.Tp)] = lo;
 }
@@ -546,8 +548,10 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
             }
             *(f32x4*)(a.out_f32 + (size_t)t * RP + 4 * k4) = hv;
             if (a.out_f32b) *(f32x4*)(a.out_f32b + (size_t)t * RP + 4 * k4) = hpv;
-            *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + 4 * k4) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-            *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + RP + 4 * k4) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+            if (a.pack_tok) {
+                *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + 4 * k4) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+                *(uint2*)(a.pack_tok + (size_t)t * (2 * RP) + RP + 4 * k4) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+            }
         }
         for (int e = tid; e < RP * (nrow >> 2); e += NTH) {
             const int k = e / (nrow >> 2), row = (e % (nrow >> 2)) << 2;
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
             const float hv = Hs[row * KP + k], hpv = Hp[row * KP + k];
             a.out_f32[(size_t)t * RP + k] = hv;
             if (a.out_f32b) a.out_f32b[(size_t)t * RP + k] = hpv;
-            write_pack_tok<RP>(a.pack_tok, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
+            if (a.pack_tok) write_pack_tok<RP>(a.pack_tok, t, k, hpv * mod_scale(a.s_mod, s_mod[row]));
         }
         // rank-major pack: consecutive lanes <-> consecutive tokens (positions permuted inside a group of 32)
         for (int e = tid; e < RP * RB; e += NTH) {
@@ -583,6 +587,13 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     if (b == a.B - 1 && blockIdx.y == nrb - 1) {
         for (int e = tid; e < (a.Tp - a.T) * RP; e += NTH) write_packs_fwd<RP>(a, a.T + e / RP, e % RP, 0.f);
     }
+}
+
+// The weight shadows alone (moka_weight_shadows): they depend on the weights only, so a trainer writes them once per optimizer
+// step, off the forward's dependency chain.  blockIdx.z = problem.
+template <int RP>
+__global__ void __launch_bounds__(256) moka_shadows_kernel(const CrossBatch ab) {
+    cross_weight_shadows<RP>(ab.z[blockIdx.z], (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, 256);
 }
 
 // Backward, part a.  Block = 4 waves on ONE tile of 16 consecutive token rows; the four waves split the KEYS of a chunk
@@ -1499,6 +1510,329 @@ __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, i
         const int cb = ch * CWK;
         issue_o(onext, ch + 1);
         __syncthreads();                                                     // the previous chunk's fragments are no longer read
+#pragma unroll
+        for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+        __syncthreads();
+        if (ch + 1 < ch1) wload(ch + 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 d[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+                    const bf16x8 wf = wl[((size_t)q * 2 + p) * KH * 64 + kh * 64 + lane];
+                    d[p] = MFMA16(wf, bh[kh], d[p]);
+                    if (RP != 16) d[p] = MFMA16(wf, bl[kh], d[p]);
+                }
+            }
+            if (cb + 32 * q >= a.C) continue;                                // C % 32 == 0 (block uniform)
+            union { bf16x8 b; unsigned u[4]; } ou, res;
+            ou.b = o[q];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)
+                res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + d[(2 * w2) >> 2][(2 * w2) & 3],
+                                    __uint_as_float(ou.u[w2] & 0xffff0000u) + d[(2 * w2 + 1) >> 2][(2 * w2 + 1) & 3]);
+            if (valid) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+        }
+    };
+    wload(ch0);
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        step(oA, oB, ch);
+        if (ch + 1 < ch1) step(oB, oA, ch + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// X + E (round 4): y += (s_out[mod] hp) . Bw^T with the cross-modal interaction computed INSIDE the token-owning y kernel -- the
+// rank-space launch (moka_cross_fwd) leaves the forward's dependency chain.  A workgroup owns 128 tokens (wave w the 16-token tile w)
+// and, before it walks its column range exactly like moka_yt_kernel, builds the MFMA B operand of its tile itself:
+//   1. the wave sums the ks split-K slices of ITS 16 rows (one stream of loads, slice order: the bits of moka_cross_fwd's h);
+//   2. workgroups that hold query rows stage their sample's key rows (the slices of the <= Lk question tokens, chunks of 64, running
+//      softmax -- the span is unbounded as in moka_cross_fwd) in LDS and the waves with query rows run the fp32-MFMA attention of
+//      moka_cross_fwd_kernel on their tile (same operand maps, same order of operations: the results are bit-identical);
+//   3. every lane splits the 8 scaled hp values it contributes to the operand into hi / lo in registers.
+// There is NO hand-over between workgroups: what a workgroup needs from other tokens (the key rows) it sums again from the
+// L2-resident slices, which is why the launcher keeps the number of column ranges per token block small (every range repeats
+// steps 1-2: ks x 64 B per token).  The y loads of the first chunk are requested before step 1, so the HBM latency of the stream
+// hides the prologue's L2 round trips.  h, the rank-major hp pack and the weight shadows, which only the BACKWARD reads, come from a
+// moka_cross_fwd launch the caller enqueues off the chain (hp_tok = NULL).  blockIdx.z = problem.
+// ------------------------------------------------------------------------------------------
+struct YxArgs {
+    const float* part;              // [ks][T][RP] split-K slices of moka_down_fwd
+    const unsigned char* Bw;        // [C][r] bf16
+    unsigned char* out;             // [T][C] bf16, in/out
+    float* h_out;                   // [T][RP] fp32 or null      } what the BACKWARD reads: written by the workgroups of the first column
+    unsigned short* kmj_out;        // hp_kmj pack or null       } range (blockIdx.x == 0), one per 128-token block
+    int C;
+};
+struct YxBatch {
+    YxArgs z[MOKA_MAX_GROUP];
+    const unsigned char* tok_mod;
+    const int* ktok;                // [B][Lkp]
+    const int* klen;                // [B]
+    float s_mod[4];                 // s_out per modality
+    int ks, B, S, T, Tp, Lkp, r;
+    float w, c;
+    int dbg;                        // diagnostics build only (timing ablations, wrong results): 1 = no interaction, 2 = no slice sums either
+};
+
+#ifndef YX_MINW
+#define YX_MINW 4
+#endif
+template <int RP>
+__global__ void __launch_bounds__(512, YX_MINW) moka_yx_kernel(const YxBatch fb, int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 8 KH fragments (1 KB each) per chunk
+    constexpr int PER = NF * 64 / 512;                                       // KH fragments per thread and chunk
+    constexpr int KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
+    constexpr int IPT = (16 * R4) / 64;                                      // float4 elements of the wave's [16 x RP] row tile per lane
+    constexpr int SB = (IPT >= 4) ? 2 : 8 / IPT;                             // slices requested together (8 loads in flight per lane)
+    bf16x8* wl = (bf16x8*)smem;                                              // column walk: [NQ][2][KH][64] (reuses the prologue's area)
+    const YxArgs& a = fb.z[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    float* Hs = (float*)smem + wave * (2 * 16 * KP);                         // per wave: h rows [16][KP]
+    float* Hp = Hs + 16 * KP;                                                //           hp rows [16][KP]
+    float* Ks = (float*)smem + 8 * 2 * 16 * KP;                              // [KC][KP] one chunk of key rows (workgroup)
+    const int T = fb.T;
+    const int ntiles = (T + 15) >> 4;
+    const int tile = blockIdx.y * 8 + wave;
+    const bool live = tile < ntiles;
+    const int tile16 = min(tile, ntiles - 1) << 4;
+    const int t = min(tile16 + i, T - 1);
+    const bool valid = live && ((tile << 4) + i) < T;
+    const int nch = (a.C + CWK - 1) / CWK;
+    const int ch0 = blockIdx.x * chunks_per_block, ch1 = min(nch, ch0 + chunks_per_block);
+    if (ch0 >= ch1) return;                                                  // a narrower problem of the batch (block uniform)
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    unsigned char* orow0 = a.out + ((size_t)t * a.C + 8 * g) * 2;
+    bf16x8 oA[NQ], oB[NQ];
+    auto issue_o = [&](bf16x8 (&o)[NQ], int ch_) {
+        const int cb = min(ch_, ch1 - 1) * CWK;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
+    };
+    issue_o(oA, ch0);                                                        // HBM first: its latency covers the prologue below
+
+    // routing of the block's first sample, requested with everything else that depends on nothing (a block almost always lies inside
+    // one sample): the key slices of a query block are then ONE dependent round trip behind the kernel's first, not two
+    const int b_lo = min((int)blockIdx.y * 128, T - 1) / fb.S, b_hi = min((int)blockIdx.y * 128 + 127, T - 1) / fb.S;
+    constexpr int KI = (KC * R4 + 511) / 512;                                // key-row float4 elements per thread and chunk
+    const int Lk0 = fb.klen[b_lo];
+    int tk_pre[KI];
+#pragma unroll
+    for (int u = 0; u < KI; ++u) tk_pre[u] = fb.ktok[b_lo * fb.Lkp + min((tid + 512 * u) / R4, fb.Lkp - 1)];
+
+    // ---- 1. h rows of my tile: lane e <-> (row e / R4, ranks 4 (e % R4) ..), slices summed in slice order
+    const size_t sstride = (size_t)T * RP;
+    {
+        size_t offR[IPT];
+        int rmod[IPT];
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int e = lane + 64 * u, row = e / R4, k4 = e % R4;
+            offR[u] = (size_t)min(tile16 + row, T - 1) * RP + 4 * k4;
+            rmod[u] = live ? (int)fb.tok_mod[tile16 + row] : MOKA_MOD_NONE;  // (padded past T with MOKA_MOD_NONE)
+        }
+        f32x4 accR[IPT];
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) accR[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ks_eff = (fb.dbg & 2) ? 1 : fb.ks;
+        for (int s0 = 0; s0 < ks_eff; s0 += SB) {
+            f32x4 xr[IPT][SB];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const size_t so = (size_t)min(s0 + q, ks_eff - 1) * sstride;
+#pragma unroll
+                for (int u = 0; u < IPT; ++u) xr[u][q] = *(const f32x4*)(a.part + offR[u] + so);
+            }
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < IPT; ++u) accR[u] += (s0 + q < fb.ks) ? xr[u][q] : z;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int e = lane + 64 * u, row = e / R4, k4 = e % R4;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                // tokens of no modality (their partial rows were never written): h = 0
+                const float hv = (rmod[u] == MOKA_MOD_NONE) ? 0.f : accR[u][cc];
+                Hs[row * KP + 4 * k4 + cc] = hv;
+                Hp[row * KP + 4 * k4 + cc] = hv;
+            }
+        }
+    }
+    const int my_mod = live ? (int)fb.tok_mod[tile16 + i] : MOKA_MOD_NONE;
+    const bool isq = (my_mod != 0 && my_mod != MOKA_MOD_NONE);
+    const int my_b = t / fb.S;
+
+    // ---- 2. the interaction for the query rows of my tile, sample by sample (a 128-token block usually lies inside one sample)
+    for (int b = b_lo; b <= b_hi; ++b) {
+        const int Lk = (b == b_lo) ? Lk0 : fb.klen[b];
+        const bool mine = isq && my_b == b && Lk > 0 && !(fb.dbg & 1);
+        if (!__syncthreads_or(mine)) continue;                               // (block uniform; also: everybody is done with the previous sample's keys)
+        const bool wq = __any(mine);                                         // this wave's 16 rows contain query rows of sample b
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4 O[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) O[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float qf[KS4];
+#pragma unroll
+        for (int ks = 0; ks < KS4; ++ks) qf[ks] = Hs[i * KP + 4 * ks + g];
+        const int nchk = (Lk + KC - 1) / KC;
+        for (int c = 0; c < nchk; ++c) {
+            if (c) __syncthreads();                                          // everybody is done with the previous chunk
+#pragma unroll
+            for (int u = 0; u < KI; ++u) {
+                const int e = tid + 512 * u;
+                if (e < KC * R4) {
+                    const int jj = e / R4, k4 = e % R4;
+                    const int j = c * KC + jj;
+                    int tk = (b == b_lo && c == 0) ? tk_pre[u] : fb.ktok[b * fb.Lkp + min(j, fb.Lkp - 1)];
+                    if (j >= Lk) tk = -1;
+                    f32x4 v = sum_slices4(a.part + (size_t)max(tk, 0) * RP + 4 * k4, sstride, fb.ks);
+                    if (tk < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};             // zero key row (still enters the softmax when slot < Lk)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) Ks[jj * KP + 4 * k4 + cc] = v[cc];
+                }
+            }
+            __syncthreads();
+            if (!wq) continue;                                               // wave uniform
+            f32x4 st[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                st[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS4; ++ks) st[tt] = MFMA4F(Ks[(16 * tt + i) * KP + 4 * ks + g], qf[ks], st[tt]);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float sv = (c * KC + 16 * tt + 4 * g + reg < Lk) ? st[tt][reg] * fb.c : -INFINITY;
+                    st[tt][reg] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+            mx = rows_max(mx);
+            const float m_new = fmaxf(m_run, mx);                            // finite: every chunk holds at least one key
+            const float alpha = __expf(m_run - m_new);                       // 0 on the first chunk
+            float ls = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { const float pv = __expf(st[tt][reg] - m_new); st[tt][reg] = pv; ls += pv; }
+            ls = rows_sum(ls);
+            l_run = fmaf(l_run, alpha, ls);
+            m_run = m_new;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                O[nt] *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp) O[nt] = MFMA4F(Ks[(16 * tt + 4 * g + sp) * KP + 16 * nt + i], st[tt][sp], O[nt]);
+            }
+        }
+        if (wq && mine) {
+            const float wl_ = fb.w / l_run;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = 16 * nt + 4 * g + reg;
+                    Hp[i * KP + k] = fmaf(wl_, O[nt][reg], Hs[i * KP + k]);
+                }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // (wave-private rows: written by other lanes of this wave)
+
+    // ---- 2b. the first column range of a token block also writes what the backward reads: h (fp32 rows) and the rank-major pack of
+    //      s_out[mod] * hp (per (rank, 4 tokens) two 8-byte stores: four consecutive tokens of a group of 32 sit at four consecutive
+    //      positions, see kmj_pos) -- the values and the layout of moka_cross_fwd
+    if (blockIdx.x == 0 && live) {
+        if (a.h_out) {
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const int e = lane + 64 * u, row = e / R4, k4 = e % R4;
+                if (tile16 + row < T) {
+                    f32x4 hv;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) hv[cc] = Hs[row * KP + 4 * k4 + cc];
+                    *(f32x4*)(a.h_out + (size_t)(tile16 + row) * RP + 4 * k4) = hv;
+                }
+            }
+        }
+        if (a.kmj_out) {
+#pragma unroll
+            for (int u = 0; u < (RP * 4) / 64; ++u) {
+                const int e = lane + 64 * u, k = e >> 2, row = (e & 3) << 2;
+                unsigned short hi[4], lo[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    split_hi_lo(Hp[(row + cc) * KP + k] * mod_scale(fb.s_mod, (int)fb.tok_mod[tile16 + row + cc]), hi[cc], lo[cc]);
+                *(uint2*)(a.kmj_out + kmj_off<RP>(0, k, tile16 + row, fb.Tp)) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+                *(uint2*)(a.kmj_out + kmj_off<RP>(1, k, tile16 + row, fb.Tp)) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+            }
+            // pack tail behind the last tile up to Tp: zero (the weight-gradient kernels read whole groups of 32 tokens)
+            if (tile == ntiles - 1) {
+                for (int e = lane; e < (fb.Tp - ntiles * 16) * RP; e += 64) {
+                    const int tt = ntiles * 16 + e / RP, k = e % RP;
+                    a.kmj_out[kmj_off<RP>(0, k, tt, fb.Tp)] = 0;
+                    a.kmj_out[kmj_off<RP>(1, k, tt, fb.Tp)] = 0;
+                }
+            }
+        }
+    }
+
+    // ---- 3. my B operand: the (hi, lo) split of s_out[mod] * hp[token i], elements as moka_cross_fwd packs them
+    bf16x8 bh[KH], bl[KH];
+    {
+        const float sc = mod_scale(fb.s_mod, my_mod);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            const int k0 = (RP == 16) ? 8 * (g & 1) : 32 * kh + 8 * g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned short hi, lo;
+                split_hi_lo(Hp[i * KP + k0 + e] * sc, hi, lo);
+                if (RP == 16) { bh[kh][e] = (short)((g < 2) ? hi : lo); }    // K = 32 is [hi(16) | lo(16)]: one MFMA
+                else { bh[kh][e] = (short)hi; bl[kh][e] = (short)lo; }
+            }
+            if (RP == 16) bl[kh] = bh[kh];
+        }
+    }
+
+    const int wr = fb.r;                                                     // row length of Bw
+    bf16x8 wp[PER];
+    auto wload = [&](int ch) {
+        const int cb = ch * CWK;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 512 * u;                                     // (q, p, kh, lane)
+            const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
+            const int cc = cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3);
+            const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
+            bf16x8 v = z8;
+            if (cc < a.C) {
+                const unsigned short* src = (const unsigned short*)a.Bw + (size_t)cc * wr;
+                if (wr == RP) v = *(const bf16x8*)(src + k0);
+                else {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) v[x] = (k0 + x < wr) ? (short)src[k0 + x] : (short)0;
+                }
+            }
+            wp[u] = v;
+        }
+    };
+    auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+        const int cb = ch * CWK;
+        issue_o(onext, ch + 1);
+        __syncthreads();                                                     // the previous chunk's fragments (first step: the prologue's rows) are no longer read
 #pragma unroll
         for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
         __syncthreads();
@@ -3255,9 +3589,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0;
 #else
-static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0;
+static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -3398,6 +3732,27 @@ static int launch_yt(const ExpandBatch& ab, int nz, hipStream_t st) {
     ensure_lds((const void*)moka_yt_kernel<RP>, lds);
     hipLaunchKernelGGL((moka_yt_kernel<RP>), dim3((nch + cpb - 1) / cpb, ntb, nz), dim3(512), lds, st, ab, cpb);
     return check_launch("moka_yt_kernel");
+}
+
+// the fused interaction + up-projection launch (moka_up_fwd_fused)
+template <int RP>
+static int launch_yx(const YxBatch& fb, int nz, hipStream_t st) {
+    int Cmax = 0;
+    for (int z = 0; z < nz; ++z) Cmax = fb.z[z].C > Cmax ? fb.z[z].C : Cmax;
+    const int T = fb.T, nch = (Cmax + 127) / 128, ntb = (T + 127) / 128;
+    // column ranges per token block: every range repeats the prologue (ks x 64 B per token from L2 + the sample's key rows), so few --
+    // four (7B widths, 8192 tokens, cpb = 2 / 4 / 8 / 16 at 4096 columns: o 43.0 / 39.2 / 35.8 / 57.4 us, q+k+v 101.9 / 92.7 / 85.0 / 105.5;
+    // gate+up 22 / 16 / 8 chunks per range: 149.6 / 169.2 / 161.1), more only where fewer tokens would leave CUs without a workgroup
+    // ("yx_bpc": workgroups per CU instead; "yx_cpb": chunks per range)
+    int want = g_tune_yx_bpc > 0 ? (g_tune_yx_bpc * num_cu() + ntb * nz - 1) / (ntb * nz) : 4;
+    if (g_tune_yx_bpc <= 0 && (long)want * ntb * nz < (long)num_cu()) want = (num_cu() + ntb * nz - 1) / (ntb * nz);
+    want = want < 1 ? 1 : (want > nch ? nch : want);
+    const int cpb = g_tune_yx_cpb > 0 ? g_tune_yx_cpb : (nch + want - 1) / want;
+    constexpr size_t lds_w = (size_t)4 * 2 * ((RP + 31) / 32) * 1024, lds_p = (size_t)(8 * 2 * 16 + 64) * (RP + 1) * 4;
+    constexpr size_t lds = lds_w > lds_p ? lds_w : lds_p;
+    ensure_lds((const void*)moka_yx_kernel<RP>, lds);
+    hipLaunchKernelGGL((moka_yx_kernel<RP>), dim3((nch + cpb - 1) / cpb, ntb, nz), dim3(512), lds, st, fb, cpb);
+    return check_launch("moka_yx_kernel");
 }
 
 // W_CK: nz batched problems (G = 1 inside the kernel).  !W_CK: nz = number of projections sharing dx.
@@ -3884,6 +4239,9 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "expand_bpc")) g_tune_expand_bpc = value;
     else if (!strcmp(key, "wgrad_ct")) g_tune_wgrad_ct = value;
     else if (!strcmp(key, "wgrad_bpc")) g_tune_wgrad_bpc = value;
+    else if (!strcmp(key, "yx_bpc")) g_tune_yx_bpc = value;
+    else if (!strcmp(key, "yx_cpb")) g_tune_yx_cpb = value;
+    else if (!strcmp(key, "yx_dbg")) g_tune_yx_dbg = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 #else
@@ -4016,14 +4374,15 @@ int moka_cross_fwd_group(const float* const* part, int ks, const moka_routing* r
                          float* const* h, float* const* hp, void* const* hp_tok, void* const* hp_kmj,
                          void* const* BwT, void* const* AT, int G, int r, float w, float inv_sqrt_dk, moka_stream_t stream) {
     GROUP_CHECK("moka_cross_fwd");
-    if (!part || !rt || !s_out || !h || !hp_tok || !hp_kmj) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer");
+    if (!part || !rt || !s_out || !h || !hp_kmj) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer");
     CrossBatch ab;
     memset(&ab, 0, sizeof(ab));
     for (int g = 0; g < G; ++g) {
         CrossArgs& a = ab.z[g];
-        if (!part[g] || !h[g] || !hp_tok[g] || !hp_kmj[g]) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer (projection %d)", g);
+        if (!part[g] || !h[g] || !hp_kmj[g]) return fail(MOKA_EINVAL, "moka_cross_fwd: null pointer (projection %d)", g);
         a.part = part[g]; a.ks = ks; a.out_f32 = h[g]; a.out_f32b = hp ? hp[g] : nullptr;
-        a.pack_tok = (unsigned short*)hp_tok[g]; a.pack_kmj = (unsigned short*)hp_kmj[g];
+        a.pack_tok = hp_tok ? (unsigned short*)hp_tok[g] : nullptr;     // (optional: moka_up_fwd_fused does not read it)
+        a.pack_kmj = (unsigned short*)hp_kmj[g];
         if (BwT && BwT[g]) {
             if (!Bw || !Bw[g] || !d_out || d_out[g] < 32) return fail(MOKA_EINVAL, "moka_cross_fwd: BwT requested without Bw / d_out");
             a.Bw = (const unsigned short*)Bw[g]; a.BwT = (unsigned short*)BwT[g]; a.C = d_out[g];
@@ -4128,6 +4487,90 @@ int moka_up_fwd_group(const void* const* hp_tok, const void* const* Bw, const ui
 int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void* y_inout,
                 int T, int r, int d_out, int dtype, moka_stream_t stream) {
     return moka_up_fwd_group(&hp_tok, &Bw, tok_mod, &y_inout, T, r, &d_out, 1, dtype, stream);
+}
+
+int moka_up_fwd_fused_ok(int r, int dtype) {
+    const int RP = rank_pad(r);
+    return (RP == 16 || RP == 32) && dtype == MOKA_BF16 ? 1 : 0;
+}
+
+int moka_up_fwd_fused_group(const float* const* part, int ks, const moka_routing* rt, const float* s_out,
+                            const void* const* Bw, void* const* y_inout, const int* d_out,
+                            float* const* h, void* const* hp_kmj,
+                            int G, int r, float w, float inv_sqrt_dk, int dtype, moka_stream_t stream) {
+    GROUP_CHECK("moka_up_fwd_fused");
+    if (!part || !rt || !s_out || !Bw || !y_inout || !d_out) return fail(MOKA_EINVAL, "moka_up_fwd_fused: null pointer");
+    if (!moka_up_fwd_fused_ok(r, dtype))
+        return fail(MOKA_EINVAL, "moka_up_fwd_fused: built for bf16 storage and r <= 32 (r=%d, dtype=%d): use moka_cross_fwd + moka_up_fwd", r, dtype);
+    if (rt->B < 1 || rt->S < 1 || rt->M < 1 || rt->M > MOKA_MAX_MOD) return fail(MOKA_EINVAL, "moka_up_fwd_fused: B=%d S=%d M=%d", rt->B, rt->S, rt->M);
+    if (!rt->tok_mod || !rt->klen || !rt->ktok) return fail(MOKA_EINVAL, "moka_up_fwd_fused: null routing pointer");
+    if (rt->Lk_max < 0) return fail(MOKA_EINVAL, "moka_up_fwd_fused: Lk_max=%d", rt->Lk_max);
+    if (ks < 1) return fail(MOKA_EINVAL, "moka_up_fwd_fused: ks=%d", ks);
+    YxBatch fb;
+    memset(&fb, 0, sizeof(fb));
+    const int T = rt->B * rt->S;
+    for (int g = 0; g < G; ++g) {
+        int rc = check_common("moka_up_fwd_fused", T, d_out[g], r, rt->M, dtype);
+        if (rc) return rc;
+        if (!part[g] || !Bw[g] || !y_inout[g]) return fail(MOKA_EINVAL, "moka_up_fwd_fused: null pointer (projection %d)", g);
+        if ((uintptr_t)part[g] & 15) return fail(MOKA_EINVAL, "moka_up_fwd_fused: part must be 16-byte aligned");
+        fb.z[g].part = part[g]; fb.z[g].Bw = (const unsigned char*)Bw[g]; fb.z[g].out = (unsigned char*)y_inout[g]; fb.z[g].C = d_out[g];
+        fb.z[g].h_out = h ? h[g] : nullptr;
+        fb.z[g].kmj_out = hp_kmj ? (unsigned short*)hp_kmj[g] : nullptr;
+        if (((uintptr_t)fb.z[g].h_out | (uintptr_t)fb.z[g].kmj_out) & 15) return fail(MOKA_EINVAL, "moka_up_fwd_fused: h / hp_kmj must be 16-byte aligned");
+    }
+    fb.Tp = (T + 31) / 32 * 32;
+    fb.tok_mod = rt->tok_mod; fb.ktok = rt->ktok; fb.klen = rt->klen;
+    for (int m = 0; m < rt->M; ++m) fb.s_mod[m] = s_out[m];
+    fb.ks = ks; fb.B = rt->B; fb.S = rt->S; fb.T = T; fb.Lkp = rt->Lk_max > 0 ? rt->Lk_max : 1; fb.r = r;
+    fb.w = w; fb.c = inv_sqrt_dk;
+    fb.dbg = g_tune_yx_dbg;
+    return rank_pad(r) == 16 ? launch_yx<16>(fb, G, (hipStream_t)stream) : launch_yx<32>(fb, G, (hipStream_t)stream);
+}
+
+int moka_up_fwd_fused(const float* part, int ks, const moka_routing* rt, const float* s_out, const void* Bw, void* y_inout,
+                      int d_out, float* h, void* hp_kmj, int r, float w, float inv_sqrt_dk, int dtype, moka_stream_t stream) {
+    return moka_up_fwd_fused_group(&part, ks, rt, s_out, &Bw, &y_inout, &d_out, h ? &h : nullptr, hp_kmj ? &hp_kmj : nullptr,
+                                   1, r, w, inv_sqrt_dk, dtype, stream);
+}
+
+int moka_weight_shadows_group(const void* const* Bw, const int* d_out, const void* const* A, int d_in,
+                              void* const* BwT, void* const* AT, int G, int r, int M, moka_stream_t stream) {
+    GROUP_CHECK("moka_weight_shadows");
+    const int RP = rank_pad(r);
+    if (RP < 0) return fail(MOKA_EINVAL, "moka_weight_shadows: rank %d not in 1..64", r);
+    if (M < 1 || M > MOKA_MAX_MOD) return fail(MOKA_EINVAL, "moka_weight_shadows: M=%d not in 1..%d", M, MOKA_MAX_MOD);
+    CrossBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    long items = 0;
+    for (int g = 0; g < G; ++g) {
+        CrossArgs& a = ab.z[g];
+        a.r = r; a.M = M;
+        if (BwT && BwT[g]) {
+            if (!Bw || !Bw[g] || !d_out || d_out[g] < 32 || (d_out[g] % 32)) return fail(MOKA_EINVAL, "moka_weight_shadows: BwT requested without Bw / d_out");
+            a.Bw = (const unsigned short*)Bw[g]; a.BwT = (unsigned short*)BwT[g]; a.C = d_out[g];
+            items = a.C > items ? a.C : items;
+        }
+        if (AT && AT[g]) {
+            if (!A || d_in < 32 || (d_in % 32)) return fail(MOKA_EINVAL, "moka_weight_shadows: AT requested without A / d_in");
+            a.AT = (unsigned short*)AT[g]; a.Cin = d_in;
+            for (int m = 0; m < M; ++m) {
+                if (!A[g * M + m]) return fail(MOKA_EINVAL, "moka_weight_shadows: A[%d] is null", g * M + m);
+                a.Aw[m] = (const unsigned short*)A[g * M + m];
+            }
+            items = (long)M * d_in > items ? (long)M * d_in : items;
+        }
+    }
+    if (items == 0) return MOKA_OK;
+    const dim3 grid((unsigned)((items + 255) / 256), 1, G);
+    if (RP == 16) hipLaunchKernelGGL(moka_shadows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, ab);
+    else if (RP == 32) hipLaunchKernelGGL(moka_shadows_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, ab);
+    else hipLaunchKernelGGL(moka_shadows_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, ab);
+    return check_launch("moka_weight_shadows");
+}
+
+int moka_weight_shadows(const void* Bw, int d_out, const void* const* A, int d_in, void* BwT, void* AT, int r, int M, moka_stream_t stream) {
+    return moka_weight_shadows_group(&Bw, &d_out, A, d_in, &BwT, &AT, 1, r, M, stream);
 }
 
 int moka_up_bwd_group(const void* const* gy, const void* const* hp_kmj, const void* const* BwT, const uint8_t* tok_mod,

@@ -77,7 +77,9 @@ class FwdState:
 
 
 def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
-              Bw: Optional[torch.Tensor] = None, want_hp: bool = False, A: Optional[Sequence[torch.Tensor]] = None) -> FwdState:
+              Bw: Optional[torch.Tensor] = None, want_hp: bool = False, A: Optional[Sequence[torch.Tensor]] = None,
+              want_tok: bool = True) -> FwdState:
+    """want_tok=False: the token-major pack is not written (the up-projection is `up_fwd_fused_`, which computes it itself)."""
     lib = _lib.load()
     ks, T, RP = part.shape
     dev = part.device
@@ -85,7 +87,7 @@ def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float
     st = FwdState()
     st.h = torch.empty((T, RP), dtype=torch.float32, device=dev)
     st.hp = torch.empty((T, RP), dtype=torch.float32, device=dev) if want_hp else None
-    st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
+    st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev) if want_tok else None
     st.hp_kmj = torch.empty((2, RP, Tp), dtype=torch.bfloat16, device=dev)
     st.BwT = torch.empty((RP, Bw.shape[0]), dtype=torch.bfloat16, device=dev) if Bw is not None else None
     st.AT = torch.empty((len(A), A[0].shape[1], RP), dtype=torch.bfloat16, device=dev) if A is not None else None
@@ -93,10 +95,46 @@ def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float
                                   None if Bw is None else Bw.data_ptr(), 0 if Bw is None else Bw.shape[0],
                                   None if A is None else _ptrs(A), 0 if A is None else A[0].shape[1],
                                   st.h.data_ptr(), None if st.hp is None else st.hp.data_ptr(),
-                                  st.hp_tok.data_ptr(), st.hp_kmj.data_ptr(), None if st.BwT is None else st.BwT.data_ptr(),
+                                  None if st.hp_tok is None else st.hp_tok.data_ptr(), st.hp_kmj.data_ptr(),
+                                  None if st.BwT is None else st.BwT.data_ptr(),
                                   None if st.AT is None else st.AT.data_ptr(),
                                   r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_fwd")
     return st
+
+
+def up_fwd_fused_(y2: torch.Tensor, part: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float],
+                  w: float, inv_sqrt_dk: float, want_state: bool = False) -> Optional[FwdState]:
+    """In place: y2 [T,d_out] bf16 += (s_out[mod] hp) Bw^T with hp computed from the split-K slices `part` inside the kernel
+    (the bits of cross_fwd + up_fwd_; bf16 storage, r <= 32).  want_state: the launch also writes what the backward reads from
+    the rank space (h, hp_kmj); returned as a FwdState whose BwT / AT are filled by `weight_shadows`."""
+    lib = _lib.load()
+    ks, T, RP = part.shape
+    st = None
+    if want_state:
+        st = FwdState()
+        st.h = torch.empty((T, RP), dtype=torch.float32, device=part.device)
+        st.hp_kmj = torch.empty((2, RP, _lib.tok_pad(T)), dtype=torch.bfloat16, device=part.device)
+        st.hp = st.hp_tok = st.BwT = st.AT = None
+    _lib.check(lib.moka_up_fwd_fused(part.data_ptr(), ks, byref(rt.struct), _floats(s_out), Bw.data_ptr(), y2.data_ptr(),
+                                     y2.shape[1], None if st is None else st.h.data_ptr(), None if st is None else st.hp_kmj.data_ptr(),
+                                     r, float(w), float(inv_sqrt_dk), _lib.MOKA_BF16, _stream_ptr(y2.device)),
+               "moka_up_fwd_fused")
+    return st
+
+
+def weight_shadows(Bw: Optional[torch.Tensor], A: Optional[Sequence[torch.Tensor]], r: int) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """(BwT [RP, d_out], AT [M, d_in, RP]) bf16: the transposed, zero-padded weight copies the backward kernels read -- functions of
+    the weights alone (moka_weight_shadows), so they need not sit on the forward's dependency chain."""
+    lib = _lib.load()
+    RP = _lib.rank_pad(r)
+    ref = Bw if Bw is not None else A[0]
+    BwT = torch.empty((RP, Bw.shape[0]), dtype=torch.bfloat16, device=ref.device) if Bw is not None else None
+    AT = torch.empty((len(A), A[0].shape[1], RP), dtype=torch.bfloat16, device=ref.device) if A is not None else None
+    _lib.check(lib.moka_weight_shadows(None if Bw is None else Bw.data_ptr(), 0 if Bw is None else Bw.shape[0],
+                                       None if A is None else _ptrs(A), 0 if A is None else A[0].shape[1],
+                                       None if BwT is None else BwT.data_ptr(), None if AT is None else AT.data_ptr(),
+                                       r, len(A) if A is not None else 1, _stream_ptr(ref.device)), "moka_weight_shadows")
+    return BwT, AT
 
 
 def up_fwd_(y2: torch.Tensor, hp_tok: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, dtype: int = 0):
@@ -191,7 +229,7 @@ def down_fwd_group(x2: torch.Tensor, A: Sequence[Sequence[torch.Tensor]], rt: Mo
 
 
 def cross_fwd_group(parts: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
-                    Bw: Sequence[torch.Tensor], A: Optional[Sequence[Sequence[torch.Tensor]]] = None) -> List[FwdState]:
+                    Bw: Sequence[torch.Tensor], A: Optional[Sequence[Sequence[torch.Tensor]]] = None, want_tok: bool = True) -> List[FwdState]:
     lib = _lib.load()
     G = len(parts)
     ks, T, RP = parts[0].shape
@@ -202,7 +240,7 @@ def cross_fwd_group(parts: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_ou
         st = FwdState()
         st.h = torch.empty((T, RP), dtype=torch.float32, device=dev)
         st.hp = None
-        st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev)
+        st.hp_tok = torch.empty((Tp, 2 * RP), dtype=torch.bfloat16, device=dev) if want_tok else None
         st.hp_kmj = torch.empty((2, RP, Tp), dtype=torch.bfloat16, device=dev)
         st.BwT = torch.empty((RP, Bw[g].shape[0]), dtype=torch.bfloat16, device=dev)
         st.AT = torch.empty((len(A[g]), A[g][0].shape[1], RP), dtype=torch.bfloat16, device=dev) if A is not None else None
@@ -210,7 +248,7 @@ def cross_fwd_group(parts: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_ou
     flatA = None if A is None else _ptrs([a for Ag in A for a in Ag])
     _lib.check(lib.moka_cross_fwd_group(_ptrs(parts), ks, byref(rt.struct), _floats(s_out),
                                         _ptrs(Bw), _ints([b.shape[0] for b in Bw]), flatA, 0 if A is None else A[0][0].shape[1],
-                                        _ptrs([st.h for st in sts]), None, _ptrs([st.hp_tok for st in sts]),
+                                        _ptrs([st.h for st in sts]), None, _ptrs([st.hp_tok for st in sts]) if want_tok else None,
                                         _ptrs([st.hp_kmj for st in sts]), _ptrs([st.BwT for st in sts]),
                                         None if A is None else _ptrs([st.AT for st in sts]),
                                         G, r, float(w), float(inv_sqrt_dk), _stream_ptr(dev)), "moka_cross_fwd_group")
@@ -223,6 +261,44 @@ def up_fwd_group_(ys: Sequence[torch.Tensor], hp_toks: Sequence[torch.Tensor], B
     _lib.check(lib.moka_up_fwd_group(_ptrs(hp_toks), _ptrs(Bw), rt.tok_mod.data_ptr(), _ptrs(ys), T, r,
                                      _ints([y.shape[1] for y in ys]), len(ys), _lib.MOKA_BF16, _stream_ptr(ys[0].device)),
                "moka_up_fwd_group")
+
+
+def up_fwd_fused_group_(ys: Sequence[torch.Tensor], parts: Sequence[torch.Tensor], Bw: Sequence[torch.Tensor], rt: MokaRouting, r: int,
+                        s_out: Sequence[float], w: float, inv_sqrt_dk: float, want_state: bool = False) -> Optional[List[FwdState]]:
+    lib = _lib.load()
+    ks, T, RP = parts[0].shape
+    sts = None
+    if want_state:
+        sts = []
+        for _ in ys:
+            st = FwdState()
+            st.h = torch.empty((T, RP), dtype=torch.float32, device=parts[0].device)
+            st.hp_kmj = torch.empty((2, RP, _lib.tok_pad(T)), dtype=torch.bfloat16, device=parts[0].device)
+            st.hp = st.hp_tok = st.BwT = st.AT = None
+            sts.append(st)
+    _lib.check(lib.moka_up_fwd_fused_group(_ptrs(parts), ks, byref(rt.struct), _floats(s_out), _ptrs(Bw), _ptrs(ys),
+                                           _ints([y.shape[1] for y in ys]),
+                                           None if sts is None else _ptrs([st.h for st in sts]),
+                                           None if sts is None else _ptrs([st.hp_kmj for st in sts]),
+                                           len(ys), r, float(w), float(inv_sqrt_dk),
+                                           _lib.MOKA_BF16, _stream_ptr(ys[0].device)), "moka_up_fwd_fused_group")
+    return sts
+
+
+def weight_shadows_group(Bws: Sequence[torch.Tensor], As: Optional[Sequence[Sequence[torch.Tensor]]], r: int):
+    """Per projection (BwT, AT) of a group in one launch (AT only when `As` is given)."""
+    lib = _lib.load()
+    RP = _lib.rank_pad(r)
+    dev = Bws[0].device
+    G = len(Bws)
+    BwTs = [torch.empty((RP, b.shape[0]), dtype=torch.bfloat16, device=dev) for b in Bws]
+    ATs = [torch.empty((len(Ag), Ag[0].shape[1], RP), dtype=torch.bfloat16, device=dev) for Ag in As] if As is not None else None
+    M = len(As[0]) if As is not None else 1
+    _lib.check(lib.moka_weight_shadows_group(_ptrs(Bws), _ints([b.shape[0] for b in Bws]),
+                                             None if As is None else _ptrs([a for Ag in As for a in Ag]), 0 if As is None else As[0][0].shape[1],
+                                             _ptrs(BwTs), None if ATs is None else _ptrs(ATs), G, r, M, _stream_ptr(dev)),
+               "moka_weight_shadows_group")
+    return BwTs, ATs
 
 
 def up_bwd_group(gys: Sequence[torch.Tensor], hp_kmjs: Sequence[torch.Tensor], BwTs: Sequence[torch.Tensor], rt: MokaRouting, r: int,
@@ -381,6 +457,12 @@ def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[t
     return out
 
 
+# The forward of the autograd nodes: True (default) = moka_down_fwd -> moka_up_fwd_fused (+ moka_weight_shadows) where the fused launch
+# exists (bf16, r <= 32); False = the three-launch path moka_down_fwd -> moka_cross_fwd -> moka_up_fwd.  Same bits either way
+# (tests/test_gpu_fused.py); a module-level switch for A/B runs, not a tuning knob.
+FUSE_FORWARD = True
+
+
 # --------------------------------------------------------------------------------------
 # autograd node of one adapted projection
 # --------------------------------------------------------------------------------------
@@ -439,6 +521,12 @@ class MokaLinearFn(torch.autograd.Function):
             hps = st.hp * _token_scale(rt, spec.s_out, x2.device)[:, None]
             up_fwd_(y, hps, Bw_c, rt, spec.r, dtype=dt)
             ctx.save_for_backward(x2, W, Bw_c, st.h, hps, Bw_c, None, *A)
+        elif FUSE_FORWARD and _lib.up_fwd_fused_ok(spec.r, dt):
+            # two launches on the dependency chain: the up-projection computes the interaction itself from the slices and writes what
+            # the backward reads from the rank space (h, hp_kmj); the weight shadows are functions of the weights alone
+            st = up_fwd_fused_(y, part, Bw_c, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, want_state=True)
+            st.BwT, st.AT = weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
+            ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
         else:
             st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
             up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
@@ -554,8 +642,14 @@ class MokaLinearGroupFn(torch.autograd.Function):
         seeds = [s_.seed for s_ in specs]
         parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
         need_x = ctx.needs_input_grad[0]
-        sts = cross_fwd_group(parts, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, Bws, As if need_x else None)
-        up_fwd_group_(ys, [st.hp_tok for st in sts], Bws, rt, sp.r)
+        if FUSE_FORWARD and _lib.up_fwd_fused_ok(sp.r, _lib.MOKA_BF16):
+            sts = up_fwd_fused_group_(ys, parts, Bws, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, want_state=True)     # (see MokaLinearFn.forward)
+            BwTs, ATs = weight_shadows_group(Bws, As if need_x else None, sp.r)
+            for g in range(G):
+                sts[g].BwT, sts[g].AT = BwTs[g], (ATs[g] if ATs is not None else None)
+        else:
+            sts = cross_fwd_group(parts, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, Bws, As if need_x else None)
+            up_fwd_group_(ys, [st.hp_tok for st in sts], Bws, rt, sp.r)
         saved = [x2]
         for g in range(G):
             saved += [Ws[g], Bws[g], sts[g].h, sts[g].hp_kmj, sts[g].BwT, sts[g].AT if need_x else None, *As[g]]
