@@ -620,10 +620,16 @@ def main():
                          "off = dA_m and dx from one moka_down_bwd call inside the chain")
     ap.add_argument("--opt-in-backward", choices=("on", "off"), default="on",
                     help="the fused AdamW step per gradient bucket inside the backward (behind the bucket's deferred dA / its all-reduce) instead of one launch behind it")
-    ap.add_argument("--chain-priority", choices=("high", "normal"), default="high",
-                    help="stream priority of the captured dependency chain (the deferred dA / dB stream stays at normal priority)")
+    ap.add_argument("--chain-priority", choices=("auto", "high", "normal"), default="auto",
+                    help="stream priority of the captured dependency chain (the deferred dA / dB stream stays at normal priority).  auto = high in the "
+                         "one-graph mode (33.5 -> 33.35 ms), normal in --graph bwd: there every bucket graph ends with the chain joining the side "
+                         "stream, and a high-priority chain starves the launches it then has to wait for (one GPU: 49.0 against 34.6 ms per step)")
     ap.add_argument("--defer-db", choices=("auto", "on", "off"), default="auto",
                     help="with --defer-da: dB also leaves the dependency chain (auto: where moka_up_bwd_passes() says dB is a pass of its own, r > 32)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="single GPU: initialise a ONE-rank RCCL process group and run the gradient collectives through it (FlatGradBucket(force_comm=True)): "
+                         "the N > 1 configuration -- --graph bwd, bucket hooks between the graphs, the AdamW slices on the communication stream behind each "
+                         "all-reduce -- priced on one GPU (`comm_exposed_ms`), the figure the first multi-GPU run is read against")
     ap.add_argument("--fuse-fwd", choices=("on", "off"), default="on",
                     help="on (default, r <= 32): the up-projection computes the cross-modal interaction itself (moka_up_fwd_fused) and the rank-space "
                          "launch, which then only writes the backward's operands, runs on a side stream off the dependency chain; off: three launches per unit")
@@ -637,7 +643,9 @@ def main():
     if args.layers is None:
         args.layers = MODELS[args.model]["layers"]
     if args.graph == "auto":
-        args.graph = "all" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "bwd"
+        args.graph = "all" if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.force_comm) else "bwd"
+    if args.chain_priority == "auto":
+        args.chain_priority = "high" if args.graph == "all" else "normal"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) under torch.distributed.run, exactly
@@ -663,6 +671,18 @@ def main():
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
+    comm = world > 1 or args.force_comm              # do the gradient collectives run?
+    if args.force_comm and world == 1:
+        # the N > 1 configuration on ONE GPU: a one-rank RCCL communicator is a real ProcessGroupNCCL (its own stream, in-place
+        # asynchronous all-reduce, wait() = stream wait), so --graph bwd, the bucket hooks and the optimizer slices behind the
+        # all-reduce run exactly as the driver's multi-GPU launch runs them; what that configuration costs on one GPU is the
+        # figure a scaling curve is read against
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(os.environ.get("MOKA_BENCH_BACKEND", "nccl"), init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                **({"device_id": dev} if os.environ.get("MOKA_BENCH_BACKEND", "nccl") == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl" on ROCm).  MOKA_BENCH_BACKEND=gloo is a functional check of the N > 1 script path on a box with fewer
@@ -681,9 +701,10 @@ def main():
         args.defer_da = "off"                                    # (the part-batch chains already overlap each other)
     # dB leaves the dependency chain with dA_m where the library computes it in a pass of its own anyway (r > 32)
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
-    if args.chains > 1 and (world > 1 or args.graph != "all"):
+    if args.chains > 1 and (comm or args.graph != "all"):
         raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")
-    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None),
+    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None,
+                                                                       force_comm=args.force_comm),
                         chains=args.chains)
     T = wl["T"]
     torch.cuda.synchronize()
@@ -700,16 +721,15 @@ def main():
     # the optimizer step per gradient bucket INSIDE the backward (off: one launch behind it): needs the side stream of the deferred dA_m
     # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and args.chains == 1 and
-                  ((world == 1 and args.defer_da == "side" and args.graph in ("auto", "all", "off")) or (world > 1 and not args.comm_bf16)))
+                  ((not comm and args.defer_da == "side" and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
     shadows_main = bool(args.fused and args.shadows == "main")
     shadows_opt = bool(args.fused and args.shadows == "opt")
     shadows_in_cb = False
     if opt_in_bwd:
-        opt.begin_step()
-        opt.t -= 1                                   # (allocates the coefficient buffers; no step counted)
-        if world > 1:
+        opt.set_device_step(0)                       # (allocates the device-side coefficient state; no step counted)
+        if comm:
             ends = wl["layer_end"]
 
             def _reduced(blo, bhi):
@@ -743,7 +763,7 @@ def main():
                     run_backward(lib, ch, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
             torch.cuda.synchronize()
             if args.graph == "all":
-                assert world == 1, "--graph all: single GPU only"
+                assert not comm, "--graph all: single GPU without collectives only"
                 fwd_bwd_graph = torch.cuda.CUDAGraph()
                 branch = [torch.cuda.Stream(device=dev) for _ in range(args.chains - 1)]
                 da_side = torch.cuda.Stream(device=dev)
@@ -755,7 +775,10 @@ def main():
                         with torch.cuda.stream(st):
                             spg = c_void_p(st.cuda_stream)
                             if opt_in_bwd and ch is wl["chains"][0]:
-                                opt.upload_coef()            # (a copy from pinned memory: every replay reads this step's coefficients)
+                                # the step's AdamW coefficients, written on the device by a one-thread launch that counts the steps itself:
+                                # every replay advances by one, nothing is read from host memory (FlatAdamW.begin_step)
+                                opt.begin_step(device_counter=True)
+                                opt.t -= 1                   # (the capture is not a step)
                             run_forward(lib, ch, spg, shadows=shadows_main)
                             run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side, args.split_db) if args.defer_da != "off" else None,
                                          bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None,
@@ -783,7 +806,7 @@ def main():
             torch.cuda.synchronize()
 
     # N > 1: how long the main stream stands still in bucket.finish() (the part of the all-reduce the backward did not hide)
-    comm_ev = [] if world > 1 else None
+    comm_ev = [] if comm else None
 
     live_side = torch.cuda.Stream(device=dev) if args.defer_da != "off" else None
 
@@ -792,9 +815,10 @@ def main():
         if opt is None:
             bucket.zero_()                           # (the optimizer kernel leaves the gradient buffer zeroed)
         if opt_in_bwd:
-            opt.begin_step()                         # this step's coefficients -> pinned memory
             if fwd_bwd_graph is None:
-                opt.upload_coef()                    # (captured in the one-graph mode)
+                opt.begin_step()                     # this step's coefficients: a one-thread launch on the main stream (launch arguments)
+            else:
+                opt.t += 1                           # (the captured launch counts on the device; the host keeps the books)
         if fwd_bwd_graph is not None:
             fwd_bwd_graph.replay()
         else:
@@ -810,8 +834,8 @@ def main():
             else:
                 run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
                              defer=(args.defer_da, main_stream, live_side, args.split_db) if args.defer_da != "off" else None,
-                             bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and world == 1) else None,
-                             shadows_after_opt=shadows_opt and opt_in_bwd and world == 1)
+                             bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and not comm) else None,
+                             shadows_after_opt=shadows_opt and opt_in_bwd and not comm)
         if comm_ev is not None and i >= args.warmup:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
@@ -822,7 +846,7 @@ def main():
             bucket.finish(average=opt is None)       # join the all-reduces; the optimizer kernel averages (grad_scale)
         if opt is not None and not opt_in_bwd:
             opt.step(grad_scale=1.0 / world, zero_grad=True)
-        if shadows_opt and opt is not None and not (opt_in_bwd and world == 1) and not shadows_in_cb:
+        if shadows_opt and opt is not None and not (opt_in_bwd and not comm) and not shadows_in_cb:
             run_shadows(lib, wl, sp, range(L))       # (every weight has changed: the shadows of the whole stack, behind the step)
 
     for i in range(args.warmup):
@@ -926,8 +950,9 @@ def main():
                                       ("one launch set per projection" if args.no_group else "q/k/v and gate/up through the grouped entry points")
                                       + ("" if args.chains == 1 else ", as %d independent part-batch chains on %d streams" % (args.chains, args.chains))),
                        "tokens_per_gpu_per_step": T, "layers": args.layers, "rank": args.rank, "parallelism": f"dp{world}"},
-            "distributed": {"world_size": world, "dist_world_size": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
-                            "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
+            "distributed": {"world_size": world, "dist_world_size": dist.get_world_size() if (comm and dist.is_initialized()) else 1,
+                            "backend": (dist.get_backend() if (comm and dist.is_initialized()) else None),
+                            "force_comm": bool(args.force_comm),
                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
                             "adapter_params": wl["n_params"]},
@@ -953,9 +978,12 @@ def main():
             out["end_to_end"] = end_to_end(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        # (written straight to file descriptor 1: with a process group initialised, a buffered sys.stdout lost the line on some boxes)
+        sys.stdout.flush()
+        os.write(1, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if comm:
         dist.destroy_process_group()
 
 

@@ -289,6 +289,12 @@ int moka_adamw_flat(float* master, void* work_bf16, float* grad, float* exp_avg,
  * backward is still running) stays valid from step to step -- the caller computes them with moka_adamw_coef() on the host and copies them
  * to coef_dev before the kernel runs (e.g. a captured copy from pinned memory).  A slice of the flat buffers is a call with offset pointers. */
 void moka_adamw_coef(float lr, float beta1, float beta2, float weight_decay, int step, float* coef3);
+/* The same coefficients written on the DEVICE by a one-thread launch whose inputs are launch arguments (copied at enqueue time: a host
+ * that runs several steps ahead of the GPU cannot disturb a step that has not read them yet -- a pinned staging buffer can).
+ * state8: 8 floats, 16-byte aligned: [0..2] the triple moka_adamw_flat_dev reads, [3] the step count (int), [4..6] the triple with
+ * decay = 1 (pass state8 + 4 as coef_dev for parameters without weight decay: biases, norm weights).  step > 0 sets the count;
+ * step <= 0 makes the device count itself (state8[3] + 1): a launch captured in a hipGraph advances by one per replay. */
+int moka_adamw_begin_dev(float* state8, float lr, float beta1, float beta2, float weight_decay, int step, moka_stream_t stream);
 int moka_adamw_flat_dev(float* master, void* work_bf16, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                         float beta1, float beta2, float eps, const float* coef_dev, float grad_scale, int zero_grad, moka_stream_t stream);
 

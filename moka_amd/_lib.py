@@ -113,6 +113,7 @@ SYMBOLS = {
     "moka_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
                                 c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
     "moka_adamw_coef": (None, [c_float, c_float, c_float, c_float, c_int, ctypes.POINTER(c_float)]),
+    "moka_adamw_begin_dev": (c_int, [c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "moka_adamw_flat_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
                                     c_float, c_float, c_float, c_void_p, c_float, c_int, c_void_p]),
 }

@@ -4806,6 +4806,37 @@ int moka_adamw_flat(float* master, void* work_bf16, float* grad, float* exp_avg,
     return check_launch("moka_adamw_kernel");
 }
 
+// The step's coefficients written ON THE DEVICE from launch arguments (copied when the launch is enqueued: a host that runs steps
+// ahead of the GPU cannot overwrite what an earlier step still has to read, as it could with a pinned staging buffer).
+// state[0..2] = {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 - lr * weight_decay}, state[3] = t (int bits),
+// state[4..6] = the same triple without decay (biases / norm weights), state[7] unused.
+__global__ void moka_adamw_begin_kernel(float* state, float lr, float beta1, float beta2, float weight_decay, int step, float c0, float c1, float c2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int* ti = (int*)(state + 3);
+    if (step > 0) {                                          // the host counts: its own coefficients (the bits of moka_adamw_flat)
+        *ti = step;
+    } else {                                                 // the device counts (a launch captured in a hipGraph)
+        const int t = *ti + 1;
+        *ti = t;
+        c0 = (float)((double)lr / (1.0 - pow((double)beta1, (double)t)));
+        c1 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)t)));
+        c2 = __fsub_rn(1.f, __fmul_rn(lr, weight_decay));
+    }
+    state[0] = c0; state[1] = c1; state[2] = c2;
+    state[4] = c0; state[5] = c1; state[6] = 1.f;
+}
+
+void moka_adamw_coef(float lr, float beta1, float beta2, float weight_decay, int step, float* coef3);
+
+int moka_adamw_begin_dev(float* state8, float lr, float beta1, float beta2, float weight_decay, int step, moka_stream_t stream) {
+    if (!state8 || ((uintptr_t)state8 & 15)) return fail(MOKA_EINVAL, "moka_adamw_begin_dev: state must be 8 floats, 16-byte aligned");
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) return fail(MOKA_EINVAL, "moka_adamw_begin_dev: betas (%g, %g) not in [0, 1)", (double)beta1, (double)beta2);
+    float c[3] = {0.f, 0.f, 0.f};
+    if (step > 0) moka_adamw_coef(lr, beta1, beta2, weight_decay, step, c);
+    hipLaunchKernelGGL(moka_adamw_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state8, lr, beta1, beta2, weight_decay, step, c[0], c[1], c[2]);
+    return check_launch("moka_adamw_begin_kernel");
+}
+
 void moka_adamw_coef(float lr, float beta1, float beta2, float weight_decay, int step, float* coef3) {
     coef3[0] = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
     coef3[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));

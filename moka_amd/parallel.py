@@ -32,10 +32,13 @@ class FlatGradBucket:
     """Flat fp32 gradient buffer + per-layer slice boundaries + bucketed asynchronous all-reduce."""
 
     def __init__(self, numel: int, layer_end: Sequence[int], device, n_buckets: int = 8,
-                 process_group=None, dtype=torch.float32, comm_dtype: Optional[torch.dtype] = None):
+                 process_group=None, dtype=torch.float32, comm_dtype: Optional[torch.dtype] = None, force_comm: bool = False):
         """comm_dtype: payload type of the all-reduce (None = the buffer's own fp32).  torch.bfloat16 halves the bytes on
         xGMI (7B r=16: 153 instead of 306 MB per step -- the figure SURVEY.md 8(e) sized): a bucket is rounded to bf16 into a
-        staging buffer, summed there and widened back; accumulation across micro-batches stays fp32."""
+        staging buffer, summed there and widened back; accumulation across micro-batches stays fp32.
+        force_comm: run the collectives even in a process group of ONE rank (default: a single rank short-circuits them).  A
+        one-rank RCCL communicator is a real ``ProcessGroupNCCL`` -- its own stream, in-place asynchronous all-reduce, ``wait()`` =
+        stream wait -- so the whole communication path (side stream, bucket hooks, ``on_reduced``) can be exercised and priced on one GPU."""
         if not layer_end or layer_end[-1] != numel:
             raise ValueError("layer_end must be increasing offsets ending at numel")
         self.flat = torch.zeros(numel, dtype=dtype, device=device)
@@ -45,9 +48,12 @@ class FlatGradBucket:
         self.n_layers = len(self.layer_end)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if force_comm and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("FlatGradBucket(force_comm=True) needs an initialised process group (one rank is enough)")
+        self.comm = self.world > 1 or bool(force_comm)      # do the collectives run?
         self.layers_per_bucket = max(1, -(-self.n_layers // max(1, n_buckets)))
         self.is_cuda = self.flat.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and self.comm) else None
         self.on_reduced = None       # callable(lo, hi), run on the communication stream behind a bucket's all-reduce (fp32 payload only)
         self._pending: List = []
 
@@ -68,7 +74,7 @@ class FlatGradBucket:
     # ---------------------------------------------------------------- backward hooks
     def layer_done(self, l: int):
         """Call after layer l's backward launches are enqueued (layers arrive last -> first)."""
-        if self.world == 1 or (l % self.layers_per_bucket) != 0:
+        if not self.comm or (l % self.layers_per_bucket) != 0:
             return
         lo, hi = self.bucket_bounds(l)
         sl = self.flat[lo:hi]
@@ -97,7 +103,7 @@ class FlatGradBucket:
 
     def finish(self, average: bool = True):
         """Join the outstanding collectives; afterwards ``flat`` holds the (averaged) global gradient."""
-        if self.world == 1:
+        if not self.comm:
             return
         if self.is_cuda:
             done = torch.cuda.Event()
@@ -114,7 +120,7 @@ class FlatGradBucket:
                 if self._stage is not None:
                     self.flat[lo:hi].copy_(self._stage[lo:hi])
         self._pending.clear()
-        if average:
+        if average and self.world > 1:
             self.flat.div_(self.world)
 
 
@@ -139,50 +145,92 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros_like(master)
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.t = 0
+        # [lo, hi) ranges of the flat buffers that take NO weight decay (biases, norm weights: what HF Trainer's default optimizer
+        # excludes, AudioVisualText/trainer.py leaves create_optimizer alone); sorted, disjoint, multiples of 4
+        self.no_decay_ranges: List = []
+        # callable() -> dict(lr=, betas=, eps=, weight_decay=) evaluated when a step BEGINS (MokaFlatOptimizer installs one that reads
+        # param_groups[0]: with the optimizer inside the backward a step begins long before optimizer.step() is called)
+        self.hyper = None
+        self._state = None                           # 8 floats on the device: the step's coefficients (moka_adamw_begin_dev)
+
+    def _pull_hyper(self) -> None:
+        if self.hyper is not None:
+            h = self.hyper()
+            self.lr, self.eps, self.weight_decay = float(h["lr"]), float(h["eps"]), float(h["weight_decay"])
+            self.betas = (float(h["betas"][0]), float(h["betas"][1]))
+
+    def _segments(self, lo: int, hi: int):
+        """[lo, hi) cut at the boundaries of the no-decay ranges: (a, b, decays) pieces in order."""
+        pos = lo
+        for a, b in self.no_decay_ranges:
+            a, b = max(a, lo), min(b, hi)
+            if a >= b:
+                continue
+            if a > pos:
+                yield pos, a, True
+            yield a, b, False
+            pos = b
+        if pos < hi:
+            yield pos, hi, True
 
     def step(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         from . import _lib
         if not self.master.is_cuda:
             raise _lib.MokaError("moka_amd: FlatAdamW runs as a HIP kernel; the buffers live on %s" % self.master.device)
+        self._pull_hyper()
         self.t += 1
         lib = _lib.load()
         stream = torch.cuda.current_stream(self.master.device).cuda_stream
-        _lib.check(lib.moka_adamw_flat(self.master.data_ptr(), None if self.work is None else self.work.data_ptr(),
-                                       self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                       self.master.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                       self.t, float(grad_scale), 1 if zero_grad else 0, stream), "moka_adamw_flat")
+        for a, b, decays in self._segments(0, self.master.numel()):
+            _lib.check(lib.moka_adamw_flat(self.master.data_ptr() + 4 * a, None if self.work is None else self.work.data_ptr() + 2 * a,
+                                           self.grad.data_ptr() + 4 * a, self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a,
+                                           b - a, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay if decays else 0.0,
+                                           self.t, float(grad_scale), 1 if zero_grad else 0, stream), "moka_adamw_flat")
 
     # -- the same step in slices, with the step-dependent coefficients in device memory (``moka_adamw_flat_dev``): launches that can be
     #    captured in a hipGraph, or enqueued per gradient bucket while the backward of the earlier layers is still running
-    def begin_step(self) -> None:
-        """Count the step and put its coefficients {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 - lr * wd} into pinned host memory."""
+    def begin_step(self, device_counter: bool = False) -> None:
+        """Count the step and ENQUEUE, on the current stream, the one-thread launch that writes its coefficients {lr / (1 - beta1^t),
+        1 / sqrt(1 - beta2^t), 1 - lr * wd} into device memory (``moka_adamw_begin_dev``).  The inputs are launch arguments -- copied when
+        the launch is enqueued -- so a host that runs steps ahead of the GPU cannot disturb a step that has not read its coefficients
+        yet (a pinned staging buffer, the round-3 form, could).  device_counter: the launch counts the steps itself instead of taking
+        t from the host: captured in a hipGraph it advances by one per replay (the caller keeps ``self.t`` in step for bookkeeping)."""
         from . import _lib
-        import ctypes
         if not self.master.is_cuda:
             raise _lib.MokaError("moka_amd: FlatAdamW runs as a HIP kernel; the buffers live on %s" % self.master.device)
-        if getattr(self, "_coef_host", None) is None:
-            self._coef_host = torch.zeros(4, dtype=torch.float32).pin_memory()
-            self._coef_dev = torch.zeros(4, dtype=torch.float32, device=self.master.device)
+        if self._state is None:
+            self._state = torch.zeros(8, dtype=torch.float32, device=self.master.device)
+        self._pull_hyper()
         self.t += 1
-        c = (ctypes.c_float * 3)()
-        _lib.load().moka_adamw_coef(self.lr, self.betas[0], self.betas[1], self.weight_decay, self.t, c)
-        self._coef_host[0], self._coef_host[1], self._coef_host[2] = float(c[0]), float(c[1]), float(c[2])
+        stream = torch.cuda.current_stream(self.master.device).cuda_stream
+        _lib.check(_lib.load().moka_adamw_begin_dev(self._state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.weight_decay,
+                                                    0 if device_counter else self.t, stream), "moka_adamw_begin_dev")
+
+    def set_device_step(self, t: int) -> None:
+        """Make the device-side step counter agree with ``t`` (before capturing / replaying a ``begin_step(device_counter=True)`` launch)."""
+        if self._state is None:
+            self._state = torch.zeros(8, dtype=torch.float32, device=self.master.device)
+        self._state[3:4].view(torch.int32).fill_(int(t))
 
     def upload_coef(self) -> None:
-        """Enqueue the copy of the coefficients to the device on the current stream (capturable: a replay reads the pinned buffer anew)."""
-        self._coef_dev.copy_(self._coef_host, non_blocking=True)
+        """Kept for callers of the round-3 interface: ``begin_step`` now writes the coefficients on the device itself."""
+        return None
 
     def step_range(self, lo: int, hi: int, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
-        """The update of parameters [lo, hi) on the current stream, behind ``upload_coef()``; lo must be a multiple of 4."""
+        """The update of parameters [lo, hi) on the current stream, behind ``begin_step()`` in stream order (or behind an event that
+        is); lo must be a multiple of 4."""
         from . import _lib
         if lo % 4 or not (0 <= lo <= hi <= self.master.numel()):
             raise ValueError(f"FlatAdamW.step_range: bad range [{lo}, {hi})")
+        if self._state is None:
+            raise RuntimeError("FlatAdamW.step_range before begin_step()")
         lib = _lib.load()
         stream = torch.cuda.current_stream(self.master.device).cuda_stream
-        _lib.check(lib.moka_adamw_flat_dev(self.master.data_ptr() + 4 * lo, None if self.work is None else self.work.data_ptr() + 2 * lo,
-                                           self.grad.data_ptr() + 4 * lo, self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo,
-                                           hi - lo, self.betas[0], self.betas[1], self.eps, self._coef_dev.data_ptr(), float(grad_scale),
-                                           1 if zero_grad else 0, stream), "moka_adamw_flat_dev")
+        for a, b, decays in self._segments(lo, hi):
+            _lib.check(lib.moka_adamw_flat_dev(self.master.data_ptr() + 4 * a, None if self.work is None else self.work.data_ptr() + 2 * a,
+                                               self.grad.data_ptr() + 4 * a, self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a,
+                                               b - a, self.betas[0], self.betas[1], self.eps, self._state.data_ptr() + (0 if decays else 16),
+                                               float(grad_scale), 1 if zero_grad else 0, stream), "moka_adamw_flat_dev")
 
     def state_dict(self) -> dict:
         return {"step": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,
@@ -202,10 +250,14 @@ class FlatAdamW:
 _LAYER_RE = re.compile(r"^(.*?(?:^|\.)layers)\.(\d+)\.")
 
 
-def _in_backward() -> bool:
-    """True while an autograd backward pass is running on this thread (activation checkpointing re-runs layer forwards there)."""
+def _in_backward(dp=None) -> bool:
+    """True while an autograd backward pass is running on this thread (activation checkpointing re-runs layer forwards there).
+    ``torch._C._current_graph_task_id`` is a private hook: where it is missing, the handle's own flag decides (set by the first
+    backward callback of a pass, cleared by finish() / step())."""
     f = getattr(torch._C, "_current_graph_task_id", None)
-    return bool(f is not None and f() != -1)
+    if f is not None:
+        return f() != -1
+    return bool(dp is not None and dp._bwd_active)
 
 
 def _decoder_prefix(names: Sequence[str]) -> Optional[str]:
@@ -253,18 +305,19 @@ class AdapterDataParallel:
         self.opt_in_backward = False
         self._opt_begun = False
         self._opt_done: List = []                    # [lo, hi) ranges of the flat buffers already updated in this step
+        self._bwd_active = False                     # a backward pass has reported work since the last finish() / step()
 
     # ---------------------------------------------------------------- backward side
     def _opt_slice(self, lo: int, hi: int) -> None:
         """AdamW on parameters [lo, hi) on the CURRENT stream (coefficients of the step uploaded on that stream the first time)."""
         if not self._opt_begun:
-            self.optimizer.begin_step()
-            self.optimizer.upload_coef()
+            self.optimizer.begin_step()              # (hyper-parameters pulled now: MokaFlatOptimizer's param_groups, a scheduler's lr)
             self._opt_begun = True
         self.optimizer.step_range(lo, hi, grad_scale=1.0 / self.bucket.world, zero_grad=True)
         self._opt_done.append((lo, hi))
 
     def _defer(self, fn, tensors) -> None:
+        self._bwd_active = True
         self._deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)]))
 
     def _flush_deferred(self) -> None:
@@ -291,14 +344,15 @@ class AdapterDataParallel:
             self._side_busy = False
 
     def _layer_done(self, l: int) -> None:
+        self._bwd_active = True
         self._flush_deferred()                       # the layer's dA_m launches leave for the side stream now
         if not self.sync or l in self._done:
             return
         self._done.add(l)
-        if self.bucket.world > 1 and (l % self.bucket.layers_per_bucket) == 0:
+        if self.bucket.comm and (l % self.bucket.layers_per_bucket) == 0:
             self._join_deferred()                    # a bucket must not ship before its dA_m have landed
-        self.bucket.layer_done(l)                    # (N > 1 with opt_in_backward: bucket.on_reduced runs the bucket's AdamW slice behind its all-reduce)
-        if self.opt_in_backward and self.bucket.world == 1 and (l % self.bucket.layers_per_bucket) == 0:
+        self.bucket.layer_done(l)                    # (collectives on, opt_in_backward: bucket.on_reduced runs the bucket's AdamW slice behind its all-reduce)
+        if self.opt_in_backward and not self.bucket.comm and (l % self.bucket.layers_per_bucket) == 0:
             dev = self.bucket.flat.device
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -312,7 +366,7 @@ class AdapterDataParallel:
         way (or already summed) and no step() / finish() in between means gradient accumulation without ``no_sync``: the next
         backward's kernels would add into memory an in-place all-reduce is working on, and those layers would not be shipped
         again.  DDP is merely slower in that situation; here it would be silently wrong, so it is an error."""
-        if self.sync and (self._done or self.bucket._pending) and torch.is_grad_enabled() and not _in_backward():
+        if self.sync and (self._done or self.bucket._pending) and torch.is_grad_enabled() and not _in_backward(self):
             raise RuntimeError("moka_amd.parallel: a new forward started while gradient buckets of the previous backward are in flight. "
                                "Accumulate micro-batches under `with dp.no_sync():` (sync only on the last one), or call dp.step() / "
                                "dp.finish() after every backward.")
@@ -340,6 +394,7 @@ class AdapterDataParallel:
             if l not in self._done and (l % self.bucket.layers_per_bucket) == 0:
                 self.bucket.layer_done(l)
         self._done.clear()
+        self._bwd_active = False
         self.bucket.finish(average=average)
 
     def step(self, max_grad_norm: Optional[float] = None) -> Optional[torch.Tensor]:
@@ -350,8 +405,6 @@ class AdapterDataParallel:
         if self.optimizer is None:
             raise RuntimeError("attach(..., optimizer=False): call finish() and run your own optimizer on dp.master / dp.bucket.flat")
         if self.opt_in_backward:
-            if max_grad_norm is not None and max_grad_norm > 0:
-                raise RuntimeError("attach(optimizer_in_backward=True) updates a bucket before the global gradient norm exists: no clipping in this mode")
             self.finish(average=False)               # ships what the hooks did not; joins the side / communication streams (and their slices)
             done, pos = sorted(self._opt_done), 0
             for lo, hi in done + [(self.bucket.flat.numel(), self.bucket.flat.numel())]:
@@ -360,6 +413,11 @@ class AdapterDataParallel:
                 pos = max(pos, hi)
             self._opt_done.clear()
             self._opt_begun = False
+            if max_grad_norm is not None and max_grad_norm > 0:
+                # (raised AFTER the step has been completed consistently: the buckets of this step were updated inside the backward,
+                #  before a global norm existed; MokaFlatOptimizer refuses the combination up front)
+                raise RuntimeError("attach(optimizer_in_backward=True) updates a bucket before the global gradient norm exists: no clipping in "
+                                   "this mode (the step just taken was NOT clipped)")
             return None
         self.finish(average=False)
         scale = 1.0 / self.bucket.world
@@ -415,7 +473,7 @@ class AdapterDataParallel:
 def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: bool = True, lr: float = 1e-4,
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
            comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True,
-           optimizer_in_backward: bool = False) -> AdapterDataParallel:
+           optimizer_in_backward: bool = False, force_comm: bool = False, no_decay="hf") -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
     base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
@@ -444,6 +502,12 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
       bucket's deferred dA_m (one GPU) or on the communication stream behind its all-reduce (N > 1, fp32 payload) -- and overlaps the
       backward of the earlier layers; ``step()`` then only updates what no bucket covered.  No gradient clipping in this mode (the
       global norm does not exist yet when the first bucket is updated), and every synchronised backward must be followed by ``step()``.
+
+    * ``force_comm``: run the bucket all-reduces even in a process group of one rank (``FlatGradBucket``): the communication path
+      -- RCCL's own stream, the bucket hooks, the optimizer slices behind the all-reduce -- as N > 1 ranks run it, on one GPU;
+    * ``no_decay``: which parameters take no weight decay: ``"hf"`` (default) = what HF ``Trainer``'s default optimizer excludes and
+      the reference therefore trains without decay (``AudioVisualText/trainer.py`` does not override ``create_optimizer``): biases and
+      the weights of normalisation layers; a callable ``(name, param, module) -> bool``; ``None`` = decay everywhere.
 
     Replaces DeepSpeed ZeRO-2's bucketed reduce-scatter + partitioned optimizer of the reference configurations
     (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``)."""
@@ -496,7 +560,7 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
         sizes.append(named[k][1].numel())
         off += (named[k][1].numel() + 7) // 8 * 8                               # 16-byte aligned bf16 / 32-byte fp32 views
     ends.append(off)
-    bucket = FlatGradBucket(off, ends, dev, n_buckets=n_buckets, process_group=process_group, comm_dtype=comm_dtype)
+    bucket = FlatGradBucket(off, ends, dev, n_buckets=n_buckets, process_group=process_group, comm_dtype=comm_dtype, force_comm=force_comm)
     master = torch.zeros(off, dtype=torch.float32, device=dev)
     work = torch.zeros(off, dtype=torch.bfloat16, device=dev)
     by_name = dict(named)
@@ -510,14 +574,31 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
             p.data = (work if p.dtype == torch.bfloat16 else master)[o:o + sz].view(p.shape)
             grad_view[n] = bucket.flat[o:o + sz].view(p.shape)
     opt = FlatAdamW(master, bucket.flat, work, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if optimizer else None
+    if opt is not None and no_decay is not None:
+        owner = {}
+        for mod_name, mod in model.named_modules():
+            for pn, _p in mod.named_parameters(recurse=False):
+                owner[(mod_name + "." if mod_name else "") + pn] = mod
+        if no_decay == "hf":
+            def no_decay(n, p, mod):                 # transformers.Trainer.get_decay_parameter_names: no norm layers, no biases
+                return n.endswith("bias") or "norm" in type(mod).__name__.lower()
+        ranges = []
+        for n, o, sz in zip(names, offsets, sizes):
+            if no_decay(n, by_name[n], owner.get(n)):
+                hi_ = o + (sz + 7) // 8 * 8          # (the padding behind a parameter belongs to it: its values are never read)
+                if ranges and ranges[-1][1] == o:
+                    ranges[-1] = (ranges[-1][0], hi_)
+                else:
+                    ranges.append((o, hi_))
+        opt.no_decay_ranges = ranges
     dp = AdapterDataParallel(model, bucket, master, work, names, offsets, sizes, opt, [])
     if optimizer_in_backward:
         if opt is None or dev.type != "cuda":
             raise ValueError("attach(optimizer_in_backward=True) needs the built-in optimizer and a GPU")
-        if bucket.world > 1 and bucket.comm_dtype is not None:
+        if bucket.comm and bucket.comm_dtype is not None:
             raise ValueError("attach(optimizer_in_backward=True): the bucket update runs behind an fp32 all-reduce (no comm_dtype)")
         dp.opt_in_backward = True
-        if bucket.world > 1:
+        if bucket.comm:
             bucket.on_reduced = dp._opt_slice
     # sinks of the adapted projections (both mirrors)
     mods = {}
@@ -582,9 +663,16 @@ class MokaFlatOptimizer(torch.optim.Optimizer):
         o = dp.optimizer
         defaults = dict(lr=o.lr if lr is None else float(lr), betas=tuple(o.betas if betas is None else betas),
                         eps=o.eps if eps is None else float(eps), weight_decay=o.weight_decay if weight_decay is None else float(weight_decay))
+        if dp.opt_in_backward and max_grad_norm is not None and max_grad_norm > 0:
+            raise ValueError("MokaFlatOptimizer(max_grad_norm=...) on attach(optimizer_in_backward=True): a bucket is updated inside the "
+                             "backward, before the global gradient norm exists -- no clipping in this mode")
         super().__init__([{"params": dp.parameters()}], defaults)
         self.dp, self.max_grad_norm = dp, max_grad_norm
         self.last_grad_norm = None
+        # the fused step reads its hyper-parameters from param_groups[0] WHEN IT BEGINS: with the optimizer inside the backward that
+        # is the first finished bucket of the backward, long before step() is called -- a scheduler's lr for this step is in
+        # param_groups by then (schedulers step after optimizer.step()), the value attach() was given is not
+        o.hyper = lambda: self.param_groups[0]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -592,9 +680,7 @@ class MokaFlatOptimizer(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        g, o = self.param_groups[0], self.dp.optimizer
-        o.lr, o.betas, o.eps, o.weight_decay = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"]), float(g["weight_decay"])
-        self.last_grad_norm = self.dp.step(max_grad_norm=self.max_grad_norm)
+        self.last_grad_norm = self.dp.step(max_grad_norm=self.max_grad_norm)     # (hyper-parameters: FlatAdamW.hyper, pulled when the step begins)
         return loss
 
     def zero_grad(self, set_to_none: bool = True) -> None:

@@ -390,7 +390,6 @@ def _opt_worker(rank, world, port, q):
         gr = torch.Generator().manual_seed(100 * step + rank)
         bucket.flat.copy_(torch.randn(ends[-1], generator=gr).to(dev))          # this rank's gradient
         opt.begin_step()
-        opt.upload_coef()
         for l in range(n_layers - 1, -1, -1):
             bucket.layer_done(l)          # a finished bucket: all-reduce on the communication stream, its AdamW slice right behind it
         bucket.finish(average=False)
@@ -501,4 +500,98 @@ def test_optimizer_in_backward_on_two_ranks():
         assert (got[0] == got[1]).all()
         res[inb] = torch.from_numpy(got[0])
     err = ((res[True] - res[False]).norm() / res[False].norm()).item()
+    assert err <= 1e-5, err
+
+
+def _rccl_one_rank_worker(port, q):
+    """One process, ONE-rank RCCL process group: the communication path of attach() as N > 1 ranks run it (ProcessGroupNCCL's own
+    stream, in-place asynchronous all-reduce of a bucket slice, the bucket's AdamW slice on the communication stream behind it),
+    against the short-circuit path, bit for bit (deterministic weight gradients; a one-rank sum is the identity)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    from moka_amd import functional as F
+    from moka_amd.parallel import attach
+    F.set_deterministic(True, device=dev)
+    outs = []
+    for force in (False, True):
+        st, dims = _build("avt", dev)
+        dp = attach(st, n_buckets=3, lr=1e-2, weight_decay=0.01, defer_dA=True, optimizer_in_backward=True, force_comm=force)
+        assert dp.bucket.comm == force and dp.bucket.world == 1
+        assert (dp.bucket.comm_stream is not None) == force
+        h, gout, mask_args, sl = _batch("avt", dims, dev)
+        for step in range(3):
+            if step == 1:
+                with dp.no_sync():
+                    _run(st, dp, h[:1], gout[:1], sl(0, 1), 1.0)
+                _run(st, dp, h[1:], gout[1:], sl(1, 2), 1.0)
+            else:
+                _run(st, dp, h, gout, mask_args, 0.5)
+            if force:
+                assert dp.bucket._pending, "no collective was issued"
+            dp.step()
+        torch.cuda.synchronize()
+        assert float(dp.bucket.flat.abs().max()) == 0.0 and dp.optimizer.t == 3
+        outs.append((dp.master.cpu().numpy(), dp.work.float().cpu().numpy()))
+    backend = dist.get_backend()
+    dist.destroy_process_group()
+    q.put((backend, outs))
+
+
+def test_one_rank_rccl_runs_the_communication_path_bit_for_bit():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    backend, outs = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert backend == "nccl"
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
+def test_bench_force_comm_prices_the_multi_gpu_configuration_on_one_gpu():
+    """bench.py --force-comm: --graph bwd, the bucket hooks between the graphs and the AdamW slices behind each (one-rank RCCL) all-reduce."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-comm", "--steps", "2", "--warmup", "1", "--layers", "4", "--batch", "1",
+                          "--seq", "512", "--no-cpu-baseline", "--no-traffic"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-1000:], out.stderr[-1000:])
+    line = json.loads(lines[0])
+    assert line["graph"] == "bwd" and line["distributed"]["backend"] == "nccl" and line["distributed"]["force_comm"] is True
+    assert line["optimizer_in_backward"] is True and line["comm_exposed_ms"] >= 0.0 and line["value"] > 0
+
+
+def test_lr_scheduler_drives_the_optimizer_inside_the_backward():
+    """MokaFlatOptimizer on attach(optimizer_in_backward=True): the step's hyper-parameters are read from param_groups[0] when the step
+    BEGINS (the first finished bucket of the backward), so the optimizer's own lr -- not the value attach() was given -- applies from
+    the first step, and a scheduler's warm-up is not a step late; clipping is refused up front in this mode."""
+    dev = torch.device("cuda:0")
+    from moka_amd.parallel import MokaFlatOptimizer, attach
+    outs = []
+    for inb in (False, True):
+        st, dims = _build("avt", dev)
+        dp = attach(st, n_buckets=3, lr=1e-4, optimizer_in_backward=inb)          # (1e-4 must never be used)
+        opt = MokaFlatOptimizer(dp, lr=2e-2, weight_decay=0.01)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: [0.1, 0.5, 1.0, 1.0][min(k, 3)])
+        h, gout, mask_args, _ = _batch("avt", dims, dev)
+        lrs = []
+        for _ in range(3):
+            _run(st, dp, h, gout, mask_args, 0.5)
+            opt.step()
+            lrs.append(dp.optimizer.lr)
+            sched.step()
+        torch.cuda.synchronize()
+        assert lrs == pytest.approx([2e-3, 1e-2, 2e-2]), lrs
+        outs.append(dp.master.clone())
+        if inb:
+            with pytest.raises(ValueError):
+                MokaFlatOptimizer(dp, max_grad_norm=1.0)
+    err = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
     assert err <= 1e-5, err

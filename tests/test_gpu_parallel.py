@@ -75,9 +75,10 @@ def test_flat_adamw_rejects_bad_arguments():
 
 
 def test_flat_adamw_in_slices_with_device_coefficients_equals_the_one_launch_step():
-    """``begin_step(); upload_coef(); step_range(lo, hi)`` per gradient bucket (moka_adamw_flat_dev: the step-dependent coefficients are read
-    from device memory) = ``step()`` bit for bit -- also when the slice launches are captured ONCE in a hipGraph and replayed: the host
-    refreshes the pinned coefficients before every replay."""
+    """``begin_step(); step_range(lo, hi)`` per gradient bucket (moka_adamw_flat_dev: the step-dependent coefficients are read from device
+    memory, written there by the one-thread launch of begin_step from its launch arguments) = ``step()`` bit for bit -- also when the
+    slice launches are captured ONCE in a hipGraph and replayed behind a live begin_step, and (to the last bit of the device's pow) when
+    begin_step itself is captured and counts the steps on the device."""
     from moka_amd.parallel import FlatAdamW
     dev = _dev()
     n = 4096 * 5 + 64
@@ -100,17 +101,14 @@ def test_flat_adamw_in_slices_with_device_coefficients_equals_the_one_launch_ste
     for gk in grads:
         g1.copy_(gk)
         opt.begin_step()
-        opt.upload_coef()
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             opt.step_range(lo, hi, grad_scale=0.25, zero_grad=True)
     assert torch.equal(m1, m0) and torch.equal(w1, w0) and torch.equal(opt.exp_avg_sq, ref.exp_avg_sq) and float(g1.abs().max()) == 0.0
     # the same launches captured once
     m2, g2, w2, opt2 = fresh()
-    opt2.begin_step()
-    opt2.t -= 1                                                   # (allocate the coefficient buffers without counting a step)
+    opt2.set_device_step(0)                                       # (allocates the coefficient state without counting a step)
     graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=dev)
     with torch.cuda.graph(graph, stream=side):
-        opt2.upload_coef()
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             opt2.step_range(lo, hi, grad_scale=0.25, zero_grad=True)
     for gk in grads:
@@ -119,5 +117,59 @@ def test_flat_adamw_in_slices_with_device_coefficients_equals_the_one_launch_ste
         graph.replay()
     torch.cuda.synchronize()
     assert opt2.t == ref.t and torch.equal(m2, m0) and torch.equal(w2, w0) and torch.equal(opt2.exp_avg, ref.exp_avg)
+    # begin_step captured too: the device counts the steps, the host enqueues NOTHING but replays (and may run any number of steps ahead)
+    m3, g3s, w3, opt3 = fresh()
+    opt3.set_device_step(0)
+    gsrc = torch.zeros_like(g3s)
+    graph3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph3, stream=side):
+        g3s.copy_(gsrc)
+        opt3.begin_step(device_counter=True)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            opt3.step_range(lo, hi, grad_scale=0.25, zero_grad=True)
+    opt3.t -= 1
+    for gk in grads:
+        gsrc.copy_(gk)
+        graph3.replay()
+        opt3.t += 1
+    torch.cuda.synchronize()
+    assert int(opt3._state[3:4].view(torch.int32).item()) == ref.t == opt3.t
+    assert (m3 - m0).abs().max().item() <= 1e-6 * m0.abs().max().item() and (opt3.exp_avg - ref.exp_avg).abs().max().item() == 0.0
     with pytest.raises(ValueError):
         opt.step_range(2, 64)
+
+
+def test_no_decay_ranges_follow_the_hf_rule_and_equal_torch_adamw_with_two_groups():
+    """attach(no_decay="hf"): biases and norm weights take no weight decay (what HF Trainer's default optimizer does and the reference
+    therefore trains with); the fused step in segments == torch.optim.AdamW with a decay and a no-decay group."""
+    from moka_amd.parallel import FlatAdamW
+    dev = _dev()
+    n = 1024 * 3
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    master, grad = p0.to(dev).clone(), torch.zeros(n, device=dev)
+    opt = FlatAdamW(master, grad, None, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1)
+    opt.no_decay_ranges = [(1024, 1536), (2048, 2052)]
+    ref = torch.nn.Parameter(p0.clone().to(dev))
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[1024:1536] = True
+    mask[2048:2052] = True
+    # torch.optim.AdamW on one flat parameter cannot mix decays: emulate with two parameters
+    pa, pb = torch.nn.Parameter(p0[~mask].clone().to(dev)), torch.nn.Parameter(p0[mask].clone().to(dev))
+    topt = torch.optim.AdamW([{"params": [pa], "weight_decay": 0.1}, {"params": [pb], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    for k, gk in enumerate(grads):
+        grad.copy_(gk.to(dev))
+        if k == 1:
+            opt.begin_step()
+            opt.step_range(0, 2048, zero_grad=True)          # (slices cut at arbitrary multiples of 4: the segments follow)
+            opt.step_range(2048, n, zero_grad=True)
+        else:
+            opt.step(zero_grad=True)
+        pa.grad, pb.grad = gk[~mask].to(dev), gk[mask].to(dev)
+        topt.step()
+    torch.cuda.synchronize()
+    got = master.cpu()
+    assert (got[~mask] - pa.detach().cpu()).abs().max().item() <= 2e-6
+    assert (got[mask] - pb.detach().cpu()).abs().max().item() <= 2e-6
+    del ref
