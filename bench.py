@@ -85,7 +85,8 @@ class Unit:
     def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False):
         from moka_amd import _lib
         G = len(members)
-        self.fused = fused
+        # per unit: the library's advice for this shape (moka_up_fwd_fused_pays: e.g. not for the 70B widths' single projections)
+        self.fused = bool(fused and _lib.up_fwd_fused_pays(T, _lib.ksplit(T, members[0]["d_in"], r), [m["d_out"] for m in members], r))
         self.label, self.G, self.T = label, G, T
         self.d_in = members[0]["d_in"]
         self.d_outs = [m["d_out"] for m in members]
@@ -308,14 +309,12 @@ def run_forward(lib, wl, sp, rec=None, shadows=False):
     interaction inside (it also writes h and the rank-major hp pack for the backward).  The weight shadows the backward reads (BwT, AT)
     are functions of the weights alone: they are rewritten where the weights change (run_shadows behind the optimizer step), not in
     the forward -- unless `shadows` asks for them in front of every unit (--shadows main)."""
-    units = wl["units"]
-    if not units[0].fused:
-        for u in units:
+    for u in wl["units"]:
+        if not u.fused:
             _call(lib, "moka_down_fwd", u, sp, rec)
             _call(lib, "moka_cross_fwd", u, sp, rec)
             _call(lib, "moka_up_fwd", u, sp, rec)
-        return
-    for u in units:
+            continue
         if shadows:
             _call(lib, "moka_weight_shadows", u, sp, rec)
         _call(lib, "moka_down_fwd", u, sp, rec)
@@ -327,7 +326,8 @@ def run_shadows(lib, wl, sp, layers, rec=None):
     units, per = wl["units"], wl["units_per_layer"]
     for l in layers:
         for u in units[l * per:(l + 1) * per]:
-            _call(lib, "moka_weight_shadows", u, sp, rec)
+            if u.fused:                      # (the other units' moka_cross_fwd writes their shadows in the forward)
+                _call(lib, "moka_weight_shadows", u, sp, rec)
 
 
 def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False):
@@ -569,11 +569,20 @@ def end_to_end(args, dev):
         torch.cuda.empty_cache()
         return ms
 
+    from moka_amd import functional as MF
     ms_base = timed(plain, False)
     ms_moka = timed(adapted, True)
+    # the adapter's x-only / gy-only halves on a side stream beside the frozen base GEMM of the same projection (functional.OVERLAP_BASE,
+    # attach(overlap_base=True)): same kernels, same bits
+    MF.set_overlap_base(True)
+    try:
+        ms_ovl = timed(adapted, True)
+    finally:
+        MF.set_overlap_base(False)
     return {"what": "decoder stack fwd+bwd (+ fused AdamW on the adapter), %d layers, %d x %d tokens, bf16; NOT the metric" % (L, B, S),
             "ms_per_step": round(ms_moka, 2), "tokens_per_s": round(B * S / (ms_moka * 1e-3), 1),
-            "frozen_base_only_ms_per_step": round(ms_base, 2), "adapter_share_of_step": round(1.0 - ms_base / ms_moka, 4)}
+            "frozen_base_only_ms_per_step": round(ms_base, 2), "adapter_share_of_step": round(1.0 - ms_base / ms_moka, 4),
+            "overlap_base": {"ms_per_step": round(ms_ovl, 2), "adapter_share_of_step": round(1.0 - ms_base / ms_ovl, 4)}}
 
 
 def main():
@@ -890,6 +899,7 @@ def main():
                 per_shape[key] = (a_ + ms, b_ + 1, u.algo[n])
             return tot, cnt, byt, per_shape
         sp_ = c_void_p(torch.cuda.current_stream().cuda_stream)
+        units_all = wl["units"]
         roof_behind = not records.items
         if not records.items:
             # graph replay: nothing can be bracketed inside the timed region -> the dominant entry point is bracketed (every n-th
@@ -957,7 +967,7 @@ def main():
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
                             "adapter_params": wl["n_params"]},
             "graph": args.graph,
-            "fused_forward": bool(args.fused),
+            "fused_forward": ("all units" if all(u.fused for u in units_all) else ("units " + ", ".join(sorted({u.label for u in units_all if u.fused})) if any(u.fused for u in units_all) else False)) if args.fused else False,
             "chains": args.chains,
             "defer_dA": args.defer_da,
             "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority, "optimizer_in_backward": bool(opt_in_bwd),

@@ -177,6 +177,11 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
  * Replaces lora.py:485-530 / layer.py:627-669.
  * bf16 storage, r <= 32 (moka_up_fwd_fused_ok() == 1); otherwise MOKA_EINVAL -- use moka_cross_fwd + moka_up_fwd. */
 int moka_up_fwd_fused_ok(int r, int dtype);
+/* 1 when the fused launch is expected to beat moka_cross_fwd + moka_up_fwd for this shape (a measured rule: projections of one
+ * width, at most 24 slices, and a group or a projection of moderate width -- every column range of the y kernel repeats the slice
+ * sums, so many slices, narrow members or a single very wide projection are better off on the two-launch path); 0 otherwise.
+ * Both paths give the same bits: the choice is the caller's, this is the library's advice. */
+int moka_up_fwd_fused_pays(int T, int ks, const int* d_out /*[G]*/, int G, int r, int dtype);
 int moka_up_fwd_fused(const float* part, int ks, const moka_routing* rt, const float* s_out /*host, M floats*/,
                       const void* Bw, void* y_inout, int d_out, float* h /*or NULL*/, void* hp_kmj /*or NULL*/,
                       int r, float w, float inv_sqrt_dk, int dtype, moka_stream_t stream);

@@ -59,6 +59,7 @@ SYMBOLS = {
     # hp_tok, Bw, tok_mod, y, T, r, d_out, dtype, stream
     "moka_up_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "moka_up_fwd_fused_ok": (c_int, [c_int, c_int]),
+    "moka_up_fwd_fused_pays": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int, c_int]),
     # part, ks, rt, s_out, Bw, y_inout, d_out, h, hp_kmj, r, w, inv_sqrt_dk, dtype, stream
     "moka_up_fwd_fused": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), POINTER(c_float), c_void_p, c_void_p,
                                   c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
@@ -193,6 +194,12 @@ def up_fwd_fused_ok(r: int, dtype: int = 0) -> bool:
     if key not in _FUSED:
         _FUSED[key] = load().moka_up_fwd_fused_ok(*key) == 1
     return _FUSED[key]
+
+
+def up_fwd_fused_pays(T: int, ks: int, d_outs, r: int, dtype: int = 0) -> bool:
+    """The library's advice: does the fused launch beat cross_fwd + up_fwd for this shape? (same bits either way)"""
+    arr = (c_int * len(d_outs))(*[int(d) for d in d_outs])
+    return load().moka_up_fwd_fused_pays(int(T), int(ks), arr, len(d_outs), int(r), int(dtype)) == 1
 
 
 def tok_pad(T: int) -> int:

@@ -4494,6 +4494,19 @@ int moka_up_fwd_fused_ok(int r, int dtype) {
     return (RP == 16 || RP == 32) && dtype == MOKA_BF16 ? 1 : 0;
 }
 
+// Does the fused launch beat moka_cross_fwd + moka_up_fwd for this shape?  Measured (MI355X, 8192 tokens, r = 16; us per unit, two
+// launches -> fused): 7B widths o 41.9 -> 35.8, down (ks = 22) 43.7 -> 40.5, q+k+v 89.2 -> 85.0, gate+up 158.4 -> 149.6; 70B widths
+// gate+up 398 -> 389, but o (8192 wide, ks = 16) 70 -> 82, down (ks = 56) 74 -> 92, q / k / v of different width (8192 / 1024 / 1024) 87 -> 133:
+// every column range repeats the slice sums, so many slices or few columns per range lose, and a single wide projection is better
+// off in the column-owning kernel.
+int moka_up_fwd_fused_pays(int T, int ks, const int* d_out, int G, int r, int dtype) {
+    if (!moka_up_fwd_fused_ok(r, dtype) || !d_out || G < 1 || G > MOKA_MAX_GROUP || T < 1 || ks < 1) return 0;
+    int cmax = 0;
+    for (int g = 0; g < G; ++g) { if (d_out[g] != d_out[0]) return 0; cmax = d_out[g] > cmax ? d_out[g] : cmax; }
+    if (ks > 24) return 0;
+    return (G > 1 || cmax <= 6144) ? 1 : 0;
+}
+
 int moka_up_fwd_fused_group(const float* const* part, int ks, const moka_routing* rt, const float* s_out,
                             const void* const* Bw, void* const* y_inout, const int* d_out,
                             float* const* h, void* const* hp_kmj,

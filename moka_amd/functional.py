@@ -8,6 +8,7 @@ with the explicit backward the reference leaves to autograd (SURVEY.md section 8
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import POINTER, byref, c_float, c_void_p
 from typing import List, Optional, Sequence, Tuple
 
@@ -17,8 +18,34 @@ from . import _lib
 from .routing import MokaRouting
 
 
+_LAUNCH = threading.local()          # .stream: launch-stream override of this thread (see _launch_on)
+
+
+def _launch_stream(device) -> "torch.cuda.Stream":
+    ov = getattr(_LAUNCH, "stream", None)
+    return ov if ov is not None else torch.cuda.current_stream(device)
+
+
 def _stream_ptr(device) -> c_void_p:
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return c_void_p(_launch_stream(device).cuda_stream)
+
+
+class _launch_on:
+    """Enqueue the library's launches on `stream` WITHOUT making it torch's current stream: the tensors the wrappers allocate keep
+    coming from the current stream's pool, so a side-stream kernel writes into memory that is handed back to the allocator of the
+    stream that later joins it -- no record_stream, no cross-stream allocator traffic (with `torch.cuda.stream(side)` +
+    `record_stream` the whole decoder stack went from 344 to 509 ms per step)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = getattr(_LAUNCH, "stream", None)
+        _LAUNCH.stream = self.stream
+
+    def __exit__(self, *exc):
+        _LAUNCH.stream = self.prev
+        return False
 
 
 def _require_device(t: torch.Tensor, name: str):
@@ -407,7 +434,7 @@ def _det_opts(device, T: int, C_max: int, r: int, G: int, M: int):
     n = int(_lib.load().moka_deterministic_ws_bytes(int(T), int(C_max), int(r), int(G), int(M)))
     if n == 0:
         return None
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev, _launch_stream(dev).cuda_stream)
     ws = _DET_WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -462,6 +489,31 @@ def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[t
 # (tests/test_gpu_fused.py); a module-level switch for A/B runs, not a tuning knob.
 FUSE_FORWARD = True
 
+# Overlap of the adapter's x-only / gy-only halves with the frozen base GEMM of the same projection (attach(overlap_base=True),
+# set_overlap_base): the down-projection (+ weight shadows) runs on a side stream beside F.linear and is joined in front of the
+# up-projection; in the backward the pass over gy and the rank-space backward run beside gy.W and are joined in front of the dx pass.
+# Same kernels, same bits; what it buys is measured per configuration (bench.py --e2e --overlap-base) -- off by default.
+OVERLAP_BASE = False
+_SIDE_STREAMS = {}
+
+
+def set_overlap_base(enabled: bool) -> None:
+    global OVERLAP_BASE
+    OVERLAP_BASE = bool(enabled)
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(dev)
+    if st is None:
+        # (high priority: measured on the 7B stack, 4 x 2048 tokens: 348.6 ms sequential, 350.3 ms with the side stream at high priority, 468 ms at the GEMM's own priority -- interleaved workgroups cost the hipBLASLt kernels far more than the overlap hides; MOKA_SIDE_PRIORITY for A/B runs)
+        import os
+        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MOKA_SIDE_PRIORITY", "-1")))
+    return st
+
+
 
 # --------------------------------------------------------------------------------------
 # autograd node of one adapted projection
@@ -508,24 +560,38 @@ class MokaLinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         if x2.shape[0] != rt.T:
             raise ValueError(f"x has {x2.shape[0]} tokens but the masks describe {rt.T}")
+        A = [a if a.is_contiguous() else a.contiguous() for a in A]
+        Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
+        fused = (dt == _lib.MOKA_BF16 and FUSE_FORWARD and
+                 _lib.up_fwd_fused_pays(x2.shape[0], _lib.ksplit(x2.shape[0], d_in, spec.r), [Bw.shape[0]], spec.r, dt))
+        overlap = OVERLAP_BASE and fused and W is not None
+        shadows = None
+        if overlap:
+            # the x-only half of the adapter beside the base GEMM (it is HBM-bound, the GEMM compute-bound)
+            cur, side = torch.cuda.current_stream(x2.device), _side_stream(x2.device)
+            side.wait_stream(cur)
+            with _launch_on(side):
+                part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
+                shadows = weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
         if W is not None:
             y = torch.nn.functional.linear(x2, W, bias)               # frozen base, stock PyTorch-ROCm
         else:                                                         # adapter term alone (per-sample adapter_names: several adapters add to one base output)
             y = torch.zeros((x2.shape[0], Bw.shape[0]), dtype=x2.dtype, device=x2.device)
-        A = [a if a.is_contiguous() else a.contiguous() for a in A]
-        Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
-        part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
+        if overlap:
+            cur.wait_stream(side)
+        else:
+            part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
         if dt == _lib.MOKA_F32:
             # fp32 storage: the rank-space rows themselves are the operands (no bf16 packs, no weight shadows)
             st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, want_hp=True)
             hps = st.hp * _token_scale(rt, spec.s_out, x2.device)[:, None]
             up_fwd_(y, hps, Bw_c, rt, spec.r, dtype=dt)
             ctx.save_for_backward(x2, W, Bw_c, st.h, hps, Bw_c, None, *A)
-        elif FUSE_FORWARD and _lib.up_fwd_fused_ok(spec.r, dt):
+        elif fused:
             # two launches on the dependency chain: the up-projection computes the interaction itself from the slices and writes what
             # the backward reads from the rank space (h, hp_kmj); the weight shadows are functions of the weights alone
             st = up_fwd_fused_(y, part, Bw_c, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, want_state=True)
-            st.BwT, st.AT = weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
+            st.BwT, st.AT = shadows if shadows is not None else weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
             ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
         else:
             st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
@@ -561,14 +627,28 @@ class MokaLinearFn(torch.autograd.Function):
         dt = ctx.dt
         # dB is needed by the optimizer only: where it is a pass of its own over gy anyway (r > 32), it leaves the dependency chain like dA_m
         split_dB = spec.sinks is not None and spec.defer is not None and dB_acc is not None and _lib.up_bwd_passes(r, dt) == 2
-        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
+        overlap = OVERLAP_BASE and dt == _lib.MOKA_BF16 and need_x and W is not None
+        bst = None
+        if overlap:
+            # the gy-only half of the adapter (pass over gy, rank-space backward) beside the base input-gradient GEMM
+            cur, side = torch.cuda.current_stream(gy2.device), _side_stream(gy2.device)
+            side.wait_stream(cur)
+            with _launch_on(side):
+                g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
+                bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+        else:
+            g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
         if split_dB:
             spec.defer(lambda: up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt, want_g=False), [gy2, hp_kmj])
         dx2 = None
         if need_x:                                                   # frozen base: dx only, never dW
             dx2 = torch.matmul(gy2, W) if W is not None else torch.zeros_like(x2)
+        if overlap:
+            cur.wait_stream(side)
         if need_A or need_x:
-            if dt == _lib.MOKA_F32:
+            if bst is not None:
+                pass
+            elif dt == _lib.MOKA_F32:
                 bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk, want_dh=True)
                 bst.dh_tok, bst.dh_kmj = bst.dh * spec.s_in, None    # the fp32 rows, scaled, stand in for the packs
                 AT = torch.stack(list(A)).contiguous()
@@ -636,15 +716,27 @@ class MokaLinearGroupFn(torch.autograd.Function):
             x2 = x2.contiguous()
         if x2.shape[0] != rt.T:
             raise ValueError(f"x has {x2.shape[0]} tokens but the masks describe {rt.T}")
-        ys = [torch.nn.functional.linear(x2, Ws[g], biases[g]) for g in range(G)]      # frozen base, stock PyTorch-ROCm
         As = [[a if a.is_contiguous() else a.contiguous() for a in Ag] for Ag in As]
         Bws = [b if b.is_contiguous() else b.contiguous() for b in Bws]
         seeds = [s_.seed for s_ in specs]
-        parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
         need_x = ctx.needs_input_grad[0]
-        if FUSE_FORWARD and _lib.up_fwd_fused_ok(sp.r, _lib.MOKA_BF16):
+        fused = FUSE_FORWARD and _lib.up_fwd_fused_pays(x2.shape[0], _lib.ksplit(x2.shape[0], d_in, sp.r), [b.shape[0] for b in Bws], sp.r)
+        overlap = OVERLAP_BASE and fused
+        shadows = None
+        if overlap:                                                  # (see MokaLinearFn.forward)
+            cur, side = torch.cuda.current_stream(x2.device), _side_stream(x2.device)
+            side.wait_stream(cur)
+            with _launch_on(side):
+                parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
+                shadows = weight_shadows_group(Bws, As if need_x else None, sp.r)
+        ys = [torch.nn.functional.linear(x2, Ws[g], biases[g]) for g in range(G)]      # frozen base, stock PyTorch-ROCm
+        if overlap:
+            cur.wait_stream(side)
+        else:
+            parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
+        if fused:
             sts = up_fwd_fused_group_(ys, parts, Bws, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, want_state=True)     # (see MokaLinearFn.forward)
-            BwTs, ATs = weight_shadows_group(Bws, As if need_x else None, sp.r)
+            BwTs, ATs = shadows if shadows is not None else weight_shadows_group(Bws, As if need_x else None, sp.r)
             for g in range(G):
                 sts[g].BwT, sts[g].AT = BwTs[g], (ATs[g] if ATs is not None else None)
         else:
@@ -702,7 +794,16 @@ class MokaLinearGroupFn(torch.autograd.Function):
             flat, acc = _grad_accumulators(shapes, dev) if shapes else (None, [])
         dB_accs = acc[:G] if need_B else None
         split_dB = use_sinks and sp.defer is not None and dB_accs is not None and _lib.up_bwd_passes(r, _lib.MOKA_BF16) == 2
-        g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
+        overlap = OVERLAP_BASE and need_x
+        bsts = None
+        if overlap:                                                  # (see MokaLinearFn.backward)
+            cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(cur)
+            with _launch_on(side):
+                g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
+                bsts = cross_bwd_group(g_parts, hs, rt, r, sp.s_in, sp.w, sp.inv_sqrt_dk)
+        else:
+            g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
         if split_dB:                                                 # (see MokaLinearFn.backward)
             sp.defer(lambda: up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs, want_g=False), list(gy2) + list(hp_kmjs))
         dx2 = None
@@ -710,9 +811,12 @@ class MokaLinearGroupFn(torch.autograd.Function):
             dx2 = torch.matmul(gy2[0], Ws[0])                        # frozen base: dx only, never dW
             for g in range(1, G):
                 dx2.addmm_(gy2[g], Ws[g])
+        if overlap:
+            cur.wait_stream(side)
         dA_accs = None
         if need_A or need_x:
-            bsts = cross_bwd_group(g_parts, hs, rt, r, sp.s_in, sp.w, sp.inv_sqrt_dk)
+            if bsts is None:
+                bsts = cross_bwd_group(g_parts, hs, rt, r, sp.s_in, sp.w, sp.inv_sqrt_dk)
             if need_A:
                 a0 = G if need_B else 0
                 dA_accs = [acc[a0 + g * M:a0 + (g + 1) * M] for g in range(G)]

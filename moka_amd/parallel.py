@@ -473,7 +473,8 @@ class AdapterDataParallel:
 def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: bool = True, lr: float = 1e-4,
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
            comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True,
-           optimizer_in_backward: bool = False, force_comm: bool = False, no_decay="hf") -> AdapterDataParallel:
+           optimizer_in_backward: bool = False, force_comm: bool = False, no_decay="hf",
+           overlap_base: Optional[bool] = None) -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
     base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
@@ -509,8 +510,15 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
       the reference therefore trains without decay (``AudioVisualText/trainer.py`` does not override ``create_optimizer``): biases and
       the weights of normalisation layers; a callable ``(name, param, module) -> bool``; ``None`` = decay everywhere.
 
+    * ``overlap_base`` (None: leave the process-wide switch alone): the adapter's x-only half (down-projection, weight shadows) and
+      gy-only half (pass over gy, rank-space backward) run on a side stream beside the frozen base GEMM of the same projection and are
+      joined in front of the kernels that add to the GEMM's result (``functional.set_overlap_base``; same kernels, same bits).
+
     Replaces DeepSpeed ZeRO-2's bucketed reduce-scatter + partitioned optimizer of the reference configurations
     (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``)."""
+    if overlap_base is not None:
+        from . import functional as _F
+        _F.set_overlap_base(bool(overlap_base))
     pick = trainable if trainable is not None else (lambda n, p: p.requires_grad)
     named = [(n, p) for n, p in model.named_parameters() if pick(n, p)]
     if not named:
