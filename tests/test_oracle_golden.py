@@ -71,3 +71,36 @@ def test_oracle_backward_matches_autograd_of_itself():
     assert torch.allclose(dB, Bw.grad, rtol=1e-10, atol=1e-12)
     for m in range(3):
         assert torch.allclose(dA[m], A[m].grad, rtol=1e-10, atol=1e-12)
+
+
+def test_reference_on_overlapping_masks_is_pinned_and_the_routed_forms_refuse_them():
+    """A token in TWO modality masks (lora.py:468 runs every adapter on its masked copy of x): the real AVT layer gives it one
+    rank-space row per modality stream, each stream interacts on its own, the streams are summed -- pinned by
+    tests/golden/avt_dual_modality.npz (oracle/make_dual_golden.py: reference fp64 outputs + gradients) through the dense-mask
+    restatement oracle/dense_avt.py.  One modality id per token cannot express that: the routed oracle and the host routing of the
+    HIP path raise ValueError instead of computing something else."""
+    import os
+    import numpy as np
+    from moka_amd.routing import MokaRouting
+    from oracle.dense_avt import avt_dense_forward
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "avt_dual_modality.npz"))
+    t = lambda k: torch.from_numpy(g[k])          # noqa: E731
+    masks = [m for m in t("masks")]
+    assert int((masks[0] + masks[1] + masks[2]).max()) == 2          # the overlap is really there
+    x = t("x").clone().requires_grad_(True)
+    A = [a.clone().requires_grad_(True) for a in t("A")]
+    Bw = t("Bw").clone().requires_grad_(True)
+    y = avt_dense_forward(x, t("W"), A, Bw, masks, float(g["alpha"]), int(g["r"]), float(g["w"]))
+    (y * t("gy")).sum().backward()
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()          # noqa: E731
+    assert rel(y.detach(), t("ref_y")) < 1e-12 and rel(x.grad, t("ref_dx")) < 1e-12 and rel(Bw.grad, t("ref_dB")) < 1e-12
+    for m in range(3):
+        assert rel(A[m].grad, t("ref_dA")[m]) < 1e-12
+    # ... and it is NOT what routing every token to one adapter would give: dropping the second membership changes y
+    single = [masks[0] * (1 - masks[1]) * (1 - masks[2])] + masks[1:]
+    y1 = avt_dense_forward(t("x"), t("W"), [a.detach() for a in A], Bw.detach(), single, float(g["alpha"]), int(g["r"]), float(g["w"]))
+    assert rel(y1, t("ref_y")) > 1e-3
+    with pytest.raises(ValueError):
+        O.routing_from_avt_masks(masks)
+    with pytest.raises(ValueError):
+        MokaRouting.from_avt_masks(masks)
