@@ -312,11 +312,12 @@ def run_forward(lib, wl, sp, rec=None, shadows=False):
     for u in wl["units"]:
         if not u.fused:
             _call(lib, "moka_down_fwd", u, sp, rec)
-            _call(lib, "moka_cross_fwd", u, sp, rec)
+            _call(lib, "moka_cross_fwd", u, sp, rec)       # (writes its own weight shadows: taking them out gained nothing at rank 64, 82.3 vs 84.1 ms)
             _call(lib, "moka_up_fwd", u, sp, rec)
             continue
         if shadows:
-            _call(lib, "moka_weight_shadows", u, sp, rec)
+            if u.fused:                      # (the other units' moka_cross_fwd writes their shadows in the forward)
+                _call(lib, "moka_weight_shadows", u, sp, rec)
         _call(lib, "moka_down_fwd", u, sp, rec)
         _call(lib, "moka_up_fwd:fused", u, sp, rec)
 
@@ -326,8 +327,7 @@ def run_shadows(lib, wl, sp, layers, rec=None):
     units, per = wl["units"], wl["units_per_layer"]
     for l in layers:
         for u in units[l * per:(l + 1) * per]:
-            if u.fused:                      # (the other units' moka_cross_fwd writes their shadows in the forward)
-                _call(lib, "moka_weight_shadows", u, sp, rec)
+            _call(lib, "moka_weight_shadows", u, sp, rec)
 
 
 def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False):
@@ -643,9 +643,9 @@ def main():
                     help="on (default, r <= 32): the up-projection computes the cross-modal interaction itself (moka_up_fwd_fused) and the rank-space "
                          "launch, which then only writes the backward's operands, runs on a side stream off the dependency chain; off: three launches per unit")
     ap.add_argument("--shadows", choices=("opt", "main"), default="opt",
-                    help="with --fuse-fwd on: where the weight-shadow launches (BwT / AT, functions of the weights alone, read by the backward) run: "
-                         "opt = where the weights change, behind the optimizer update (per gradient bucket on the side / communication stream with "
-                         "--opt-in-backward); main = in front of every unit on the forward's chain")
+                    help="fused units: where BwT / AT (functions of the weights alone, read by the backward) are written: opt = where the weights change, "
+                         "behind the optimizer update (moka_weight_shadows per gradient bucket on the side / communication stream with --opt-in-backward); "
+                         "main = in front of every fused unit on the forward's chain (three-launch units: inside moka_cross_fwd)")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -747,7 +747,7 @@ def main():
                     run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), [l for l in range(L) if blo < ends[l] <= bhi])
             bucket.on_reduced = _reduced
             shadows_in_cb = shadows_opt
-    if args.fused:
+    if shadows_opt:
         run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), range(L))     # the initial weights' shadows
         torch.cuda.synchronize()
 

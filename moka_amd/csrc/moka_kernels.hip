@@ -361,7 +361,7 @@ static __device__ __forceinline__ f32x4 sum_slices4(const float* p, size_t strid
 // owns IPT float4 elements of each array; per batch SB slices of both arrays are requested before anything is consumed
 // (16 loads of 16 bytes in flight per thread), so a 4096-wide input (8 slices) costs one memory round trip instead of the
 // five a load-wait-load-wait sequence took, a 11008-wide one three instead of thirteen.  Sums run in slice order.
-template <int IPT, int SB>
+template <int IPT, int SB, bool KEYS>
 static __device__ __forceinline__ void sum_rows_and_keys(const float* part, size_t sstride, int ks, const size_t (&offR)[IPT], const size_t (&offK)[IPT],
                                                          f32x4 (&accR)[IPT], f32x4 (&accK)[IPT]) {
 #pragma unroll
@@ -372,13 +372,13 @@ static __device__ __forceinline__ void sum_rows_and_keys(const float* part, size
         for (int q = 0; q < SB; ++q) {
             const size_t so = (size_t)min(s0 + q, ks - 1) * sstride;
 #pragma unroll
-            for (int u = 0; u < IPT; ++u) { xr[u][q] = *(const f32x4*)(part + offR[u] + so); xk[u][q] = *(const f32x4*)(part + offK[u] + so); }
+            for (int u = 0; u < IPT; ++u) { xr[u][q] = *(const f32x4*)(part + offR[u] + so); if (KEYS) xk[u][q] = *(const f32x4*)(part + offK[u] + so); }
         }
 #pragma unroll
         for (int q = 0; q < SB; ++q) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < IPT; ++u) { accR[u] += (s0 + q < ks) ? xr[u][q] : z; accK[u] += (s0 + q < ks) ? xk[u][q] : z; }
+            for (int u = 0; u < IPT; ++u) { accR[u] += (s0 + q < ks) ? xr[u][q] : z; if (KEYS) accK[u] += (s0 + q < ks) ? xk[u][q] : z; }
         }
     }
 }
@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
         tk[u] = a.ktok[b * a.Lkp + min(row, a.Lkp - 1)];
         rmod[u] = a.tok_mod[b * a.S + r0 + min(row, nrow - 1)];
     }
+    const int anyq0 = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     // ---- round trip 2 (.. 1 + ks / SB): the rows' and the first chunk's key rows' split-K slices, all in flight together
     {
         size_t offR[IPT], offK[IPT];
@@ -438,7 +439,10 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
             offK[u] = (size_t)max(tk[u], 0) * RP + 4 * k4;
         }
         f32x4 accR[IPT], accK[IPT];
-        sum_rows_and_keys<IPT, SB>(a.part, sstride, a.ks, offR, offK, accR, accK);
+        // (the key rows only where the block holds query rows -- block uniform, known from the routing bytes of round trip 1: three
+        //  blocks in four of the bench layout skip half of their loads; at rank pad 64 the slices are 256 bytes per token each)
+        if (anyq0) sum_rows_and_keys<IPT, SB, true>(a.part, sstride, a.ks, offR, offK, accR, accK);
+        else sum_rows_and_keys<IPT, SB, false>(a.part, sstride, a.ks, offR, offK, accR, accK);
 #pragma unroll
         for (int u = 0; u < IPT; ++u) {
             const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
@@ -453,7 +457,8 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
         }
     }
     if (tid < RB) s_mod[tid] = my_mod;
-    const int anyq = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
+    __syncthreads();
+    const int anyq = anyq0;
     if (anyq) {
         const int qrow = wave * 16 + i;                           // the lane's query row inside the block
         const int mq = s_mod[qrow];
