@@ -391,9 +391,9 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
 
 
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
-# PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
+# PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
 # in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), never a constant in here.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def pmc_traffic_per_launch(T, launches_per_layer):
@@ -927,12 +927,28 @@ def main():
         # the dominant kernel: the largest entry point of a pass that is ONE kernel launch
         # (moka_up_fwd -> moka_yt_kernel<RP> for the batched launches, moka_expand_kernel<.., true> for single projections; grouped units
         #  run their members in one launch, grid z)
-        single = {"moka_up_fwd": ("moka_yx_kernel<%d> (moka_up_fwd_fused: interaction + up-projection)" % _lib.rank_pad(args.rank)) if args.fused
-                  else "moka_yt_kernel<RP> / moka_expand_kernel<RP,NQ,true> (moka_up_fwd)"}
+        # the dominant KERNEL: every launch of moka_up_fwd is moka_yx_kernel<RP> where the whole stack runs the fused forward (the headline);
+        # otherwise the entry point is served by several kernels and the line names them
+        RPk = _lib.rank_pad(args.rank)
+        all_fused = all(u.fused for u in units_all)
+        any_fused = any(u.fused for u in units_all)
+        kern_name = ("moka_yx_kernel<%d>" % RPk) if all_fused else (
+            ("moka_yx_kernel<%d> (units %s) + " % (RPk, ", ".join(sorted({u.label for u in units_all if u.fused}))) if any_fused else "") +
+            "moka_yt_kernel<%d> / moka_expand_kernel<%d,NQ,true> (three-launch units)" % (RPk, RPk))
         dom = "moka_up_fwd"
         dom_bytes = byt[dom]
         dom_avg_ms = tot[dom] / cnt[dom]
         achieved = dom_bytes / cnt[dom] / (dom_avg_ms * 1e-3) / 1e9
+        # the bytes THIS implementation has to move per step (grouped x / dx counted once per group, the deferred dA's second read of x
+        # counted; rank-space tensors and weights left out as in the contract figure): forward x + y read-modify-write, backward gy +
+        # dx read-modify-write + x again
+        per_layer = wl["units_per_layer"]
+        actual_b = 0
+        for u in units_all[:per_layer]:
+            sdo = sum(u.d_outs)
+            actual_b += E * T * (u.d_in + 2 * sdo) + E * T * (sdo + 2 * u.d_in + u.d_in)
+        actual_b *= args.layers
+        actual_gbs = actual_b / (ms_per_step * 1e-3) / 1e9
         traffic, traffic_src = None, None
         if not args.no_traffic and (args.model, args.rank, args.variant) == ("7b", 16, "avt") and not args.no_group:
             # (the PMC passes profile the headline workload; per launch = per layer / the layer's up-projection launches)
@@ -973,7 +989,11 @@ def main():
             "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority, "optimizer_in_backward": bool(opt_in_bwd),
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
-            "roofline": {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # what the bus really carries: this implementation's own bytes (x / dx of a group once, x a second time for the deferred dA)
+            "adapter_actual_bytes_per_step": int(actual_b), "adapter_actual_GBps_per_gpu": round(actual_gbs, 1),
+            "adapter_actual_hbm_frac": round(actual_gbs / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": kern_name, "entry_point": "moka_up_fwd_fused" if all_fused else "moka_up_fwd",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(dom_bytes / cnt[dom]),
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches_timed": cnt[dom],
@@ -988,13 +1008,20 @@ def main():
             out["end_to_end"] = end_to_end(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        # (written straight to file descriptor 1: with a process group initialised, a buffered sys.stdout lost the line on some boxes)
-        sys.stdout.flush()
-        os.write(1, (json.dumps(out) + "\n").encode())
+        final_line = json.dumps(out)
     if world > 1:
         dist.barrier()
     if comm:
         dist.destroy_process_group()
+    if rank == 0 and out is not None:
+        # the ONE JSON line, as the last thing on stdout: RCCL writes its version banner through C stdio, which is flushed at exit --
+        # behind a line printed from Python -- so C stdio is flushed first and the line goes straight to file descriptor 1
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.write(1, (final_line + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -5,8 +5,8 @@ values in KiB per dispatch, FETCH_SIZE doubled (gfx950 reports half of the bytes
 
     python tools/pmc_traffic.py <fetch_results.db> <write_results.db> <layers> <T> > profiles/rNN_pmc_traffic.json
 
-Sums the corrected bytes of every dispatch of `moka_yt_kernel<..>` / `moka_expand_kernel<.., true, ..>` (the y += hp Bw^T kernels behind
-moka_up_fwd) and divides by the number of decoder layers the profiled run covered: bench.py turns that into bytes per
+Sums the corrected bytes of every dispatch of `moka_yx_kernel<..>` (and `moka_yt_kernel<..>` / `moka_expand_kernel<.., true, ..>`: the y += hp Bw^T
+kernels behind moka_up_fwd / moka_up_fwd_fused) and divides by the number of decoder layers the profiled run covered: bench.py turns that into bytes per
 launch (a layer has 4 up-projection launches: q+k+v, o, gate+up, down) next to its algorithmic figure."""
 import json
 import re
@@ -28,14 +28,14 @@ def total(path, counter, pattern):
 
 
 def main(fetch_db, write_db, layers, T, launches_per_layer=4):
-    pat = r"moka_expand_kernel<\d+, \d+, true|moka_yt_kernel<"          # the two forms of the y += hp Bw^T pass (column- / token-owning)
+    pat = r"moka_expand_kernel<\d+, \d+, true|moka_yt_kernel<|moka_yx_kernel<"          # the forms of the y += hp Bw^T pass (column- / token-owning / fused with the interaction)
     fb, fn, fg = total(fetch_db, "FETCH_SIZE", pat)
     wb, wn, wg = total(write_db, "WRITE_SIZE", pat)
     assert fn == wn and fn > 0 and fn % (layers * launches_per_layer) == 0, (fn, wn)
     passes = fn // (layers * launches_per_layer)          # forward passes the profiled run made (warm-up, timed, bracketed extras)
     per_layer = (2.0 * fb + wb) / (layers * passes)
     print(json.dumps({
-        "kernel": "moka_yt_kernel<RP> / moka_expand_kernel<RP,NQ,true> (moka_up_fwd)",
+        "kernel": "moka_yx_kernel<RP> (moka_up_fwd_fused; moka_yt_kernel / moka_expand_kernel<RP,NQ,true> where a unit runs the three-launch forward)",
         "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py; FETCH_SIZE x 2 "
                   "(gfx950 unit correction of MI355X_MICROARCH.md) + WRITE_SIZE; summed over the launches of one decoder layer",
         "tokens": T, "layers_profiled": layers, "forward_passes_profiled": passes, "dispatches": fn,

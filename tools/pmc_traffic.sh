@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 LAYERS=4
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pmcF /tmp/pmcW
+rm -rf /tmp/pmcF /tmp/pmcW /tmp/pmc[0-9]*
 # --graph off --steps 1 --warmup 1: 2 optimizer steps + the extra bracketed passes; every pass runs the forward once per layer
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcF -o f -- python $REPO/bench.py --layers $LAYERS --steps 1 --warmup 1 --graph off --no-cpu-baseline --no-traffic > $OUT/runF.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcW -o w -- python $REPO/bench.py --layers $LAYERS --steps 1 --warmup 1 --graph off --no-cpu-baseline --no-traffic > $OUT/runW.log 2>&1
