@@ -74,6 +74,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the fix; the guard stays as a belt-and-braces measure because it is free (A/B on one box: 35.67 / 35.61 ms with, 35.59 / 35.65 ms
 // without) -- 32 wait states cover even an 8-pass MFMA; the accumulator is an operand so the instruction cannot be moved across.
 #define MFMA_SETTLE(acc) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc))
+// loads of the read-modify-write streams (y, dx): touched once per kernel
+#ifdef MOKA_NT_RMW
+#define STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define STREAM_LOAD(p) (*(p))
+#endif
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -211,8 +217,13 @@ static __device__ __forceinline__ const unsigned short* kmj_frag(const unsigned 
 // like a load, but the compiler does not see it: kernels that use it wait by explicit count.
 static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
     unsigned keep;
+#ifdef MOKA_NT_GLDS
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+#endif
 }
 
 static __device__ __forceinline__ float mod_scale(const float* s_mod, int m) {
@@ -1064,7 +1075,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         const unsigned char* orow = a.out + ((size_t)t * a.C + c_wave + 8 * g) * 2;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (FAST || c_wave + 32 * q < a.C) R.o[q] = *(const bf16x8*)(orow + 64 * q);   // wave-uniform condition
+            if (FAST || c_wave + 32 * q < a.C) R.o[q] = STREAM_LOAD((const bf16x8*)(orow + 64 * q));   // wave-uniform condition
     };
 
     auto process = [&](Tile& R, int tile, Tile& N, int next_tile) {
@@ -1618,7 +1629,7 @@ __global__ void __launch_bounds__(512, YX_MINW) moka_yx_kernel(const YxBatch fb,
     auto issue_o = [&](bf16x8 (&o)[NQ], int ch_) {
         const int cb = min(ch_, ch1 - 1) * CWK;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
+        for (int q = 0; q < NQ; ++q) o[q] = STREAM_LOAD((const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2));
     };
     issue_o(oA, ch0);                                                        // HBM first: its latency covers the prologue below
 
@@ -3204,9 +3215,13 @@ __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_ker
 // ONEW: one weight set for every modality (the gy pass of the backward: x = gy, A[0][0] = Bw^T, s_mod = s_out): one slot, no second walk.
 // G > 1: G projections that read the same x (q/k/v, gate/up), each through its own dropout mask, in ONE pass over x: G weight sets in
 // one modality slot (G x 32 KB), a walk per modality of the run.
+// blockIdx.z selects one of up to MOKA_MAX_GROUP independent problems of one token count (the g passes of a q/k/v or gate/up group in
+// ONE launch: 13B r = 64, seven launches per layer -> four; a member with fewer slices than the grid has writes zeros into the rest).
+struct XaBatch { XaArgs z[MOKA_MAX_GROUP]; };
 template <int RP, bool ONEW, int G>
-__global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaArgs a, int cps) {
+__global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaBatch ab, int cps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const XaArgs& a = ab.z[blockIdx.z];
     constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK, NSLOT = (ONEW || G > 1) ? 1 : 2;
     constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality slot, rank tile)
     static_assert(NU == 2, "a chunk streams in two units");
@@ -4027,22 +4042,21 @@ static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) 
             // the chunk-walk kernel of the forward with one weight set (moka_xwm_kernel<64, true, 1>): a launch per projection
             const int T = gb.z[0].T;
             const int kw = bwd_kw(T, Cmax, gb.z[0].r), ks = (Cmax + kw - 1) / kw;
+            XaBatch xb;
+            memset(&xb, 0, sizeof(xb));
             for (int z = 0; z < nz; ++z) {
                 const GyArgs& ga = gb.z[z];
-                XaArgs xa;
-                memset(&xa, 0, sizeof(xa));
+                XaArgs& xa = xb.z[z];
                 xa.x = ga.gy; xa.tok_mod = ga.tok_mod; xa.T = T; xa.C = ga.C; xa.r = ga.r; xa.M = ga.M;
                 xa.part[0] = ga.g_part;
                 xa.drop[0].inv_keep = 1.f;
                 for (int m = 0; m < MOKA_MAX_MOD; ++m) { xa.s_mod[m] = ga.s_mod[m]; xa.A[0][m] = ga.BwT; }
-                const int ksg = (ga.C + kw - 1) / kw;
-                // (a narrower member of a group leaves its upper slices zero: the interaction backward sums ks slices for every member)
-                if (ksg < ks && hipMemsetAsync(ga.g_part + (size_t)ksg * T * 64, 0, (size_t)(ks - ksg) * T * 64 * 4, st) != hipSuccess)
-                    return fail(MOKA_ELAUNCH, "moka_up_bwd: memset");
-                const size_t lds = (size_t)4 * 8 * 1024;
-                ensure_lds((const void*)moka_xwm_kernel<64, true, 1>, lds);
-                hipLaunchKernelGGL((moka_xwm_kernel<64, true, 1>), dim3(ksg, (T + 127) / 128), dim3(512), lds, st, xa, kw / 256);
             }
+            // ONE launch for the group (grid z): a narrower member's workgroups beyond its own slices find no chunk to walk and write zeros
+            // (the interaction backward sums ks slices for every member)
+            const size_t lds = (size_t)4 * 8 * 1024;
+            ensure_lds((const void*)moka_xwm_kernel<64, true, 1>, lds);
+            hipLaunchKernelGGL((moka_xwm_kernel<64, true, 1>), dim3(ks, (T + 127) / 128, nz), dim3(512), lds, st, xb, kw / 256);
             return check_launch("moka_xwm_kernel");
         }
         // rank pad 64: 128 columns per wave, one split-K slice per 1024 columns (bwd_kw): the rank-space backward reads half as many
@@ -4339,18 +4353,21 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             else {
                 const int kw = fwd_kw(T, d_in, r);
                 const dim3 grid((d_in + kw - 1) / kw, (T + 127) / 128);
+                XaBatch xb;
+                memset(&xb, 0, sizeof(xb));
+                xb.z[0] = xa;
                 if (per_launch == 1) {
                     const size_t lds = (size_t)2 * 4 * 8 * 1024;
                     ensure_lds((const void*)moka_xwm_kernel<64, false, 1>, lds);
-                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 1>), grid, dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 1>), grid, dim3(512), lds, (hipStream_t)stream, xb, kw / 256);
                 } else if (per_launch == 2) {
                     const size_t lds = (size_t)2 * 4 * 8 * 1024;
                     ensure_lds((const void*)moka_xwm_kernel<64, false, 2>, lds);
-                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 2>), grid, dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 2>), grid, dim3(512), lds, (hipStream_t)stream, xb, kw / 256);
                 } else {
                     const size_t lds = (size_t)3 * 4 * 8 * 1024;
                     ensure_lds((const void*)moka_xwm_kernel<64, false, 3>, lds);
-                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 3>), grid, dim3(512), lds, (hipStream_t)stream, xa, kw / 256);
+                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 3>), grid, dim3(512), lds, (hipStream_t)stream, xb, kw / 256);
                 }
                 rc = check_launch("moka_xwm_kernel");
             }
