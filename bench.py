@@ -772,6 +772,8 @@ def main():
                     run_backward(lib, ch, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
             torch.cuda.synchronize()
             if args.graph == "all":
+                # (collectives cannot ride inside the graph: capturing the one-rank RCCL all-reduce with torch 2.10 / RCCL 2.26.6 segfaults at
+                #  capture time -- measured round 4 -- so N > 1 and --force-comm use one graph per gradient bucket with the hooks between them)
                 assert not comm, "--graph all: single GPU without collectives only"
                 fwd_bwd_graph = torch.cuda.CUDAGraph()
                 branch = [torch.cuda.Stream(device=dev) for _ in range(args.chains - 1)]
