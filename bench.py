@@ -351,12 +351,19 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
     sps = c_void_p(side.cuda_stream)
     done = {}                                                    # layer -> event "its deferred dA launches have finished" (side mode)
     for l in range(n_layers - 1, lo - 1, -1):
-        if mode == "side" and (l + 2) in done:
+        if mode in ("side", "window") and (l + 2) in done:
             main.wait_event(done.pop(l + 2))                     # layer l reuses the pack buffers of layer l + 2
+        pending = None
         for u in reversed(units[l * per:(l + 1) * per]):
             _call(lib, up, u, sp, rec)
+            if mode == "window" and pending is not None:
+                # the dA of the unit before goes out HERE, so that it starts with this unit's rank-space backward -- the two launches of
+                # the chain that leave the memory system idle (a unit's dA moves about as many bytes as that window could)
+                side.wait_stream(main)
+                _call(lib, "moka_down_bwd:dA", pending, sps, None)
             _call(lib, "moka_cross_bwd", u, sp, rec)
             _call(lib, "moka_down_bwd:dx", u, sp, None)
+            pending = u
         if mode == "main":
             for u in reversed(units[l * per:(l + 1) * per]):
                 if split_db:
@@ -367,8 +374,10 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
             for u in reversed(units[l * per:(l + 1) * per]):
                 if split_db:
                     _call(lib, "moka_up_bwd:dB", u, sps, None)
+                if mode == "window" and u is not pending:
+                    continue                                        # (already out, beside the next unit's rank-space backward)
                 _call(lib, "moka_down_bwd:dA", u, sps, None)
-            if bucket_opt is not None and mode == "side":
+            if bucket_opt is not None and mode in ("side", "window"):
                 # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the
                 # update of the finished layers overlaps the backward of the earlier ones (FlatAdamW.step_range, coefficients in device memory)
                 opt_, bucket_, scale_ = bucket_opt
@@ -383,10 +392,10 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
             ev.record(side)
             done[l] = ev
         if on_layer_done is not None:
-            if mode == "side":
+            if mode in ("side", "window"):
                 main.wait_event(done[l])                         # (a bucket must not ship before its dA has landed)
             on_layer_done(l)
-    if mode == "side":
+    if mode in ("side", "window"):
         main.wait_stream(side)
 
 
@@ -622,11 +631,13 @@ def main():
                          "are independent, and the fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide "
                          "behind the streaming kernels of the other.  Single GPU with --graph all only; per-kernel durations (`roofline`, "
                          "`kernels`) are then taken with the chains back to back on one stream")
-    ap.add_argument("--defer-da", choices=("off", "main", "side"), default="side",
+    ap.add_argument("--defer-da", choices=("off", "main", "side", "window"), default="side",
                     help="the dA_m halves of moka_down_bwd are needed by the optimizer only: side (default, what moka_amd.parallel.attach does) = "
                          "a layer's worth of them is enqueued on a second stream when the layer's chain is, and runs beside the next layer's chain "
                          "(joined before a gradient bucket ships and before the optimizer step); main = the same launches on the one stream; "
-                         "off = dA_m and dx from one moka_down_bwd call inside the chain")
+                         "off = dA_m and dx from one moka_down_bwd call inside the chain; window = a unit's dA_m forked behind the NEXT unit's pass over gy, "
+                         "so that it starts with that unit's rank-space backward, the window in which the chain leaves the memory system idle (live "
+                         "launches: 35.96 -> 35.16 ms; inside the hipGraph a fork per unit makes the replay host-bound: 51 ms -- an experiment, not a default)")
     ap.add_argument("--opt-in-backward", choices=("on", "off"), default="on",
                     help="the fused AdamW step per gradient bucket inside the backward (behind the bucket's deferred dA / its all-reduce) instead of one launch behind it")
     ap.add_argument("--chain-priority", choices=("auto", "high", "normal"), default="auto",
@@ -730,7 +741,7 @@ def main():
     # the optimizer step per gradient bucket INSIDE the backward (off: one launch behind it): needs the side stream of the deferred dA_m
     # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and args.chains == 1 and
-                  ((not comm and args.defer_da == "side" and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
+                  ((not comm and args.defer_da in ("side", "window") and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
     shadows_main = bool(args.fused and args.shadows == "main")
