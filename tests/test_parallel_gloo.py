@@ -287,3 +287,92 @@ def test_sample_sharding_mean_of_rank_gradients_is_the_full_batch_gradient(comm_
     res = [q.get(timeout=5) for _ in range(2)]
     tol = 2e-2 if comm_bf16 else 1e-6
     assert all(err <= tol for _, err in res), res
+
+
+def _force_comm_worker(port, q):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    from moka_amd.parallel import FlatGradBucket
+    ends = [40, 100, 164, 200]
+    plain = FlatGradBucket(200, ends, "cpu", n_buckets=2)
+    forced = FlatGradBucket(200, ends, "cpu", n_buckets=2, force_comm=True)
+    calls = []
+    forced.on_reduced = lambda lo, hi: calls.append((lo, hi))       # (CPU: on_reduced is a CUDA-stream feature; must stay unused here)
+    g = torch.randn(200, generator=torch.Generator().manual_seed(1))
+    out = []
+    for b in (plain, forced):
+        b.flat.copy_(g)
+        for l in range(3, -1, -1):
+            b.layer_done(l)
+        pending = len(b._pending)
+        b.finish(average=True)
+        out.append((b.comm, b.world, pending, b.flat.clone()))
+    dist.destroy_process_group()
+    q.put([(c, w, p, t.numpy()) for c, w, p, t in out])
+
+
+def test_force_comm_runs_the_collectives_in_a_group_of_one_rank():
+    """FlatGradBucket(force_comm=True): a process group of ONE rank still ships every bucket through dist.all_reduce (the sum over one
+    rank is the identity, the average divides by one) -- the switch that lets the N > 1 communication path run on one device."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_comm_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    (c0, w0, p0, t0), (c1, w1, p1, t1) = res
+    assert (c0, w0, p0) == (False, 1, 0) and (c1, w1, p1) == (True, 1, 2)      # two buckets of two layers were really shipped
+    assert (t0 == t1).all()
+
+
+def test_force_comm_needs_a_process_group():
+    from moka_amd.parallel import FlatGradBucket
+    with pytest.raises(RuntimeError):
+        FlatGradBucket(8, [8], "cpu", force_comm=True)
+
+
+def test_flat_adamw_segments_follow_the_no_decay_ranges():
+    """FlatAdamW._segments: a range of the flat buffers cut at the boundaries of the no-decay ranges (biases / norm weights), in order."""
+    from moka_amd.parallel import FlatAdamW
+    m, g = torch.zeros(64), torch.zeros(64)
+    opt = FlatAdamW(m, g, None, lr=1e-3, weight_decay=0.1)
+    assert list(opt._segments(0, 64)) == [(0, 64, True)]
+    opt.no_decay_ranges = [(8, 16), (32, 40)]
+    assert list(opt._segments(0, 64)) == [(0, 8, True), (8, 16, False), (16, 32, True), (32, 40, False), (40, 64, True)]
+    assert list(opt._segments(12, 36)) == [(12, 16, False), (16, 32, True), (32, 36, False)]
+    assert list(opt._segments(16, 32)) == [(16, 32, True)]
+    assert list(opt._segments(8, 16)) == [(8, 16, False)]
+    pulled = []
+    opt.hyper = lambda: (pulled.append(1), dict(lr=5e-2, betas=(0.8, 0.9), eps=1e-6, weight_decay=0.0))[1]
+    opt._pull_hyper()
+    assert (opt.lr, opt.betas, opt.eps, opt.weight_decay) == (5e-2, (0.8, 0.9), 1e-6, 0.0) and pulled == [1]
+
+
+def test_attach_marks_biases_and_norm_weights_as_no_decay_on_cpu():
+    """attach(no_decay="hf"): the ranges of the flat buffers that belong to biases / normalisation layers (HF Trainer's rule)."""
+    from moka_amd.parallel import attach
+
+    class Proj(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(8, 8, bias=True)
+            self.norm = torch.nn.LayerNorm(8)
+
+        def forward(self, x):
+            return self.norm(self.fc(x))
+
+    model = Proj().to(torch.bfloat16)
+    dp = attach(model, optimizer=True, lr=1e-3, weight_decay=0.1, defer_dA=False)
+    by = dict(zip(dp.names, zip(dp.offsets, dp.sizes)))
+    want = sorted((o, o + (sz + 7) // 8 * 8) for n, (o, sz) in by.items() if n != "fc.weight")
+    merged = []
+    for lo, hi in want:
+        if merged and merged[-1][1] == lo:
+            merged[-1] = (merged[-1][0], hi)
+        else:
+            merged.append((lo, hi))
+    assert dp.optimizer.no_decay_ranges == merged
+    o, sz = by["fc.weight"]
+    assert all(not (lo <= o < hi) for lo, hi in dp.optimizer.no_decay_ranges)
+    assert attach(Proj().to(torch.bfloat16), weight_decay=0.1, defer_dA=False, no_decay=None).optimizer.no_decay_ranges == []
