@@ -115,7 +115,7 @@ int         moka_device_check(void);
 
 /* Diagnostics build only (-DMOKA_DIAGNOSTICS: `python -m moka_amd.build --diag` -> libmoka_hip_diag.so, loaded through
  * MOKA_HIP_LIB): override a launch heuristic ("expand_bpc", "expand_depth", "expand_nq", "wgrad_nw", "wgrad_ct", "wgrad_bpc",
- * "gy_ng", "xa_ng", "xa_form"; value 0 restores the default).  Results never depend on it (set "xa_form" before sizing `part`:
+ * "gy_ng", "xa_ng", "xa_form", "g32_fwd", "g32_dx", "g32_da"; value 0 restores the default).  Results never depend on it (set "xa_form" before sizing `part`:
  * moka_ksplit() follows it).  This is process-wide mutable state, which is why the PRODUCT library does not have it: there
  * moka_tune() returns MOKA_EINVAL and moka_diagnostics() returns 0. */
 int moka_tune(const char* key, int value);
@@ -125,7 +125,7 @@ int moka_diagnostics(void);
 int moka_rank_pad(int r);
 /* Token count rounded up to the pack granularity (32). */
 int moka_tok_pad(int T);
-/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C = d_in (one per 512 columns; rank pad 64: a whole
+/* Number of split-K partial slices moka_down_fwd writes for T tokens of width C = d_in (one per 512 columns; rank pads 32 / 64: a whole
  * number of 256-column chunks per slice, chosen from T and the device's CU count so that the launch fills the chip -- at most one
  * per 256 columns, so C / 256 rounded up is an upper bound for any T).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);

@@ -3609,9 +3609,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0;
+static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0;
 #else
-static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0;
+static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -3806,7 +3806,7 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         else if (g_tune_expand_nq == 3) launch_expand_t<64, 2, false, 1, 2>(ab, nz, st);            // the per-tile form (A/B)
         // (the token-owning form of the groups, moka_dxg_kernel<1>, loses for a single projection: dx + dA of o / down 97 / 227 -> 109 / 253 us)
         else launch_expand_t<64, 4, false, 1, 2, true>(ab, nz, st);
-    } else if (RP == 64) {                               // projections sharing dx at rank pad 64: the token-owning form (moka_dxg_kernel)
+    } else if (RP == 64 || RP == 32) {                   // projections sharing dx at rank pads 32 / 64: the token-owning form (moka_dxg_kernel)
         const int T = ab.z[0].T, C = ab.z[0].C;
         const int nch = (C + 127) / 128, ntb = (T + 127) / 128;
         // column ranges: three workgroups per CU, one resident (13B widths, dx + dA per pass with 1 / 2 / 3 / 4 / 6: 29.4 / 28.3 / 27.7 / 28.1 / 28.4 ms; per-projection passes: 30.7)
@@ -3814,13 +3814,12 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         want = want < 1 ? 1 : (want > nch ? nch : want);
         const int cpb = (nch + want - 1) / want;
         const dim3 grid((nch + cpb - 1) / cpb, ntb);
-        if (nz == 2) {
-            ensure_lds((const void*)moka_dxg_kernel<64, 2>, (size_t)2 * 16 * 1024);
-            hipLaunchKernelGGL((moka_dxg_kernel<64, 2>), grid, dim3(512), (size_t)2 * 16 * 1024, st, ab, cpb);
-        } else {
-            ensure_lds((const void*)moka_dxg_kernel<64, 3>, (size_t)3 * 16 * 1024);
-            hipLaunchKernelGGL((moka_dxg_kernel<64, 3>), grid, dim3(512), (size_t)3 * 16 * 1024, st, ab, cpb);
-        }
+        auto go = [&](auto kernel, size_t lds) {
+            ensure_lds((const void*)kernel, lds);
+            hipLaunchKernelGGL(kernel, grid, dim3(512), lds, st, ab, cpb);
+        };
+        if (RP == 64) { if (nz == 2) go(moka_dxg_kernel<64, 2>, (size_t)2 * 16 * 1024); else go(moka_dxg_kernel<64, 3>, (size_t)3 * 16 * 1024); }
+        else          { if (nz == 2) go(moka_dxg_kernel<32, 2>, (size_t)2 * 8 * 1024); else go(moka_dxg_kernel<32, 3>, (size_t)3 * 8 * 1024); }
         return check_launch("moka_dxg_kernel");
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
         // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass;
@@ -3925,9 +3924,12 @@ static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
             else if (g_tune_wgrad_nw == 4 || (g_tune_wgrad_nw == 0 && !OUT_CK && ab.z[0].C > 8192)) launch_wgrad_t<16, 1, 4, OUT_CK, 1>(ab, nz, st);   // measured at C = 11008: 56 vs 60 us
             else launch_wgrad_t<16, 1, 8, OUT_CK, 1>(ab, nz, st);
         } else launch_wgrad_t<32, 1, 8, OUT_CK, 1>(ab, nz, st);
-    } else {                                             // can_group(): RP == 16
+    } else if (RP == 16) {                               // can_group()
         if (nz == 2) launch_wgrad_t<16, 1, 4, false, 2>(ab, nz, st);
         else launch_wgrad_t<16, 1, 4, false, 3>(ab, nz, st);
+    } else {                                             // rank pad 32: 240 registers, two waves per SIMD: three sets of two waves
+        if (nz == 2) launch_wgrad_t<32, 1, 4, false, 2>(ab, nz, st);
+        else launch_wgrad_t<32, 1, 2, false, 3>(ab, nz, st);
     }
     return check_launch("moka_wgrad_kernel");
 }
@@ -4159,6 +4161,27 @@ static int launch_xa(const XaArgs& a, hipStream_t st) {
     return check_launch("moka_xa_kernel");
 }
 
+// the chunk-walk kernel (rank pads 32 / 64): G projections that read the same x in one launch, one split-K slice per kw columns
+template <int RP>
+static int launch_xwm(const XaArgs& xa, int G, int kw, hipStream_t st) {
+    const dim3 grid((xa.C + kw - 1) / kw, (xa.T + 127) / 128);
+    XaBatch xb;
+    memset(&xb, 0, sizeof(xb));
+    xb.z[0] = xa;
+    constexpr size_t slot = (size_t)(RP / 16) * 8 * 1024;       // one (modality slot, projection): RP/16 rank tiles x 8 K steps x 1 KB
+    if (G == 1) {
+        ensure_lds((const void*)moka_xwm_kernel<RP, false, 1>, 2 * slot);
+        hipLaunchKernelGGL((moka_xwm_kernel<RP, false, 1>), grid, dim3(512), 2 * slot, st, xb, kw / 256);
+    } else if (G == 2) {
+        ensure_lds((const void*)moka_xwm_kernel<RP, false, 2>, 2 * slot);
+        hipLaunchKernelGGL((moka_xwm_kernel<RP, false, 2>), grid, dim3(512), 2 * slot, st, xb, kw / 256);
+    } else {
+        ensure_lds((const void*)moka_xwm_kernel<RP, false, 3>, 3 * slot);
+        hipLaunchKernelGGL((moka_xwm_kernel<RP, false, 3>), grid, dim3(512), 3 * slot, st, xb, kw / 256);
+    }
+    return check_launch("moka_xwm_kernel");
+}
+
 // number of part slices moka_down_fwd writes for input width C
 // which form of the down-projection runs: the weights-in-registers form for r <= 16 (q/k/v and gate/up as one launch), the
 // independent-wave form with the weights staged in LDS for the wider ranks (measured at 13B widths, r = 64, seq 4096: 21.5 -> 13.8 ms
@@ -4167,7 +4190,7 @@ static bool use_xw(int RP) { return g_tune_xa_form == 2 || ((g_tune_xa_form == 0
 // columns per split-K slice of the forward: 512; rank pad 64: a whole number of 256-column chunks, as few slices as still give every CU a
 // workgroup of 128 tokens (moka_xwm_kernel)
 static int fwd_kw(int T, int C, int r) {
-    if (!(use_xw(rank_pad(r)) && rank_pad(r) == 64)) return 512;
+    if (!(use_xw(rank_pad(r)) && (rank_pad(r) == 64 || (rank_pad(r) == 32 && g_tune_g32_fwd == 0)))) return 512;
     if (g_tune_xa_form == 3) return 256;                                  // one chunk per slice (the first form of the kernel, A/B)
     const int nch = (C + 255) / 256, ntb = (T + 127) / 128;
     // three workgroups per CU (two resident): 13B widths, 8192 tokens: 13.2 / 12.7 / 11.1 / 11.2 ms per forward pass with 1 / 2 / 3 / 4
@@ -4261,6 +4284,9 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "yx_bpc")) g_tune_yx_bpc = value;
     else if (!strcmp(key, "yx_cpb")) g_tune_yx_cpb = value;
     else if (!strcmp(key, "yx_dbg")) g_tune_yx_dbg = value;
+    else if (!strcmp(key, "g32_fwd")) g_tune_g32_fwd = value;
+    else if (!strcmp(key, "g32_dx")) g_tune_g32_dx = value;
+    else if (!strcmp(key, "g32_da")) g_tune_g32_da = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 #else
@@ -4334,9 +4360,11 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
     }
     const int RP = rank_pad(r);
     // r <= 16: the weights of all modalities (and of all G projections) are resident per wave -> one launch for the group;
-    // rank pad 32: one launch per projection.  One split-K slice per 512 columns (rank pad 64: fwd_kw).
+    // One split-K slice per 512 columns (rank pads 32 / 64: fwd_kw).
     // rank pad 64: the chunk-walk kernel takes the whole group too (13B widths: x.A^T 11.05 -> 9.6 ms per pass: q/k/v 3 x 28 -> 70 us)
-    const int per_launch = (RP == 16 || (RP == 64 && use_xw(64) && g_tune_xa_form != 3)) ? G : 1;
+    // rank pad 32: the same chunk-walk kernel (7B widths, r = 32: x.A^T 7.33 -> 5.88 ms per pass; "g32_fwd" 1: moka_xw_kernel, one launch per projection)
+    const bool xwm32 = RP == 32 && use_xw(32) && g_tune_g32_fwd != 1;
+    const int per_launch = (RP == 16 || (RP == 64 && use_xw(64) && g_tune_xa_form != 3) || xwm32) ? G : 1;
     for (int g0 = 0; g0 < G; g0 += per_launch) {
         XaArgs xa;
         memset(&xa, 0, sizeof(xa));
@@ -4348,29 +4376,10 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
         }
         if (use_xw(RP)) {                                    // independent waves, weights staged in LDS
             if (RP == 16) rc = G == 1 ? launch_xw<16, 1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xw<16, 2>(xa, (hipStream_t)stream) : launch_xw<16, 3>(xa, (hipStream_t)stream));
-            else if (RP == 32) rc = launch_xw<32, 1>(xa, (hipStream_t)stream);
-            else if (fwd_kw(T, d_in, r) == 256 && g_tune_xa_form == 3) rc = launch_xw<64, 1>(xa, (hipStream_t)stream);
-            else {
-                const int kw = fwd_kw(T, d_in, r);
-                const dim3 grid((d_in + kw - 1) / kw, (T + 127) / 128);
-                XaBatch xb;
-                memset(&xb, 0, sizeof(xb));
-                xb.z[0] = xa;
-                if (per_launch == 1) {
-                    const size_t lds = (size_t)2 * 4 * 8 * 1024;
-                    ensure_lds((const void*)moka_xwm_kernel<64, false, 1>, lds);
-                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 1>), grid, dim3(512), lds, (hipStream_t)stream, xb, kw / 256);
-                } else if (per_launch == 2) {
-                    const size_t lds = (size_t)2 * 4 * 8 * 1024;
-                    ensure_lds((const void*)moka_xwm_kernel<64, false, 2>, lds);
-                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 2>), grid, dim3(512), lds, (hipStream_t)stream, xb, kw / 256);
-                } else {
-                    const size_t lds = (size_t)3 * 4 * 8 * 1024;
-                    ensure_lds((const void*)moka_xwm_kernel<64, false, 3>, lds);
-                    hipLaunchKernelGGL((moka_xwm_kernel<64, false, 3>), grid, dim3(512), lds, (hipStream_t)stream, xb, kw / 256);
-                }
-                rc = check_launch("moka_xwm_kernel");
-            }
+            else if (RP == 32 && !xwm32) rc = launch_xw<32, 1>(xa, (hipStream_t)stream);
+            else if (RP == 64 && fwd_kw(T, d_in, r) == 256 && g_tune_xa_form == 3) rc = launch_xw<64, 1>(xa, (hipStream_t)stream);
+            else if (RP == 32) rc = launch_xwm<32>(xa, per_launch, fwd_kw(T, d_in, r), (hipStream_t)stream);
+            else rc = launch_xwm<64>(xa, per_launch, fwd_kw(T, d_in, r), (hipStream_t)stream);
         } else
         if (RP == 16 && (T & 15) == 0 && g_tune_xa_form != 1)    // LDS-DMA ring (whole 16-token tiles; "xa_form" 1 forces the first form)
             rc = G == 1 ? launch_xs<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xs<2>(xa, (hipStream_t)stream) : launch_xs<3>(xa, (hipStream_t)stream));
@@ -4762,7 +4771,9 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
             }
             ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in; ga.r = r; ga.M = M; ga.per_mod = 1; ga.drop = drop[g];
         }
-        if (fused) {
+        // (rank pad 32: G sets of waves on one x tile lose to G launches -- 240 registers, one 6- or 8-wave workgroup per CU: dx + dA 14.6 -> 14.9 ms
+        //  per pass at the 7B widths; "g32_da" 2 runs them)
+        if (fused || (RP == 32 && G > 1 && g_tune_g32_da == 2)) {
             rc = launch_wgrad<false>(gb, G, RP, (hipStream_t)stream);
             if (rc) return rc;
         } else {
@@ -4787,7 +4798,7 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
             a.T = T; a.C = d_in; a.r = r; a.M = M; a.drop = drop[g];
         }
         // rank pad 64: the group's dx terms in one pass over dx too (moka_dxg_kernel; "dx_group" 1: one pass per projection)
-        if (fused || (RP == 64 && G > 1 && g_tune_dx_group != 1)) {
+        if (fused || (RP == 64 && G > 1 && g_tune_dx_group != 1) || (RP == 32 && G > 1 && g_tune_g32_dx != 1)) {
             rc = launch_expand<false>(eb, G, RP, (hipStream_t)stream);
         } else {
             for (int g = 0; g < G && !rc; ++g) {

@@ -551,6 +551,10 @@ def _group_data(variant, B, S, d_in, d_outs, r, seed, layouts=None):
     dict(variant="avt", B=1, S=1024, d_in=1024, d_outs=(1024, 512), r=64, p=0.1),            # r > 16: per-projection fallback
     dict(variant="avt", B=3, S=700, d_in=1376, d_outs=(352, 96, 1376), r=16, p=0.1),         # ragged: T % 32 != 0, widths % 64 != 0, % 512 != 0
     dict(variant="vt", B=2, S=333, d_in=11008, d_outs=(4096, 160), r=8, p=0.05),             # 11008-wide input, r < 16, odd T
+    dict(variant="avt", B=2, S=2048, d_in=4096, d_outs=(4096, 4096, 4096), r=32, p=0.05),    # rank pad 32: q/k/v in one pass over x / dx (round 4)
+    dict(variant="avt", B=1, S=2048, d_in=4096, d_outs=(11008, 11008), r=32, p=0.05),        # rank pad 32: gate/up
+    dict(variant="vt", B=3, S=700, d_in=1376, d_outs=(352, 96, 1376), r=24, p=0.1),          # rank pad 32, r < pad, ragged everything
+    dict(variant="avt", B=2, S=333, d_in=11008, d_outs=(1024, 160), r=32, p=0.0),            # rank pad 32: 11008-wide input, odd T, no dropout
 ])
 def test_group_matches_single_projection_nodes(cfg):
     _group_vs_singles(cfg)
@@ -566,6 +570,14 @@ def _scrambled_layout(S=4096):
         left -= n
         k += 1
     return lay + [("q", 150), ("t", left - 150)]
+
+
+@pytest.mark.parametrize("d_outs", [(96, 64, 128), (160, 96)])
+def test_rank_pad_32_group_walks_chunks_with_three_modalities_per_run(d_outs):
+    """The same at rank pad 32 (round 4: moka_xwm_kernel<32, false, G>, moka_dxg_kernel<32, G>, the G-set dA kernel): all three modalities and
+    padding inside single 128-token runs."""
+    lay = _scrambled_layout()
+    _group_vs_singles(dict(variant="avt", B=2, S=4096, d_in=4096, d_outs=d_outs, r=32, p=0.1, layouts=[lay, [("t", 3)] + lay[1:]]))
 
 
 @pytest.mark.parametrize("d_outs", [(96, 64, 128), (160, 96)])
@@ -608,6 +620,14 @@ def _random_group_cfg(seed):
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_groups_match_single_projection_nodes(seed):
     _group_vs_singles(_random_group_cfg(seed))
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_groups_at_rank_pad_32(seed):
+    import random
+    cfg = _random_group_cfg(50 + seed)
+    cfg["r"] = random.Random(seed).choice([17, 24, 32, 32])
+    _group_vs_singles(cfg)
 
 
 def _group_vs_singles(cfg):
@@ -658,13 +678,14 @@ def _group_vs_singles(cfg):
     assert (xg.grad.float() - xs.grad.float()).abs().max().item() <= 2.0 ** -5 * xs.grad.float().abs().max().item(), "dx max"
 
 
-def test_group_dx_against_fp64_oracle():
+@pytest.mark.parametrize("r", [16, 32])
+def test_group_dx_against_fp64_oracle(r):
     """dx of a q/k/v group with a zero base weight (so only the adapter terms remain) against the fp64
     oracle's sum over the three projections: one bf16 rounding of the sum."""
     from moka_amd import functional as F
     dev = _dev()
     bf = torch.bfloat16
-    cds = _group_data("avt", 2, 512, 1024, (1024, 512, 1024), 16, 555)
+    cds = _group_data("avt", 2, 512, 1024, (1024, 512, 1024), r, 555)
     G = len(cds)
     spec, rt, ort = _spec_and_routing(cds[0], dev)
     c = cds[0].case
