@@ -175,7 +175,7 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
  * when asked for -- h and hp_kmj (the workgroups of the first column range write the rows they computed anyway; the bits of
  * moka_cross_fwd) -- and from moka_weight_shadows (BwT, AT: functions of the weights alone).
  * Replaces lora.py:485-530 / layer.py:627-669.
- * bf16 storage, r <= 32 (moka_up_fwd_fused_ok() == 1); otherwise MOKA_EINVAL -- use moka_cross_fwd + moka_up_fwd. */
+ * bf16 storage, r <= 64 (moka_up_fwd_fused_ok() == 1; moka_up_fwd_fused_pays() keeps the two launches at 32 < r <= 64); otherwise MOKA_EINVAL -- use moka_cross_fwd + moka_up_fwd. */
 int moka_up_fwd_fused_ok(int r, int dtype);
 /* 1 when the fused launch is expected to beat moka_cross_fwd + moka_up_fwd for this shape (a measured rule: projections of one
  * width, at most 24 slices, and a group or a projection of moderate width -- every column range of the y kernel repeats the slice

@@ -1598,7 +1598,7 @@ struct YxBatch {
 #define YX_MINW 4
 #endif
 template <int RP>
-__global__ void __launch_bounds__(512, YX_MINW) moka_yx_kernel(const YxBatch fb, int chunks_per_block) {
+__global__ void __launch_bounds__(512, RP == 64 ? 2 : YX_MINW) moka_yx_kernel(const YxBatch fb, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;   // 8 KH fragments (1 KB each) per chunk
     constexpr int PER = NF * 64 / 512;                                       // KH fragments per thread and chunk
@@ -2397,6 +2397,7 @@ struct GyBatch {
     GyArgs z[MOKA_MAX_GROUP];
     int xend[MOKA_MAX_GROUP];      // blockIdx.x < xend[z] belongs to problem z: its column blocks, plus ONE block per token run that zeroes
     int ncb_max;                   // the slices a narrower member leaves unwritten (the group's consumers read ncb_max slices of everyone)
+    int dbg;                       // diagnostics build only (timing ablation, wrong results): 1 = the dB sums are not sent to memory
 };
 
 // Block = 8 waves on a [NG*32 tokens x 512 columns] tile of gy; wave w owns columns 64w..64w+63 for the
@@ -2769,7 +2770,7 @@ __global__ void __launch_bounds__(512) moka_gs_kernel(const GyBatch ab, int NG) 
                 const int c = c0 + cb * 16 + cl;
                 if (c < a.C && kk < a.r) {
                     if (DET) a.det[((size_t)blockIdx.y * a.det_planes + zi) * a.det_stride + (size_t)c * a.r + kk] = mine[cl * RP + kk];
-                    else atomicAdd(a.dB + (size_t)c * a.r + kk, mine[cl * RP + kk]);
+                    else if (ab.dbg != 1) atomicAdd(a.dB + (size_t)c * a.r + kk, mine[cl * RP + kk]);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the next round rewrites the area)
@@ -3609,9 +3610,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0;
+static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0;
 #else
-static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0;
+static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -3912,13 +3913,14 @@ static void launch_wgrad_wide(WgradBatch& ab, int nz, hipStream_t st) {
 }
 
 // OUT_CK: nz batched problems.  !OUT_CK: nz projections sharing x (one kernel when can_group()).
+// zbatch (dA): the nz projections as independent problems of one launch (grid z) instead of wave sets that share a tile
 template <bool OUT_CK>
-static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st) {
+static int launch_wgrad(WgradBatch& ab, int nz, int RP, hipStream_t st, bool zbatch = false) {
     if (RP == 64) {
         launch_wgrad_wide<OUT_CK>(ab, nz, st);
         return check_launch("moka_wgrad_wide_kernel");
     }
-    if (OUT_CK || nz == 1) {
+    if (OUT_CK || nz == 1 || zbatch) {
         if (RP == 16) {
             if (g_tune_wgrad_ct == 2) launch_wgrad_t<16, 2, 8, OUT_CK, 1>(ab, nz, st);
             else if (g_tune_wgrad_nw == 4 || (g_tune_wgrad_nw == 0 && !OUT_CK && ab.z[0].C > 8192)) launch_wgrad_t<16, 1, 4, OUT_CK, 1>(ab, nz, st);   // measured at C = 11008: 56 vs 60 us
@@ -3990,6 +3992,7 @@ static void launch_gs_t(const GyBatch& gb, int nz, int ncb, int ng, hipStream_t 
         gx.xend[z] = xtot;
     }
     gx.ncb_max = ncb;
+    gx.dbg = g_tune_gs_dbg;
     SumRunsArgs sr;
     bool det = false;
     const int ntb_static = (ngroups + ng - 1) / ng;
@@ -4287,6 +4290,8 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "g32_fwd")) g_tune_g32_fwd = value;
     else if (!strcmp(key, "g32_dx")) g_tune_g32_dx = value;
     else if (!strcmp(key, "g32_da")) g_tune_g32_da = value;
+    else if (!strcmp(key, "gs_dbg")) g_tune_gs_dbg = value;
+    else if (!strcmp(key, "g64_da")) g_tune_g64_da = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 #else
@@ -4522,7 +4527,7 @@ int moka_up_fwd(const void* hp_tok, const void* Bw, const uint8_t* tok_mod, void
 
 int moka_up_fwd_fused_ok(int r, int dtype) {
     const int RP = rank_pad(r);
-    return (RP == 16 || RP == 32) && dtype == MOKA_BF16 ? 1 : 0;
+    return (RP == 16 || RP == 32 || RP == 64) && dtype == MOKA_BF16 ? 1 : 0;
 }
 
 // Does the fused launch beat moka_cross_fwd + moka_up_fwd for this shape?  Measured (MI355X, 8192 tokens, r = 16; us per unit, two
@@ -4535,6 +4540,9 @@ int moka_up_fwd_fused_pays(int T, int ks, const int* d_out, int G, int r, int dt
     int cmax = 0;
     for (int g = 0; g < G; ++g) { if (d_out[g] != d_out[0]) return 0; cmax = d_out[g] > cmax ? d_out[g] : cmax; }
     if (ks > 24) return 0;
+    // rank pad 64 (13B widths, 8192 tokens, us per unit): o / down 73 -> 72, gate+up 228 -> 224, q+k+v 153 -> 174, and the shadows launch on
+    // top: the slice rows are 256 bytes, one 83 KB workgroup per CU -- the kernel is correct there (tests) but the two launches stay
+    if (rank_pad(r) == 64) return 0;
     return (G > 1 || cmax <= 6144) ? 1 : 0;
 }
 
@@ -4545,7 +4553,7 @@ int moka_up_fwd_fused_group(const float* const* part, int ks, const moka_routing
     GROUP_CHECK("moka_up_fwd_fused");
     if (!part || !rt || !s_out || !Bw || !y_inout || !d_out) return fail(MOKA_EINVAL, "moka_up_fwd_fused: null pointer");
     if (!moka_up_fwd_fused_ok(r, dtype))
-        return fail(MOKA_EINVAL, "moka_up_fwd_fused: built for bf16 storage and r <= 32 (r=%d, dtype=%d): use moka_cross_fwd + moka_up_fwd", r, dtype);
+        return fail(MOKA_EINVAL, "moka_up_fwd_fused: built for bf16 storage (r=%d, dtype=%d): use moka_cross_fwd + moka_up_fwd", r, dtype);
     if (rt->B < 1 || rt->S < 1 || rt->M < 1 || rt->M > MOKA_MAX_MOD) return fail(MOKA_EINVAL, "moka_up_fwd_fused: B=%d S=%d M=%d", rt->B, rt->S, rt->M);
     if (!rt->tok_mod || !rt->klen || !rt->ktok) return fail(MOKA_EINVAL, "moka_up_fwd_fused: null routing pointer");
     if (rt->Lk_max < 0) return fail(MOKA_EINVAL, "moka_up_fwd_fused: Lk_max=%d", rt->Lk_max);
@@ -4569,7 +4577,8 @@ int moka_up_fwd_fused_group(const float* const* part, int ks, const moka_routing
     fb.ks = ks; fb.B = rt->B; fb.S = rt->S; fb.T = T; fb.Lkp = rt->Lk_max > 0 ? rt->Lk_max : 1; fb.r = r;
     fb.w = w; fb.c = inv_sqrt_dk;
     fb.dbg = g_tune_yx_dbg;
-    return rank_pad(r) == 16 ? launch_yx<16>(fb, G, (hipStream_t)stream) : launch_yx<32>(fb, G, (hipStream_t)stream);
+    const int RPx = rank_pad(r);
+    return RPx == 16 ? launch_yx<16>(fb, G, (hipStream_t)stream) : (RPx == 32 ? launch_yx<32>(fb, G, (hipStream_t)stream) : launch_yx<64>(fb, G, (hipStream_t)stream));
 }
 
 int moka_up_fwd_fused(const float* part, int ks, const moka_routing* rt, const float* s_out, const void* Bw, void* y_inout,
@@ -4772,9 +4781,11 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
             ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in; ga.r = r; ga.M = M; ga.per_mod = 1; ga.drop = drop[g];
         }
         // (rank pad 32: G sets of waves on one x tile lose to G launches -- 240 registers, one 6- or 8-wave workgroup per CU: dx + dA 14.6 -> 14.9 ms
-        //  per pass at the 7B widths; "g32_da" 2 runs them)
-        if (fused || (RP == 32 && G > 1 && g_tune_g32_da == 2)) {
-            rc = launch_wgrad<false>(gb, G, RP, (hipStream_t)stream);
+        //  per pass at the 7B widths; "g32_da" 2 runs them; the default is the G problems as one launch of the single kernel, grid z)
+        //  rank pad 64: the G problems as ONE launch (grid z) of the wide kernel: the sibling workgroups of an x strip run side by side, so
+        //  the repeats of the strip are served on die, and the group costs one launch start-up; "g64_da" 1: a launch per projection)
+        if (fused || (RP == 32 && G > 1 && g_tune_g32_da != 1) || (RP == 64 && G > 1 && g_tune_g64_da != 1)) {
+            rc = launch_wgrad<false>(gb, G, RP, (hipStream_t)stream, RP == 32 && g_tune_g32_da != 2);
             if (rc) return rc;
         } else {
             for (int g = 0; g < G; ++g) {

@@ -80,10 +80,11 @@ def test_fused_equals_two_launches_on_the_golden_cases(name):
 def test_fused_equals_two_launches_on_random_shapes(seed):
     """Random spans (several samples inside one 128-token block, span boundaries inside 16-token tiles, padding, ragged T, ranks
     below their pad, rank pad 32), with dropout in the producer."""
-    _fused_vs_two_launches(_random_case(seed, ranks=(4, 8, 16, 16, 16, 24, 32)), p=0.1 if seed % 2 else 0.0)
+    _fused_vs_two_launches(_random_case(seed, ranks=(4, 8, 16, 16, 16, 24, 32, 48, 64)), p=0.1 if seed % 2 else 0.0)
 
 
-@pytest.mark.parametrize("variant,r,n_q", [("avt", 16, 500), ("vt", 16, 300), ("avt", 32, 450), ("avt", 16, 600), ("vt", 16, 1100)])
+@pytest.mark.parametrize("variant,r,n_q", [("avt", 16, 500), ("vt", 16, 300), ("avt", 32, 450), ("avt", 16, 600), ("vt", 16, 1100), ("avt", 64, 200),
+                                            ("vt", 48, 700)])
 def test_fused_long_question_spans(variant, r, n_q):
     """Keys far beyond one chunk of 64: the running softmax over key chunks inside the y kernel."""
     _fused_vs_two_launches(_long_question_case(f"fused_longq_{variant}_{r}_{n_q}", variant, r, n_q))
@@ -157,6 +158,8 @@ def _group_fused(cfg):
     dict(variant="avt", B=3, S=700, d_in=1376, d_outs=(352, 96, 1376), r=16, p=0.1),         # ragged
     dict(variant="vt", B=2, S=333, d_in=11008, d_outs=(4096, 160), r=8, p=0.05),
     dict(variant="avt", B=3, S=700, d_in=160, d_outs=(1376, 1376, 1376), r=24, p=0.05),      # rank pad 32
+    dict(variant="avt", B=1, S=4096, d_in=5120, d_outs=(5120, 5120, 5120), r=64, p=0.05),    # q/k/v, Llama-2-13B, rank pad 64
+    dict(variant="vt", B=2, S=333, d_in=1056, d_outs=(160, 96), r=48, p=0.1),                # rank pad 64, r < pad, ragged
 ])
 def test_fused_group_equals_two_launches(cfg):
     _group_fused(cfg)
@@ -171,7 +174,8 @@ def test_fused_refuses_what_it_was_not_built_for():
     from moka_amd import _lib
     lib = _lib.load()
     assert lib.moka_up_fwd_fused_ok(16, _lib.MOKA_BF16) == 1 and lib.moka_up_fwd_fused_ok(32, _lib.MOKA_BF16) == 1
-    assert lib.moka_up_fwd_fused_ok(64, _lib.MOKA_BF16) == 0 and lib.moka_up_fwd_fused_ok(16, _lib.MOKA_F32) == 0
+    assert lib.moka_up_fwd_fused_ok(64, _lib.MOKA_BF16) == 1 and lib.moka_up_fwd_fused_ok(16, _lib.MOKA_F32) == 0
+    assert lib.moka_up_fwd_fused_ok(65, _lib.MOKA_BF16) == 0
 
 
 @pytest.mark.parametrize("name", ["avt_tiny", "avt_r16_q", "vt_r16_q"])
