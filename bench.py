@@ -323,11 +323,13 @@ def run_forward(lib, wl, sp, rec=None, shadows=False):
 
 
 def run_shadows(lib, wl, sp, layers, rec=None):
-    """BwT / AT of the given layers (all chains share the parameters: the first chain's units carry the buffers)."""
+    """BwT / AT of the given layers' FUSED units (the other units' moka_cross_fwd writes theirs in the forward; all chains share the
+    parameters: the first chain's units carry the buffers)."""
     units, per = wl["units"], wl["units_per_layer"]
     for l in layers:
         for u in units[l * per:(l + 1) * per]:
-            _call(lib, "moka_weight_shadows", u, sp, rec)
+            if u.fused:
+                _call(lib, "moka_weight_shadows", u, sp, rec)
 
 
 def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False):
