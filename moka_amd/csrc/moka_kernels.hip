@@ -1561,6 +1561,137 @@ __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, i
 }
 
 // ------------------------------------------------------------------------------------------
+// E (rank pad 64, one projection): dx += mask o (dh . A_mod(t)) in the token-owning form of moka_yt_kernel -- the same walk (128 tokens per
+// workgroup, the chunk's 16 KB of A^T staged in LDS one chunk ahead, ~110 registers, four waves per SIMD), once per MODALITY of the
+// workgroup's token run (block uniform; one, except on span boundaries): a walk stages that modality's weights, the waves that hold none of
+// its tokens only help staging, and a lane -- one token, eight consecutive columns -- adds and stores only if its token has the walk's
+// modality, so every dx element is still read, added to and rounded exactly once.  The product passes the dropout mask of x.
+// Replaces moka_expand_kernel<64, 4, false, 1, 2, true> (256 registers, one wave per SIMD: 13B widths, dx of o / down 2.7 TB/s).
+// ------------------------------------------------------------------------------------------
+template <int RP>
+__global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;
+    constexpr int PER = NF * 64 / 512;
+    bf16x8* wl = (bf16x8*)smem;                                              // [NQ][2][KH][64]
+    __shared__ unsigned s_wpm[8];
+    const ExpandArgs& a = ab.z[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ntiles = (a.T + 15) >> 4;
+    const int tile = blockIdx.y * 8 + wave;
+    const bool live = tile < ntiles;
+    const int t = min((min(tile, ntiles - 1) << 4) + i, a.T - 1);
+    const bool valid = live && ((tile << 4) + i) < a.T;
+    const int nch = (a.C + CWK - 1) / CWK;
+    const int ch0 = blockIdx.x * chunks_per_block, ch1 = min(nch, ch0 + chunks_per_block);
+    if (ch0 >= ch1) return;
+
+    const int mrow = live ? (int)a.tok_mod[(tile << 4) + i] : MOKA_MOD_NONE;     // padded past T with MOKA_MOD_NONE
+    unsigned pm = 0;
+#pragma unroll
+    for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+    if (lane == 0) s_wpm[wave] = pm;
+    unsigned char* orow0 = a.out + ((size_t)t * a.C + 8 * g) * 2;
+    bf16x8 oA[NQ], oB[NQ];
+    auto issue_o = [&](bf16x8 (&o)[NQ], int ch_) {
+        const int cb = min(ch_, ch1 - 1) * CWK;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
+    };
+    bf16x8 bh[KH], bl[KH];
+    {
+        const unsigned char* prp = (const unsigned char*)a.pack + (size_t)t * (2 * RP * 2);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            if (RP == 16) { bh[kh] = *(const bf16x8*)(prp + 16 * g); bl[kh] = bh[kh]; }
+            else {
+                bh[kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+                bl[kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned pmB = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
+    if (pmB == 0) return;                                                    // a run of padding only (block uniform)
+    const unsigned trow = (unsigned)t;
+    const float dsc = a.drop.thr ? a.drop.inv_keep : 1.f;
+
+    unsigned rest = pmB;
+    while (rest) {                                                           // block uniform: one walk per modality of the run
+        const int m = __builtin_ctz(rest);
+        rest &= rest - 1;
+        const bool wmine = (pm >> m) & 1u;                                   // wave uniform: some of my 16 tokens have this modality
+        const bool mine = valid && mrow == m;
+        const unsigned char* wm = a.W[0] + (size_t)m * a.C * RP * 2;         // (the shadows of the modalities follow each other)
+        bf16x8 wp[PER];
+        auto wload = [&](int ch) {
+            const int cb = ch * CWK;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int e = tid + 512 * u;                                 // (q, p, kh, lane)
+                const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
+                const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);   // columns >= C are never stored
+                const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
+                wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + k0) * 2);
+            }
+        };
+        auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+            const int cb = ch * CWK;
+            if (wmine) issue_o(onext, ch + 1);
+            __syncthreads();                                                 // the previous chunk's fragments are no longer read
+#pragma unroll
+            for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+            __syncthreads();
+            if (ch + 1 < ch1) wload(ch + 1);
+            if (!wmine) return;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 d[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kh = 0; kh < KH; ++kh) {
+                        const bf16x8 wf = wl[((size_t)q * 2 + p) * KH * 64 + kh * 64 + lane];
+                        d[p] = MFMA16(wf, bh[kh], d[p]);
+                        if (RP != 16) d[p] = MFMA16(wf, bl[kh], d[p]);
+                    }
+                }
+                if (cb + 32 * q >= a.C) continue;                            // C % 32 == 0 (block uniform)
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
+                if (a.drop.thr) {
+                    const KeepMask keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
+                        v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
+                        v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
+                    }
+                }
+                union { bf16x8 b; unsigned u[4]; } ou, res;
+                ou.b = o[q];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2)
+                    res.u[w2] = f2bf_pk(fmaf(v[2 * w2], dsc, __uint_as_float(ou.u[w2] << 16)), fmaf(v[2 * w2 + 1], dsc, __uint_as_float(ou.u[w2] & 0xffff0000u)));
+                if (mine) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+            }
+        };
+        if (wmine) issue_o(oA, ch0);
+        wload(ch0);
+        for (int ch = ch0; ch < ch1; ch += 2) {
+            step(oA, oB, ch);
+            if (ch + 1 < ch1) step(oB, oA, ch + 1);
+        }
+        __syncthreads();                                                     // the last chunk's fragments are no longer read (next walk restages)
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // X + E (round 4): y += (s_out[mod] hp) . Bw^T with the cross-modal interaction computed INSIDE the token-owning y kernel -- the
 // rank-space launch (moka_cross_fwd) leaves the forward's dependency chain.  A workgroup owns 128 tokens (wave w the 16-token tile w)
 // and, before it walks its column range exactly like moka_yt_kernel, builds the MFMA B operand of its tile itself:
@@ -3805,8 +3936,20 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
         }
         else if (W_CK) { if (g_tune_expand_nq == 2) launch_expand_t<64, 2, true, 1, 2>(ab, nz, st); else launch_expand_t<64, 4, true, 1, 2>(ab, nz, st); }
         else if (g_tune_expand_nq == 3) launch_expand_t<64, 2, false, 1, 2>(ab, nz, st);            // the per-tile form (A/B)
-        // (the token-owning form of the groups, moka_dxg_kernel<1>, loses for a single projection: dx + dA of o / down 97 / 227 -> 109 / 253 us)
-        else launch_expand_t<64, 4, false, 1, 2, true>(ab, nz, st);
+        // (the token-owning form of the groups, moka_dxg_kernel<1>, loses for a single projection: dx + dA of o / down 97 / 227 -> 109 / 253 us;
+        //  the lean one, moka_dxt_kernel -- moka_yt_kernel's walk once per modality of the run -- wins; "expand_nq" 4: the column-owning form)
+        else if (g_tune_expand_nq == 4) launch_expand_t<64, 4, false, 1, 2, true>(ab, nz, st);
+        else {
+            const int T = ab.z[0].T, C = ab.z[0].C;
+            const int nch = (C + 127) / 128, ntb = (T + 127) / 128;
+            int want = ((g_tune_expand_bpc > 0 ? g_tune_expand_bpc : 2) * num_cu() + ntb - 1) / ntb;
+            want = want < 1 ? 1 : (want > nch ? nch : want);
+            const int cpb = (nch + want - 1) / want;
+            constexpr size_t lds = (size_t)4 * 2 * 2 * 1024;
+            ensure_lds((const void*)moka_dxt_kernel<64>, lds);
+            hipLaunchKernelGGL((moka_dxt_kernel<64>), dim3((nch + cpb - 1) / cpb, ntb), dim3(512), lds, st, ab, cpb);
+            return check_launch("moka_dxt_kernel");
+        }
     } else if (RP == 64 || RP == 32) {                   // projections sharing dx at rank pads 32 / 64: the token-owning form (moka_dxg_kernel)
         const int T = ab.z[0].T, C = ab.z[0].C;
         const int nch = (C + 127) / 128, ntb = (T + 127) / 128;
@@ -4205,15 +4348,16 @@ static int fwd_ks(int T, int C, int r) { const int kw = fwd_kw(T, C, r); return 
 
 // number of g_part slices moka_up_bwd writes for output width C
 // the LDS-DMA gy pass (g and dB out of one LDS tile) also at rank pad 32: 13B widths 12.0 -> 10.4 ms per pass.  At rank pad 64 it loses
-// (115 KB of LDS: one workgroup per CU, 48 MFMAs per tile and wave: 28.8 against 24.7 ms for the g-only pass + the wide dB kernel)
+// (115 KB of LDS: one workgroup per CU, 48 MFMAs per tile and wave: 28.8 against 24.7 ms for the g-only pass + the wide dB kernel; round 4, with dB
+// deferred to the side stream: 28.8 against 21.2 ms, step 79.9 -> 88.4-89.2 ms -- the second read of gy is not what that rank pays for)
 static bool gs_wide(int RP) { return RP == 32 && g_tune_gy_form != 1; }
 // columns per g_part slice: 512; rank pad 64: the gy pass is the chunk-walk kernel of the forward (x = gy, one weight set = Bw^T): whole
-// 256-column chunks, as few slices as still give every CU two workgroups of 128 tokens ("gy_form" 1: the first form, 1024 columns)
+// 256-column chunks, as few slices as still give every CU one workgroup of 128 tokens (13B widths: 2 / 1 / 3 per CU: up_bwd + cross_bwd 27.3 / 26.4 / 28.3 ms per pass) ("gy_form" 1: the first form, 1024 columns)
 static int bwd_kw(int T, int C, int r) {
     if (rank_pad(r) != 64) return 512;
     if (g_tune_gy_form == 1) return 1024;
     const int nch = (C + 255) / 256, ntb = (T + 127) / 128;
-    int want = (((g_tune_gy_ng >= 1 && g_tune_gy_ng <= 6) ? g_tune_gy_ng : 2) * num_cu() + ntb - 1) / ntb;
+    int want = (((g_tune_gy_ng >= 1 && g_tune_gy_ng <= 6) ? g_tune_gy_ng : 1) * num_cu() + ntb - 1) / ntb;
     want = want < 1 ? 1 : (want > nch ? nch : want);
     return (nch + want - 1) / want * 256;
 }
