@@ -43,12 +43,13 @@ def test_ksplit_covers_width(lib):
     for T, C, r in [(8192, 4096, 16), (8192, 11008, 16), (2048, 4096, 16), (96, 64, 4), (4096, 5120, 64), (10, 64, 8)]:
         ks = lib.moka_ksplit(T, C, r)
         assert 1 <= ks <= 32
-    # slices per projection: one per 512 columns; rank pad 64: whole 256-column chunks, as few as still give every CU three (forward) /
-    # two (backward) workgroups of 128 tokens (no device here: 256 CUs assumed)
+    # slices per projection: one per 512 columns; rank pads 32 (forward) / 64: whole 256-column chunks, as few as still give every CU three
+    # (forward) / one (backward) workgroups of 128 tokens (no device here: 256 CUs assumed)
     assert lib.moka_ksplit(8192, 5120, 16) == 10 and lib.moka_ksplit(8192, 5120, 64) == 10 and lib.moka_ksplit(8192, 13824, 64) == 11
     assert lib.moka_ksplit(128, 5120, 64) == 20 and lib.moka_ksplit(65536, 5120, 64) == 2
-    assert lib.moka_ksplit_bwd(8192, 5120, 16) == 10 and lib.moka_ksplit_bwd(8192, 5120, 64) == 7 and lib.moka_ksplit_bwd(8192, 13824, 64) == 8
+    assert lib.moka_ksplit_bwd(8192, 5120, 16) == 10 and lib.moka_ksplit_bwd(8192, 5120, 64) == 4 and lib.moka_ksplit_bwd(8192, 13824, 64) == 4
     assert lib.moka_ksplit_bwd(128, 5120, 64) == 20
+    assert lib.moka_ksplit(8192, 4096, 32) == 8 and lib.moka_ksplit(8192, 11008, 32) == 11 and lib.moka_ksplit_bwd(8192, 11008, 32) == 22
     # passes over gy of moka_up_bwd: one up to rank 32 in bf16 storage, dB on its own beyond and in fp32 storage
     assert [lib.moka_up_bwd_passes(r, 0) for r in (4, 16, 32, 33, 64)] == [1, 1, 1, 2, 2] and lib.moka_up_bwd_passes(16, 1) == 2
     assert lib.moka_up_bwd_passes(65, 0) < 0 and lib.moka_up_bwd_passes(16, 7) < 0
