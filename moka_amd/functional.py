@@ -132,7 +132,7 @@ def cross_fwd(part: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float
 def up_fwd_fused_(y2: torch.Tensor, part: torch.Tensor, Bw: torch.Tensor, rt: MokaRouting, r: int, s_out: Sequence[float],
                   w: float, inv_sqrt_dk: float, want_state: bool = False) -> Optional[FwdState]:
     """In place: y2 [T,d_out] bf16 += (s_out[mod] hp) Bw^T with hp computed from the split-K slices `part` inside the kernel
-    (the bits of cross_fwd + up_fwd_; bf16 storage, r <= 32).  want_state: the launch also writes what the backward reads from
+    (the bits of cross_fwd + up_fwd_; bf16 storage).  want_state: the launch also writes what the backward reads from
     the rank space (h, hp_kmj); returned as a FwdState whose BwT / AT are filled by `weight_shadows`."""
     lib = _lib.load()
     ks, T, RP = part.shape
@@ -485,7 +485,7 @@ def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[t
 
 
 # The forward of the autograd nodes: True (default) = moka_down_fwd -> moka_up_fwd_fused (+ moka_weight_shadows) where the fused launch
-# exists (bf16, r <= 32); False = the three-launch path moka_down_fwd -> moka_cross_fwd -> moka_up_fwd.  Same bits either way
+# exists (bf16 storage) and pays for the shape (moka_up_fwd_fused_pays: not at rank pad 64); False = the three-launch path moka_down_fwd -> moka_cross_fwd -> moka_up_fwd.  Same bits either way
 # (tests/test_gpu_fused.py); a module-level switch for A/B runs, not a tuning knob.
 FUSE_FORWARD = True
 
