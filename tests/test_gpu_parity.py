@@ -588,6 +588,20 @@ def test_rank_pad_64_group_walks_chunks_with_three_modalities_per_run(d_outs):
     _group_vs_singles(dict(variant="avt", B=2, S=4096, d_in=5120, d_outs=d_outs, r=48, p=0.1, layouts=[lay, [("t", 3)] + lay[1:]]))
 
 
+@pytest.mark.parametrize("r,d_in,d_out", [(64, 5120, 96), (48, 1376, 160), (64, 160, 96)])
+def test_rank_pad_64_single_projection_on_scrambled_spans(r, d_in, d_out):
+    """Rank pad 64, ONE projection: the token-owning dx kernel (moka_dxt_kernel: one walk over the workgroup's columns per modality of its
+    128-token run) on runs that hold all three modalities, padding and span boundaries inside 16-token tiles; widths that are not a
+    multiple of its 128-column chunk; through the dropout mask, against the fp64 oracle replaying that mask."""
+    lay = _scrambled_layout(2048)
+    name = f"scrambled_{r}_{d_in}_{d_out}"
+    C._CASES[name] = dict(variant="avt", B=2, S=2048, d_in=d_in, d_out=d_out, r=r, alpha=16.0, w=1.0, layouts=[lay, [("t", 3)] + lay[1:]],
+                          seed=77, big=True)
+    cd = C.make_case_data(name)
+    _stage_check(cd)
+    _dropout_replay(cd, 0.1, strict_rate=False)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(variant="avt", B=3, S=700, d_in=160, d_outs=(352, 352), r=8, p=0.1),            # T % 16 != 0, width % 128 != 0, r < rank pad (16)
     dict(variant="vt", B=2, S=333, d_in=96, d_outs=(96, 96, 96), r=16, p=0.0),           # one chunk, narrower than a chunk
