@@ -62,10 +62,12 @@ def main(tag):
         for path, t in parts:
             out += ["", f"## raw counters, {t}", ""] + open(path).read().splitlines()
         open(os.path.join(dst, f"{tag}_pmc_mfma_lds.md"), "w").write("\n".join(out) + "\n")
-    # ---- stall
-    path = os.path.join(ROOT, "gpurun_out", f"{tag}_stall", "summary.md")
-    if os.path.exists(path):
-        out = [f"# rocprofv3 --pmc stall / memory-pipeline passes on the {tag} build (`tools/pmc_stall.sh {tag}_stall \"--layers 2\"`: `bench.py --layers 2 --steps 1 --warmup 1 --graph off`, one pass per counter group)", "",
+    # ---- stall (the headline configuration and, when it was run, the rank-64 one: tools/pmc_stall.sh <tag>_stall_r64 "--model 13b --rank 64 ...")
+    for suffix, cmd in (("", "--layers 2"), ("_r64", "--model 13b --rank 64 --seq 4096 --batch 2 --layers 2 --defer-da off")):
+        path = os.path.join(ROOT, "gpurun_out", f"{tag}_stall{suffix}", "summary.md")
+        if not os.path.exists(path):
+            continue
+        out = [f"# rocprofv3 --pmc stall / memory-pipeline passes on the {tag} build (`tools/pmc_stall.sh {tag}_stall{suffix} \"{cmd}\"`: `bench.py {cmd} --steps 1 --warmup 1 --graph off`, one pass per counter group)", "",
                "Fractions of `SQ_WAVE_CYCLES` (quad-cycles): wait_any = `SQ_WAIT_ANY` (s_waitcnt / barrier), wait_inst = `SQ_WAIT_INST_ANY` (waiting to issue), active = `SQ_ACTIVE_INST_ANY`;",
                "latency = `TCP_TCC_READ_REQ_LATENCY` / `TCP_TCC_READ_REQ` (cycles per L2 read request); L2 hit share = `TCC_HIT` / (`TCC_HIT` + `TCC_MISS`).", "",
                "| kernel | grid (threads) | avg us | wait_any | wait_inst | active | of which VALU | latency | L2 hit share |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
@@ -80,7 +82,7 @@ def main(tag):
                 continue
             out.append(f"| {r['moka kernel']} | {r['grid (threads)']} | {r['avg us']} | {wa / wc:.2f} | {wi / wc:.2f} | {ac / wc:.2f} | {va / wc:.2f} | {lat:.0f} | {hit:.2f} |")
         out += ["", "## raw counters", ""] + open(path).read().splitlines()
-        open(os.path.join(dst, f"{tag}_pmc_stall.md"), "w").write("\n".join(out) + "\n")
+        open(os.path.join(dst, f"{tag}_pmc_stall{suffix}.md"), "w").write("\n".join(out) + "\n")
     for f in sorted(glob.glob(os.path.join(dst, f"{tag}_bench*.json"))):
         d = json.load(open(f))
         print(os.path.basename(f), d["value"], d["ms_per_step"], d.get("adapter_hbm_roofline_frac"), d.get("adapter_actual_hbm_frac"), d["roofline"]["achieved"], d.get("comm_exposed_ms"))
