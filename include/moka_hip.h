@@ -115,7 +115,7 @@ int         moka_device_check(void);
 
 /* Diagnostics build only (-DMOKA_DIAGNOSTICS: `python -m moka_amd.build --diag` -> libmoka_hip_diag.so, loaded through
  * MOKA_HIP_LIB): override a launch heuristic ("expand_bpc", "expand_depth", "expand_nq", "wgrad_nw", "wgrad_ct", "wgrad_bpc",
- * "gy_ng", "xa_ng", "xa_form", "g32_fwd", "g32_dx", "g32_da"; value 0 restores the default).  Results never depend on it (set "xa_form" before sizing `part`:
+ * "gy_ng", "xa_ng", "xa_form", "g32_fwd", "g32_dx", "g32_da", "g64_da", and the timing ablations "yx_dbg" / "gs_dbg" whose results are WRONG by design; value 0 restores the default).  Results never depend on it (set "xa_form" before sizing `part`:
  * moka_ksplit() follows it).  This is process-wide mutable state, which is why the PRODUCT library does not have it: there
  * moka_tune() returns MOKA_EINVAL and moka_diagnostics() returns 0. */
 int moka_tune(const char* key, int value);
