@@ -111,6 +111,8 @@ class Unit:
         do = I(self.d_outs)
         tm = rt.tok_mod.data_ptr()
         self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sd, do, x, dx)
+        # (--defer-da layer: the dA_m halves of a whole decoder layer as one moka_down_bwd_da_batch launch)
+        self.da_items = [((own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]), x, self.d_in, members[g]["dA"], seeds[g]) for g in range(G)]
         self.calls = {
             "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sd, 0)),
             "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
@@ -256,9 +258,20 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
                                   own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None, fused=fused))
-        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc))
+        layer_da = []
+        if defer:
+            per = len(unit_defs)
+            for l in range(L):
+                items = [it for u in reversed(units[l * per:(l + 1) * per]) for it in u.da_items]
+                n = len(items)
+                argl = ((c_void_p * n)(*[it[0].data_ptr() for it in items]), (c_void_p * n)(*[it[1].data_ptr() for it in items]),
+                        (ctypes.c_int * n)(*[it[2] for it in items]), rt.tok_mod.data_ptr(),
+                        (c_void_p * (n * M))(*[a.data_ptr() for it in items for a in it[3]]), n, Tc, r, M, args.dropout,
+                        (ctypes.c_ulonglong * n)(*[it[4] for it in items]), 0, None)
+                layer_da.append(argl)
+        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da))
         keep.append((sets, masks, scratch2, own))
-    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], chains=chain_list, master=master, work=work,
+    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], chains=chain_list, master=master, work=work,
                 gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
@@ -352,6 +365,10 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
     up = "moka_up_bwd:g" if split_db else "moka_up_bwd"
     sps = c_void_p(side.cuda_stream)
     done = {}                                                    # layer -> event "its deferred dA launches have finished" (side mode)
+    if mode == "layer":
+        mode, batched = "side", True                             # the side schedule with ONE dA launch per layer
+    else:
+        batched = False
     for l in range(n_layers - 1, lo - 1, -1):
         if mode in ("side", "window") and (l + 2) in done:
             main.wait_event(done.pop(l + 2))                     # layer l reuses the pack buffers of layer l + 2
@@ -376,9 +393,12 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
             for u in reversed(units[l * per:(l + 1) * per]):
                 if split_db:
                     _call(lib, "moka_up_bwd:dB", u, sps, None)
-                if mode == "window" and u is not pending:
+                if batched or (mode == "window" and u is not pending):
                     continue                                        # (already out, beside the next unit's rank-space backward)
                 _call(lib, "moka_down_bwd:dA", u, sps, None)
+            if batched:
+                from moka_amd import _lib as _L
+                _L.check(lib.moka_down_bwd_da_batch(*wl["layer_da"][l], sps), "moka_down_bwd_da_batch")
             if bucket_opt is not None and mode in ("side", "window"):
                 # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the
                 # update of the finished layers overlaps the backward of the earlier ones (FlatAdamW.step_range, coefficients in device memory)
@@ -633,10 +653,11 @@ def main():
                          "are independent, and the fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide "
                          "behind the streaming kernels of the other.  Single GPU with --graph all only; per-kernel durations (`roofline`, "
                          "`kernels`) are then taken with the chains back to back on one stream")
-    ap.add_argument("--defer-da", choices=("off", "main", "side", "window"), default="side",
-                    help="the dA_m halves of moka_down_bwd are needed by the optimizer only: side (default, what moka_amd.parallel.attach does) = "
-                         "a layer's worth of them is enqueued on a second stream when the layer's chain is, and runs beside the next layer's chain "
-                         "(joined before a gradient bucket ships and before the optimizer step); main = the same launches on the one stream; "
+    ap.add_argument("--defer-da", choices=("off", "main", "side", "window", "layer"), default="layer",
+                    help="the dA_m halves of moka_down_bwd are needed by the optimizer only: layer (default, what moka_amd.parallel.attach does) = "
+                         "a layer's worth of them goes out as ONE launch (moka_down_bwd_da_batch: 4 -> 1 launches per layer) on a second stream when "
+                         "the layer's chain has been enqueued, and runs beside the next layer's chain (joined before a gradient bucket ships and before "
+                         "the optimizer step); side = the same schedule with one launch per unit (round 3); main = those launches on the one stream; "
                          "off = dA_m and dx from one moka_down_bwd call inside the chain; window = a unit's dA_m forked behind the NEXT unit's pass over gy, "
                          "so that it starts with that unit's rank-space backward, the window in which the chain leaves the memory system idle (live "
                          "launches: 35.96 -> 35.16 ms; inside the hipGraph a fork per unit makes the replay host-bound: 51 ms -- an experiment, not a default)")
@@ -743,7 +764,7 @@ def main():
     # the optimizer step per gradient bucket INSIDE the backward (off: one launch behind it): needs the side stream of the deferred dA_m
     # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and args.chains == 1 and
-                  ((not comm and args.defer_da in ("side", "window") and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
+                  ((not comm and args.defer_da in ("side", "window", "layer") and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
     shadows_main = bool(args.fused and args.shadows == "main")

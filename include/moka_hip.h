@@ -69,12 +69,14 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      600            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+#define MOKA_VERSION      601            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
                                             at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
-                                            0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional */
+                                            0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional;
+                                            0.6.1: moka_down_bwd_da_batch, moka_up_fwd_fused at every rank pad */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
+#define MOKA_MAX_BATCH    8              /* independent problems of one moka_down_bwd_da_batch launch (a decoder layer has 7) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
 #define MOKA_BF16         0
 #define MOKA_F32          1              /* fp32 storage: see "fp32 storage" below */
@@ -217,6 +219,17 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
                   void* dx_inout, int T, int d_in, int r, int M,
                   float dropout_p, unsigned long long seed, int dtype, const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
+
+/* The dA_m halves of n (1..MOKA_MAX_BATCH) projections of ONE token set in one launch: problem i reads its own x[i] [T, d_in[i]] and
+ * operand pack dh_kmj[i] (moka_cross_bwd) and adds into dA_acc[i*M + m].  Only the optimizer reads dA, so a trainer defers these launches
+ * (bench.py --defer-da, parallel.attach); batched per decoder layer they are one launch instead of four (7B widths).  Projections that
+ * share x (q/k/v, gate/up) are independent problems here: their workgroups walk the same strip of x side by side and the repeats are
+ * served on die.  bf16 storage; with opts->det_ws one moka_down_bwd call per problem.  Replaces the autograd of lora.py:468-477 /
+ * layer.py:603-621 (the lora_A weight gradients) for a whole decoder layer. */
+int moka_down_bwd_da_batch(const void* const* dh_kmj /*[n]*/, const void* const* x /*[n]*/, const int* d_in /*[n]*/, const uint8_t* tok_mod,
+                           float* const* dA_acc /*[n*M]*/, int n, int T, int r, int M, float dropout_p,
+                           const unsigned long long* seeds /*[n] or NULL when dropout_p == 0*/, int dtype,
+                           const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
 
 /* ---- grouped entry points (the decoder-layer shim) -------------------------------
  * G (1..MOKA_MAX_GROUP) adapted projections that are fed by the SAME input x -- q/k/v of the attention

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOKA_HIP_LIB") or os.path.join(_HERE, "libmoka_hip.so")
 
 MOKA_BF16 = 0
+MOKA_MAX_BATCH = 8        # problems of one moka_down_bwd_da_batch launch (include/moka_hip.h)
 MOKA_F32 = 1
 MOKA_MOD_NONE = 255
 MOKA_MAX_MOD = 3
@@ -106,6 +107,9 @@ SYMBOLS = {
     "moka_down_bwd_group": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
                                     POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                     POINTER(ctypes.c_ulonglong), c_int, POINTER(MokaOpts), c_void_p]),
+    # dh_kmj[n], x[n], d_in[n], tok_mod, dA_acc[n*M], n, T, r, M, dropout_p, seeds[n], dtype, opts, stream
+    "moka_down_bwd_da_batch": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
+                                       c_int, c_float, POINTER(ctypes.c_ulonglong), c_int, POINTER(MokaOpts), c_void_p]),
     # dropout_p, seed, T, d_in, keep_out, stream
     "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
     "moka_dropout_scale": (c_float, [c_float]),

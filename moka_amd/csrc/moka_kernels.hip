@@ -2031,7 +2031,7 @@ struct WgradArgs {
 };
 // OUT_CK (dB): blockIdx.z selects one of the batched problems.
 // !OUT_CK (dA) with G > 1: the G entries share `in` (= x) and the routing; wave set g of a block works on entry g.
-struct WgradBatch { WgradArgs z[MOKA_MAX_GROUP]; };
+struct WgradBatch { WgradArgs z[MOKA_MAX_BATCH]; };      // (MOKA_MAX_BATCH >= MOKA_MAX_GROUP: moka_down_bwd_da_batch)
 
 // Block = NW waves owning NSB*64 columns for a long run of tokens.  Each wave walks over a contiguous
 // run of 32-token groups with a 2-deep software pipeline: tok_mod of group i+2 and the
@@ -4965,6 +4965,45 @@ int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, co
         }
     }
     return rc;
+}
+
+// dA_m of up to MOKA_MAX_BATCH projections of ONE token set as one launch (grid z): problem i has its own input x[i] [T, d_in[i]], operand
+// pack, dropout seed and M accumulators.  What a trainer defers per decoder layer (the optimizer alone reads dA): 4 launches -> 1 at the
+// 7B widths.  Projections that read the same x (q/k/v, gate/up) are independent problems here -- their workgroups walk the same strip
+// side by side and the repeats are served on die (rank pad 64: L2 hit share 0.75, profiles/r04_pmc_stall_r64.md).
+// bf16 storage; the deterministic mode takes one moka_down_bwd call per problem.
+int moka_down_bwd_da_batch(const void* const* dh_kmj, const void* const* x, const int* d_in, const uint8_t* tok_mod,
+                           float* const* dA_acc, int n, int T, int r, int M, float dropout_p, const unsigned long long* seeds,
+                           int dtype, const moka_opts* opts, moka_stream_t stream) {
+    if (n < 1 || n > MOKA_MAX_BATCH) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: n=%d not in 1..%d", n, MOKA_MAX_BATCH);
+    if (!dh_kmj || !x || !d_in || !tok_mod || !dA_acc) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: null pointer");
+    if (dropout_p != 0.f && !seeds) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: dropout without seeds");
+    if (dtype != MOKA_BF16) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: bf16 storage only (fp32 storage: one moka_down_bwd call per projection)");
+    if (opts && opts->det_ws) {                          // deterministic mode: the per-run partial tiles are sized per call
+        for (int i = 0; i < n; ++i) {
+            int rc = moka_down_bwd(nullptr, dh_kmj[i], x[i], nullptr, tok_mod, dA_acc + (size_t)i * M, nullptr,
+                                   T, d_in[i], r, M, dropout_p, seeds ? seeds[i] : 0ull, dtype, opts, stream);
+            if (rc) return rc;
+        }
+        return MOKA_OK;
+    }
+    WgradBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    for (int i = 0; i < n; ++i) {
+        int rc = check_common("moka_down_bwd_da_batch", T, d_in[i], r, M, dtype);
+        if (rc) return rc;
+        if (!dh_kmj[i] || !x[i]) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: dh_kmj / x of problem %d is null", i);
+        WgradArgs& ga = gb.z[i];
+        rc = make_drop("moka_down_bwd_da_batch", dropout_p, seeds ? seeds[i] : 0ull, &ga.drop);
+        if (rc) return rc;
+        ga.in = (const unsigned char*)x[i]; ga.pack = (const unsigned short*)dh_kmj[i]; ga.tok_mod = tok_mod;
+        for (int m = 0; m < M; ++m) {
+            if (!dA_acc[i * M + m]) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: dA_acc[%d] is null", i * M + m);
+            ga.acc[m] = dA_acc[i * M + m];
+        }
+        ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_in[i]; ga.r = r; ga.M = M; ga.per_mod = 1;
+    }
+    return launch_wgrad<false>(gb, n, rank_pad(r), (hipStream_t)stream, true);
 }
 
 int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const void* AT, const uint8_t* tok_mod,

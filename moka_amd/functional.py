@@ -383,6 +383,20 @@ def down_bwd_group_(bsts: Sequence[BwdState], x2: torch.Tensor, ATs: Optional[Se
                "moka_down_bwd_group")
 
 
+def down_bwd_da_batch_(dh_kmjs: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], rt: MokaRouting, r: int,
+                       dA_accs: Sequence[Sequence[torch.Tensor]], dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None):
+    """dA_accs[i][m] += for n independent projections of one token set (their own x [T, d_in_i] and operand pack) in ONE launch: what a
+    trainer defers per decoder layer (moka_down_bwd_da_batch; with the deterministic mode on: one launch per projection)."""
+    lib = _lib.load()
+    n, T = len(xs), xs[0].shape[0]
+    d_ins = [int(x.shape[1]) for x in xs]
+    _lib.check(lib.moka_down_bwd_da_batch(_ptrs(dh_kmjs), _ptrs(xs), (ctypes.c_int * n)(*d_ins), rt.tok_mod.data_ptr(),
+                                          _ptrs([a for Ai in dA_accs for a in Ai]), n, T, r, rt.M, float(dropout_p),
+                                          _u64s(seeds if seeds is not None else [0] * n), _lib.MOKA_BF16,
+                                          _det_opts(xs[0].device, T, max(d_ins), r, 1, rt.M), _stream_ptr(xs[0].device)),
+               "moka_down_bwd_da_batch")
+
+
 def dropout_mask(dropout_p: float, seed: int, T: int, d_in: int, device) -> torch.Tensor:
     """The keep mask (uint8 [T,d_in]) the kernels derive from (dropout_p, seed) -- for checkers."""
     lib = _lib.load()
@@ -657,8 +671,12 @@ class MokaLinearFn(torch.autograd.Function):
             if spec.sinks is not None and spec.defer is not None and dA_acc is not None:
                 if dx2 is not None:
                     down_bwd_(bst, x2, AT, rt, r, None, dx2, spec.dropout_p, spec.seed, dtype=dt)
-                spec.defer(lambda bst=bst, x2=x2, AT=AT, dA_acc=dA_acc: down_bwd_(bst, x2, AT, rt, r, dA_acc, None, spec.dropout_p, spec.seed, dtype=dt),
-                           [x2, bst.dh_tok, bst.dh_kmj, AT])
+                fn = lambda bst=bst, x2=x2, AT=AT, dA_acc=dA_acc: down_bwd_(bst, x2, AT, rt, r, dA_acc, None, spec.dropout_p, spec.seed, dtype=dt)   # noqa: E731
+                if dt == _lib.MOKA_BF16 and getattr(spec.defer, "accepts_da", False):
+                    # (described as well: attach() sends a decoder layer's dA_m halves out as ONE launch, moka_down_bwd_da_batch)
+                    spec.defer(fn, [x2, bst.dh_tok, bst.dh_kmj, AT], da=((rt, r, float(spec.dropout_p)), [(bst.dh_kmj, x2, list(dA_acc), spec.seed or 0)]))
+                else:
+                    spec.defer(fn, [x2, bst.dh_tok, bst.dh_kmj, AT])
             else:
                 down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed, dtype=dt)
         gB, gA = None, [None] * len(A)
@@ -824,8 +842,12 @@ class MokaLinearGroupFn(torch.autograd.Function):
             if use_sinks and sp.defer is not None and dA_accs is not None:
                 if dx2 is not None:
                     down_bwd_group_(bsts, x2, ATs, rt, r, None, dx2, sp.dropout_p, seeds_)
-                sp.defer(lambda: down_bwd_group_(bsts, x2, None, rt, r, dA_accs, None, sp.dropout_p, seeds_),
-                         [x2] + [b.dh_tok for b in bsts] + [b.dh_kmj for b in bsts])
+                fn = lambda: down_bwd_group_(bsts, x2, None, rt, r, dA_accs, None, sp.dropout_p, seeds_)   # noqa: E731
+                keep_ = [x2] + [b.dh_tok for b in bsts] + [b.dh_kmj for b in bsts]
+                if getattr(sp.defer, "accepts_da", False):
+                    sp.defer(fn, keep_, da=((rt, r, float(sp.dropout_p)), [(bsts[g].dh_kmj, x2, list(dA_accs[g]), seeds_[g] or 0) for g in range(G)]))
+                else:
+                    sp.defer(fn, keep_)
             else:
                 down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, seeds_)
         cast = _split_like(flat.to(x2.dtype), shapes) if flat is not None else []      # one cast kernel for all weight gradients

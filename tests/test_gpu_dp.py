@@ -349,12 +349,20 @@ def test_deferred_dA_on_the_side_stream_gives_the_same_gradients(rank):
     from moka_amd.parallel import attach
     assert _lib.up_bwd_passes(8) == 1 and _lib.up_bwd_passes(32) == 1 and _lib.up_bwd_passes(40) == 2 and _lib.up_bwd_passes(8, _lib.MOKA_F32) == 2
     outs = []
+    from moka_amd import functional as F
+    batches, real = [], F.down_bwd_da_batch_
+
+    def counted(dh_kmjs, xs, *a, **k):
+        batches.append(len(xs))
+        return real(dh_kmjs, xs, *a, **k)
+
     for defer in (False, True):
         st, dims = _build("avt", dev, rank=rank)
         for m in st.modules():
             if hasattr(m, "lora_dropout_p"):
                 m.lora_dropout_p = 0.1
         dp = attach(st, n_buckets=3, defer_dA=defer)
+        F.down_bwd_da_batch_ = counted
         h, gout, mask_args, sl = _batch("avt", dims, dev)
         torch.manual_seed(123)                                    # the dropout seeds are drawn from torch's CPU generator
         with dp.no_sync():
@@ -365,6 +373,10 @@ def test_deferred_dA_on_the_side_stream_gives_the_same_gradients(rank):
         torch.cuda.synchronize()
         assert not dp._deferred and not dp._side_busy
         outs.append(dp.bucket.flat.clone())
+        F.down_bwd_da_batch_ = real
+        # a decoder layer's seven dA_m halves leave as ONE launch (moka_down_bwd_da_batch), two backward passes per run
+        assert batches == ([7] * (2 * 3) if defer else []), batches          # (three layers)
+        batches.clear()
     err = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
     assert outs[0].norm().item() > 0 and err <= 1e-5, err
 

@@ -692,6 +692,73 @@ def _group_vs_singles(cfg):
     assert (xg.grad.float() - xs.grad.float()).abs().max().item() <= 2.0 ** -5 * xs.grad.float().abs().max().item(), "dx max"
 
 
+@pytest.mark.parametrize("r", [16, 24, 64])
+def test_dA_of_a_decoder_layer_as_one_batched_launch(r):
+    """moka_down_bwd_da_batch: the dA_m halves of seven projections of one token set -- three and two of them reading the same x, inputs of
+    different width -- as ONE launch against one moka_down_bwd call per projection (fp32 atomics: equal up to the order of the adds) and
+    against the fp64 oracle; in the deterministic mode (one launch per projection inside the entry point) bit for bit."""
+    from moka_amd import functional as F
+    dev = _dev()
+    bf = torch.bfloat16
+    lay = [[("p", 3), ("t", 40), ("v", 70), ("t", 9), ("a", 37), ("q", 21), ("t", 153)]] * 2
+    widths = [(256, 96)] * 3 + [(256, 64)] + [(160, 96)] * 2 + [(704, 64)]          # (d_in, d_out): q k v | o | gate up | down
+    cds = []
+    for i, (d_in, d_out) in enumerate(widths):
+        name = f"dAbatch_{r}_{i}"
+        C._CASES[name] = dict(variant="avt", B=2, S=333, d_in=d_in, d_out=d_out, r=r, alpha=16.0, w=1.0, layouts=lay, seed=300 + i, big=True)
+        cds.append(C.make_case_data(name))
+    for i in (1, 2):
+        cds[i].x = cds[0].x
+    cds[5].x = cds[4].x
+    spec, rt, ort = _spec_and_routing(cds[0], dev)
+    T, M, p = 2 * 333, rt.M, 0.1
+    xs, packs, seeds = [], [], []
+    for i, cd in enumerate(cds):
+        c = cd.case
+        x2 = cd.x.reshape(T, c.d_in).to(dev, bf).contiguous()
+        A = [a.to(dev, bf).contiguous() for a in cd.A]
+        Bw = cd.Bw.to(dev, bf).contiguous()
+        st = F.cross_fwd(F.down_fwd(x2, A, rt, r, spec.s_in, p, 50 + i), rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, A=A)
+        gy2 = cd.gy.reshape(T, c.d_out).to(dev, bf).contiguous()
+        bst = F.cross_bwd(F.up_bwd(gy2, st.hp_kmj, st.BwT, rt, r, spec.s_out, None), st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+        xs.append(x2); packs.append(bst); seeds.append(50 + i)
+
+    def zeros():
+        return [[torch.zeros(r, x.shape[1], dtype=torch.float32, device=dev) for _ in range(M)] for x in xs]
+
+    one, batch = zeros(), zeros()
+    for i in range(len(xs)):
+        F.down_bwd_(packs[i], xs[i], None, rt, r, one[i], None, p, seeds[i])
+    F.down_bwd_da_batch_([b.dh_kmj for b in packs], xs, rt, r, batch, p, seeds)
+    for i in range(len(xs)):
+        for m in range(M):
+            if one[i][m].norm().item() > 0:
+                assert rel(batch[i][m], one[i][m]) < 1e-5, f"dA[{i}][{m}]"
+            else:
+                assert batch[i][m].abs().max().item() == 0
+    # the fp64 oracle through the same mask (projection 6: the widest input)
+    cd = cds[6]
+    keep = F.dropout_mask(p, seeds[6], T, cd.case.d_in, dev).cpu().reshape(2, 333, -1).double()
+    y0 = torch.zeros(2, 333, cd.case.d_out, dtype=torch.float64)
+    _, ctx = O.adapter_forward(cd.x.double() * keep / (1 - p), y0, [a.double() for a in cd.A], cd.Bw.double(), ort, spec.s_in, spec.s_out, spec.w, r,
+                               dtype=torch.float64)
+    _, dAo, _, _ = O.adapter_backward(cd.gy.double(), ctx)
+    for m in range(M):
+        if dAo[m].norm().item() > 0:
+            assert rel(batch[6][m], dAo[m]) < 2e-3, f"oracle dA[{m}]"          # (x, A, Bw, gy enter as bf16 on the device)
+    F.set_deterministic(True, device=dev)
+    try:
+        d1, d2 = zeros(), zeros()
+        for i in range(len(xs)):
+            F.down_bwd_(packs[i], xs[i], None, rt, r, d1[i], None, p, seeds[i])
+        F.down_bwd_da_batch_([b.dh_kmj for b in packs], xs, rt, r, d2, p, seeds)
+        for i in range(len(xs)):
+            for m in range(M):
+                assert torch.equal(d1[i][m], d2[i][m])
+    finally:
+        F.set_deterministic(False, device=dev)
+
+
 @pytest.mark.parametrize("r", [16, 32])
 def test_group_dx_against_fp64_oracle(r):
     """dx of a q/k/v group with a zero base weight (so only the adapter terms remain) against the fp64
