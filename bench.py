@@ -113,6 +113,7 @@ class Unit:
         self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sd, do, x, dx)
         # (--defer-da layer: the dA_m halves of a whole decoder layer as one moka_down_bwd_da_batch launch)
         self.da_items = [((own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]), x, self.d_in, members[g]["dA"], seeds[g]) for g in range(G)]
+        self.db_items = [(members[g]["y"], members[g]["hp_kmj"], members[g]["d_out"], members[g]["dB"]) for g in range(G)]
         self.calls = {
             "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sd, 0)),
             "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
@@ -258,7 +259,7 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
                                   own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None, fused=fused))
-        layer_da = []
+        layer_da, layer_db = [], []
         if defer:
             per = len(unit_defs)
             for l in range(L):
@@ -269,9 +270,13 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                         (c_void_p * (n * M))(*[a.data_ptr() for it in items for a in it[3]]), n, Tc, r, M, args.dropout,
                         (ctypes.c_ulonglong * n)(*[it[4] for it in items]), 0, None)
                 layer_da.append(argl)
-        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da))
+                dbi = [it for u in reversed(units[l * per:(l + 1) * per]) for it in u.db_items]
+                layer_db.append(((c_void_p * n)(*[it[0].data_ptr() for it in dbi]), (c_void_p * n)(*[it[1].data_ptr() for it in dbi]),
+                                 (ctypes.c_int * n)(*[it[2] for it in dbi]), rt.tok_mod.data_ptr(), (c_void_p * n)(*[it[3].data_ptr() for it in dbi]),
+                                 n, Tc, r, M, 0, None))
+        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db))
         keep.append((sets, masks, scratch2, own))
-    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], chains=chain_list, master=master, work=work,
+    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], chains=chain_list, master=master, work=work,
                 gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
@@ -391,13 +396,15 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
         else:
             side.wait_stream(main)
             for u in reversed(units[l * per:(l + 1) * per]):
-                if split_db:
+                if split_db and not batched:
                     _call(lib, "moka_up_bwd:dB", u, sps, None)
                 if batched or (mode == "window" and u is not pending):
                     continue                                        # (already out, beside the next unit's rank-space backward)
                 _call(lib, "moka_down_bwd:dA", u, sps, None)
             if batched:
                 from moka_amd import _lib as _L
+                if split_db:
+                    _L.check(lib.moka_up_bwd_db_batch(*wl["layer_db"][l], sps), "moka_up_bwd_db_batch")
                 _L.check(lib.moka_down_bwd_da_batch(*wl["layer_da"][l], sps), "moka_down_bwd_da_batch")
             if bucket_opt is not None and mode in ("side", "window"):
                 # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the

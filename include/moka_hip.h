@@ -73,7 +73,7 @@ typedef void* moka_stream_t;            /* hipStream_t */
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
                                             at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
                                             0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional;
-                                            0.6.1: moka_down_bwd_da_batch, moka_up_fwd_fused at every rank pad */
+                                            0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_up_fwd_fused at every rank pad */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MAX_BATCH    8              /* independent problems of one moka_down_bwd_da_batch launch (a decoder layer has 7) */
@@ -230,6 +230,14 @@ int moka_down_bwd_da_batch(const void* const* dh_kmj /*[n]*/, const void* const*
                            float* const* dA_acc /*[n*M]*/, int n, int T, int r, int M, float dropout_p,
                            const unsigned long long* seeds /*[n] or NULL when dropout_p == 0*/, int dtype,
                            const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
+
+/* The dB halves of n (1..MOKA_MAX_BATCH) projections of ONE token set in one launch (problem i: gy[i] [T, d_out[i]], hp_kmj[i] of its
+ * forward, dB_acc[i] [d_out[i], r]) -- for the ranks at which dB is a pass of its own (moka_up_bwd_passes() == 2) and a trainer defers
+ * it with dA.  bf16 storage; with opts->det_ws one moka_up_bwd call per problem.  Replaces the autograd of lora.py:524-530 /
+ * layer.py:655-669 (the lora_B weight gradients) for a whole decoder layer. */
+int moka_up_bwd_db_batch(const void* const* gy /*[n]*/, const void* const* hp_kmj /*[n]*/, const int* d_out /*[n]*/, const uint8_t* tok_mod,
+                         float* const* dB_acc /*[n]*/, int n, int T, int r, int M, int dtype,
+                         const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
 
 /* ---- grouped entry points (the decoder-layer shim) -------------------------------
  * G (1..MOKA_MAX_GROUP) adapted projections that are fed by the SAME input x -- q/k/v of the attention

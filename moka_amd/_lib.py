@@ -110,6 +110,9 @@ SYMBOLS = {
     # dh_kmj[n], x[n], d_in[n], tok_mod, dA_acc[n*M], n, T, r, M, dropout_p, seeds[n], dtype, opts, stream
     "moka_down_bwd_da_batch": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                        c_int, c_float, POINTER(ctypes.c_ulonglong), c_int, POINTER(MokaOpts), c_void_p]),
+    # gy[n], hp_kmj[n], d_out[n], tok_mod, dB_acc[n], n, T, r, M, dtype, opts, stream
+    "moka_up_bwd_db_batch": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
+                                     c_int, c_int, POINTER(MokaOpts), c_void_p]),
     # dropout_p, seed, T, d_in, keep_out, stream
     "moka_dropout_mask": (c_int, [c_float, ctypes.c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
     "moka_dropout_scale": (c_float, [c_float]),

@@ -4862,6 +4862,35 @@ int moka_up_bwd(const void* gy, const void* hp_kmj, const void* BwT, const uint8
     return moka_up_bwd_group(&gy, &hp_kmj, &BwT, tok_mod, s_out, &g_part, &dB_acc, T, r, &d_out, M, 1, dtype, opts, stream);
 }
 
+// dB of up to MOKA_MAX_BATCH projections of ONE token set as one launch (grid z) -- the counterpart of moka_down_bwd_da_batch for
+// the ranks at which dB is a pass of its own (moka_up_bwd_passes() == 2: a trainer defers it with dA).  bf16 storage; the
+// deterministic mode takes one moka_up_bwd call per problem.
+int moka_up_bwd_db_batch(const void* const* gy, const void* const* hp_kmj, const int* d_out, const uint8_t* tok_mod,
+                         float* const* dB_acc, int n, int T, int r, int M, int dtype, const moka_opts* opts, moka_stream_t stream) {
+    if (n < 1 || n > MOKA_MAX_BATCH) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: n=%d not in 1..%d", n, MOKA_MAX_BATCH);
+    if (!gy || !hp_kmj || !d_out || !tok_mod || !dB_acc) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: null pointer");
+    if (dtype != MOKA_BF16) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: bf16 storage only (fp32 storage: one moka_up_bwd call per projection)");
+    if (opts && opts->det_ws) {
+        const float s1[MOKA_MAX_MOD] = {1.f, 1.f, 1.f};                      // (s_out is carried by the pack: unused by the dB half)
+        for (int i = 0; i < n; ++i) {
+            int rc = moka_up_bwd(gy[i], hp_kmj[i], nullptr, tok_mod, s1, nullptr, dB_acc[i], T, r, d_out[i], M, dtype, opts, stream);
+            if (rc) return rc;
+        }
+        return MOKA_OK;
+    }
+    WgradBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    for (int i = 0; i < n; ++i) {
+        int rc = check_common("moka_up_bwd_db_batch", T, d_out[i], r, M, dtype);
+        if (rc) return rc;
+        if (!gy[i] || !hp_kmj[i] || !dB_acc[i]) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: gy / hp_kmj / dB_acc of problem %d is null", i);
+        WgradArgs& ga = gb.z[i];
+        ga.in = (const unsigned char*)gy[i]; ga.pack = (const unsigned short*)hp_kmj[i]; ga.tok_mod = tok_mod; ga.acc[0] = dB_acc[i];
+        ga.T = T; ga.Tp = (T + 31) / 32 * 32; ga.C = d_out[i]; ga.r = r; ga.M = M; ga.per_mod = 0;
+    }
+    return launch_wgrad<true>(gb, n, rank_pad(r), (hipStream_t)stream);
+}
+
 int moka_down_bwd_group(const void* const* dh_tok, const void* const* dh_kmj, const void* x, const void* const* AT,
                         const uint8_t* tok_mod, float* const* dA_acc, void* dx_inout, int T, int d_in, int r, int M, int G,
                         float dropout_p, const unsigned long long* seeds, int dtype, const moka_opts* opts, moka_stream_t stream) {

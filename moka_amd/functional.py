@@ -397,6 +397,17 @@ def down_bwd_da_batch_(dh_kmjs: Sequence[torch.Tensor], xs: Sequence[torch.Tenso
                "moka_down_bwd_da_batch")
 
 
+def up_bwd_db_batch_(gys: Sequence[torch.Tensor], hp_kmjs: Sequence[torch.Tensor], rt: MokaRouting, r: int, dB_accs: Sequence[torch.Tensor]):
+    """dB_accs[i] [d_out_i, r] += for n independent projections of one token set in ONE launch (moka_up_bwd_db_batch): the deferred dB of a
+    decoder layer at the ranks where dB is a pass of its own."""
+    lib = _lib.load()
+    n, T = len(gys), gys[0].shape[0]
+    d_outs = [int(g.shape[1]) for g in gys]
+    _lib.check(lib.moka_up_bwd_db_batch(_ptrs(gys), _ptrs(hp_kmjs), (ctypes.c_int * n)(*d_outs), rt.tok_mod.data_ptr(), _ptrs(dB_accs), n, T, r, rt.M,
+                                        _lib.MOKA_BF16, _det_opts(gys[0].device, T, max(d_outs), r, 1, rt.M), _stream_ptr(gys[0].device)),
+               "moka_up_bwd_db_batch")
+
+
 def dropout_mask(dropout_p: float, seed: int, T: int, d_in: int, device) -> torch.Tensor:
     """The keep mask (uint8 [T,d_in]) the kernels derive from (dropout_p, seed) -- for checkers."""
     lib = _lib.load()
@@ -653,7 +664,11 @@ class MokaLinearFn(torch.autograd.Function):
         else:
             g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
         if split_dB:
-            spec.defer(lambda: up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt, want_g=False), [gy2, hp_kmj])
+            fn_db = lambda: up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt, want_g=False)   # noqa: E731
+            if dt == _lib.MOKA_BF16 and getattr(spec.defer, "accepts_da", False):
+                spec.defer(fn_db, [gy2, hp_kmj], db=((rt, r), [(gy2, hp_kmj, dB_acc)]))
+            else:
+                spec.defer(fn_db, [gy2, hp_kmj])
         dx2 = None
         if need_x:                                                   # frozen base: dx only, never dW
             dx2 = torch.matmul(gy2, W) if W is not None else torch.zeros_like(x2)
@@ -823,7 +838,11 @@ class MokaLinearGroupFn(torch.autograd.Function):
         else:
             g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
         if split_dB:                                                 # (see MokaLinearFn.backward)
-            sp.defer(lambda: up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs, want_g=False), list(gy2) + list(hp_kmjs))
+            fn_db = lambda: up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs, want_g=False)   # noqa: E731
+            if getattr(sp.defer, "accepts_da", False):
+                sp.defer(fn_db, list(gy2) + list(hp_kmjs), db=((rt, r), [(gy2[g], hp_kmjs[g], dB_accs[g]) for g in range(G)]))
+            else:
+                sp.defer(fn_db, list(gy2) + list(hp_kmjs))
         dx2 = None
         if need_x:
             dx2 = torch.matmul(gy2[0], Ws[0])                        # frozen base: dx only, never dW

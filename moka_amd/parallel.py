@@ -316,17 +316,20 @@ class AdapterDataParallel:
         self.optimizer.step_range(lo, hi, grad_scale=1.0 / self.bucket.world, zero_grad=True)
         self._opt_done.append((lo, hi))
 
-    def _defer(self, fn, tensors, da=None) -> None:
-        """fn: the launch as a closure; da = (key, items): the same work described as problems of moka_down_bwd_da_batch -- key =
-        (routing, r, dropout_p), items = [(dh_kmj, x2, [dA_acc_m], seed)] -- so that a decoder layer's dA_m launches leave as ONE."""
+    def _defer(self, fn, tensors, da=None, db=None) -> None:
+        """fn: the launch as a closure; da / db = (key, items): the same work described as problems of moka_down_bwd_da_batch (key =
+        (routing, r, dropout_p), items = [(dh_kmj, x2, [dA_acc_m], seed)]) or moka_up_bwd_db_batch (key = (routing, r), items =
+        [(gy2, hp_kmj, dB_acc)]), so that a decoder layer's weight-gradient launches leave as ONE per kind."""
         self._bwd_active = True
-        self._deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)], da))
+        desc = ("da", da) if da is not None else (("db", db) if db is not None else None)
+        self._deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)], desc))
     _defer.accepts_da = True
 
     def _flush_deferred(self) -> None:
         """Launch what the backward has deferred so far on the side stream, behind everything the main stream has enqueued.  The dA_m
-        halves that came with a description and share routing, rank and dropout rate go out as one batched launch per MOKA_MAX_BATCH
-        projections (a decoder layer of 7 projections: one launch instead of four); everything else as it was handed in."""
+        (and, where dB is a pass of its own, dB) halves that came with a description and share routing, rank and dropout rate go out as one
+        batched launch per MOKA_MAX_BATCH projections (a decoder layer of 7 projections: one launch instead of four); everything else as
+        it was handed in."""
         if not self._deferred:
             return
         from . import functional as F
@@ -336,23 +339,32 @@ class AdapterDataParallel:
             self._side = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         self._side.wait_stream(main)
+
+        def key_of(desc):
+            return (desc[0], id(desc[1][0][0])) + tuple(desc[1][0][1:])
+
         groups = {}
-        for fn, tensors, da in self._deferred:
-            if da is not None:
-                groups.setdefault((id(da[0][0]),) + tuple(da[0][1:]), []).append(da)
+        for fn, tensors, desc in self._deferred:
+            if desc is not None:
+                groups.setdefault(key_of(desc), []).append(desc[1])
         batched = {k for k, v in groups.items() if sum(len(d[1]) for d in v) > 1}
         with torch.cuda.stream(self._side):
-            for fn, tensors, da in self._deferred:
-                if da is None or ((id(da[0][0]),) + tuple(da[0][1:])) not in batched:
+            for fn, tensors, desc in self._deferred:
+                if desc is None or key_of(desc) not in batched:
                     fn()
                 for t in tensors:
                     t.record_stream(self._side)      # (the caching allocator must not hand the block out before the side kernel has read it)
             for k in batched:
-                rt, r, p = groups[k][0][0]
                 items = [it for d in groups[k] for it in d[1]]
+                head = groups[k][0][0]
                 for i in range(0, len(items), _lib.MOKA_MAX_BATCH):
                     part = items[i:i + _lib.MOKA_MAX_BATCH]
-                    F.down_bwd_da_batch_([it[0] for it in part], [it[1] for it in part], rt, r, [it[2] for it in part], p, [it[3] for it in part])
+                    if k[0] == "da":
+                        rt, r, p = head
+                        F.down_bwd_da_batch_([it[0] for it in part], [it[1] for it in part], rt, r, [it[2] for it in part], p, [it[3] for it in part])
+                    else:
+                        rt, r = head
+                        F.up_bwd_db_batch_([it[0] for it in part], [it[1] for it in part], rt, r, [it[2] for it in part])
         self._deferred.clear()
         self._side_busy = True
 

@@ -712,7 +712,7 @@ def test_dA_of_a_decoder_layer_as_one_batched_launch(r):
     cds[5].x = cds[4].x
     spec, rt, ort = _spec_and_routing(cds[0], dev)
     T, M, p = 2 * 333, rt.M, 0.1
-    xs, packs, seeds = [], [], []
+    xs, packs, seeds, gys, hps = [], [], [], [], []
     for i, cd in enumerate(cds):
         c = cd.case
         x2 = cd.x.reshape(T, c.d_in).to(dev, bf).contiguous()
@@ -721,7 +721,7 @@ def test_dA_of_a_decoder_layer_as_one_batched_launch(r):
         st = F.cross_fwd(F.down_fwd(x2, A, rt, r, spec.s_in, p, 50 + i), rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, A=A)
         gy2 = cd.gy.reshape(T, c.d_out).to(dev, bf).contiguous()
         bst = F.cross_bwd(F.up_bwd(gy2, st.hp_kmj, st.BwT, rt, r, spec.s_out, None), st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
-        xs.append(x2); packs.append(bst); seeds.append(50 + i)
+        xs.append(x2); packs.append(bst); seeds.append(50 + i); gys.append(gy2); hps.append(st.hp_kmj)
 
     def zeros():
         return [[torch.zeros(r, x.shape[1], dtype=torch.float32, device=dev) for _ in range(M)] for x in xs]
@@ -746,6 +746,14 @@ def test_dA_of_a_decoder_layer_as_one_batched_launch(r):
     for m in range(M):
         if dAo[m].norm().item() > 0:
             assert rel(batch[6][m], dAo[m]) < 2e-3, f"oracle dA[{m}]"          # (x, A, Bw, gy enter as bf16 on the device)
+    # dB the same way (moka_up_bwd_db_batch): against one moka_up_bwd call per projection
+    b_one = [torch.zeros(g.shape[1], r, dtype=torch.float32, device=dev) for g in gys]
+    b_batch = [torch.zeros_like(b) for b in b_one]
+    for i in range(len(gys)):
+        F.up_bwd(gys[i], hps[i], None, rt, r, spec.s_out, b_one[i], want_g=False)
+    F.up_bwd_db_batch_(gys, hps, rt, r, b_batch)
+    for i in range(len(gys)):
+        assert b_one[i].norm().item() > 0 and rel(b_batch[i], b_one[i]) < 1e-5, f"dB[{i}]"
     F.set_deterministic(True, device=dev)
     try:
         d1, d2 = zeros(), zeros()
@@ -755,6 +763,13 @@ def test_dA_of_a_decoder_layer_as_one_batched_launch(r):
         for i in range(len(xs)):
             for m in range(M):
                 assert torch.equal(d1[i][m], d2[i][m])
+        e1 = [torch.zeros_like(b) for b in b_one]
+        e2 = [torch.zeros_like(b) for b in b_one]
+        for i in range(len(gys)):
+            F.up_bwd(gys[i], hps[i], None, rt, r, spec.s_out, e1[i], want_g=False)
+        F.up_bwd_db_batch_(gys, hps, rt, r, e2)
+        for i in range(len(gys)):
+            assert torch.equal(e1[i], e2[i])
     finally:
         F.set_deterministic(False, device=dev)
 
