@@ -113,6 +113,7 @@ class Unit:
         self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sd, do, x, dx)
         # (--defer-da layer: the dA_m halves of a whole decoder layer as one moka_down_bwd_da_batch launch)
         self.da_items = [((own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]), x, self.d_in, members[g]["dA"], seeds[g]) for g in range(G)]
+        self.sh_items = [(m["Bw"], m["d_out"], m["A"], self.d_in, m["BwT"], m["AT"]) for m in members]
         self.db_items = [(members[g]["y"], members[g]["hp_kmj"], members[g]["d_out"], members[g]["dB"]) for g in range(G)]
         self.calls = {
             "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sd, 0)),
@@ -274,9 +275,9 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                 layer_db.append(((c_void_p * n)(*[it[0].data_ptr() for it in dbi]), (c_void_p * n)(*[it[1].data_ptr() for it in dbi]),
                                  (ctypes.c_int * n)(*[it[2] for it in dbi]), rt.tok_mod.data_ptr(), (c_void_p * n)(*[it[3].data_ptr() for it in dbi]),
                                  n, Tc, r, M, 0, None))
-        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db))
+        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db, rank=r))
         keep.append((sets, masks, scratch2, own))
-    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], chains=chain_list, master=master, work=work,
+    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], rank=r, chains=chain_list, master=master, work=work,
                 gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
@@ -340,14 +341,34 @@ def run_forward(lib, wl, sp, rec=None, shadows=False):
         _call(lib, "moka_up_fwd:fused", u, sp, rec)
 
 
+SHADOWS_BATCH = True          # --shadows-batch off: one moka_weight_shadows_group launch per unit (A/B)
+
+
 def run_shadows(lib, wl, sp, layers, rec=None):
     """BwT / AT of the given layers' FUSED units (the other units' moka_cross_fwd writes theirs in the forward; all chains share the
-    parameters: the first chain's units carry the buffers)."""
+    parameters: the first chain's units carry the buffers): one moka_weight_shadows_batch launch per 16 projections (a recorder gets
+    the per-unit launches, so that the entry point keeps its line in the table)."""
     units, per = wl["units"], wl["units_per_layer"]
-    for l in layers:
-        for u in units[l * per:(l + 1) * per]:
-            if u.fused:
-                _call(lib, "moka_weight_shadows", u, sp, rec)
+    if rec is not None or not SHADOWS_BATCH:
+        for l in layers:
+            for u in units[l * per:(l + 1) * per]:
+                if u.fused:
+                    _call(lib, "moka_weight_shadows", u, sp, rec)
+        return
+    from moka_amd import _lib as _L
+    key = ("shadows", tuple(layers))
+    if key not in wl:
+        items = [it for l in layers for u in units[l * per:(l + 1) * per] if u.fused for it in u.sh_items]
+        calls = []
+        for i in range(0, len(items), _L.MOKA_MAX_SHADOW_BATCH):
+            part = items[i:i + _L.MOKA_MAX_SHADOW_BATCH]
+            n, M = len(part), len(part[0][2])
+            calls.append(((c_void_p * n)(*[it[0].data_ptr() for it in part]), (ctypes.c_int * n)(*[it[1] for it in part]),
+                          (c_void_p * (n * M))(*[a.data_ptr() for it in part for a in it[2]]), (ctypes.c_int * n)(*[it[3] for it in part]),
+                          (c_void_p * n)(*[it[4].data_ptr() for it in part]), (c_void_p * n)(*[it[5].data_ptr() for it in part]), n, wl["rank"], M))
+        wl[key] = calls
+    for argl in wl[key]:
+        _L.check(lib.moka_weight_shadows_batch(*argl, sp), "moka_weight_shadows_batch")
 
 
 def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False):
@@ -683,6 +704,8 @@ def main():
     ap.add_argument("--fuse-fwd", choices=("on", "off"), default="on",
                     help="on (default, r <= 32): the up-projection computes the cross-modal interaction itself (moka_up_fwd_fused) and the rank-space "
                          "launch, which then only writes the backward's operands, runs on a side stream off the dependency chain; off: three launches per unit")
+    ap.add_argument("--shadows-batch", choices=("on", "off"), default="on",
+                    help="with --shadows opt: the shadows of up to 16 projections per launch (moka_weight_shadows_batch; default) or one launch per unit")
     ap.add_argument("--shadows", choices=("opt", "main"), default="opt",
                     help="fused units: where BwT / AT (functions of the weights alone, read by the backward) are written: opt = where the weights change, "
                          "behind the optimizer update (moka_weight_shadows per gradient bucket on the side / communication stream with --opt-in-backward); "
@@ -750,6 +773,8 @@ def main():
     if args.chains > 1:
         args.defer_da = "off"                                    # (the part-batch chains already overlap each other)
     # dB leaves the dependency chain with dA_m where the library computes it in a pass of its own anyway (r > 32)
+    global SHADOWS_BATCH
+    SHADOWS_BATCH = args.shadows_batch == "on"
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
     if args.chains > 1 and (comm or args.graph != "all"):
         raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")

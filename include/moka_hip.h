@@ -73,9 +73,10 @@ typedef void* moka_stream_t;            /* hipStream_t */
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
                                             at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
                                             0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional;
-                                            0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_up_fwd_fused at every rank pad */
+                                            0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_weight_shadows_batch, moka_up_fwd_fused at every rank pad */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
+#define MOKA_MAX_SHADOW_BATCH 16         /* projections of one moka_weight_shadows_batch launch */
 #define MOKA_MAX_BATCH    8              /* independent problems of one moka_down_bwd_da_batch launch (a decoder layer has 7) */
 #define MOKA_MOD_NONE     255            /* tok_mod value of a token that belongs to no modality */
 #define MOKA_BF16         0
@@ -219,6 +220,11 @@ int moka_down_bwd(const void* dh_tok, const void* dh_kmj, const void* x, const v
                   const uint8_t* tok_mod, float* const* dA_acc /*host array of M device ptrs*/,
                   void* dx_inout, int T, int d_in, int r, int M,
                   float dropout_p, unsigned long long seed, int dtype, const moka_opts* opts /*NULL: defaults*/, moka_stream_t stream);
+
+/* BwT / AT (moka_weight_shadows) of n (1..MOKA_MAX_SHADOW_BATCH) projections of any widths in one launch -- e.g. everything a gradient
+ * bucket's optimizer step has just changed.  Entries of BwT / AT may be NULL (skipped). */
+int moka_weight_shadows_batch(const void* const* Bw /*[n]*/, const int* d_out /*[n]*/, const void* const* A /*[n*M]*/, const int* d_in /*[n]*/,
+                              void* const* BwT /*NULL or [n]*/, void* const* AT /*NULL or [n]*/, int n, int r, int M, moka_stream_t stream);
 
 /* The dA_m halves of n (1..MOKA_MAX_BATCH) projections of ONE token set in one launch: problem i reads its own x[i] [T, d_in[i]] and
  * operand pack dh_kmj[i] (moka_cross_bwd) and adds into dA_acc[i*M + m].  Only the optimizer reads dA, so a trainer defers these launches

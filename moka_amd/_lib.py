@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOKA_HIP_LIB") or os.path.join(_HERE, "libmoka_hip.so")
 
 MOKA_BF16 = 0
+MOKA_MAX_SHADOW_BATCH = 16
 MOKA_MAX_BATCH = 8        # problems of one moka_down_bwd_da_batch launch (include/moka_hip.h)
 MOKA_F32 = 1
 MOKA_MOD_NONE = 255
@@ -110,6 +111,9 @@ SYMBOLS = {
     # dh_kmj[n], x[n], d_in[n], tok_mod, dA_acc[n*M], n, T, r, M, dropout_p, seeds[n], dtype, opts, stream
     "moka_down_bwd_da_batch": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                        c_int, c_float, POINTER(ctypes.c_ulonglong), c_int, POINTER(MokaOpts), c_void_p]),
+    # Bw[n], d_out[n], A[n*M], d_in[n], BwT[n], AT[n], n, r, M, stream
+    "moka_weight_shadows_batch": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+                                          c_int, c_int, c_int, c_void_p]),
     # gy[n], hp_kmj[n], d_out[n], tok_mod, dB_acc[n], n, T, r, M, dtype, opts, stream
     "moka_up_bwd_db_batch": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                      c_int, c_int, POINTER(MokaOpts), c_void_p]),

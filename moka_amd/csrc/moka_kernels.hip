@@ -612,6 +612,19 @@ __global__ void __launch_bounds__(256) moka_shadows_kernel(const CrossBatch ab) 
     cross_weight_shadows<RP>(ab.z[blockIdx.z], (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, 256);
 }
 
+// The weight shadows of up to MOKA_MAX_SHADOW_BATCH projections of any widths in one launch (moka_weight_shadows_batch): blockIdx.z = problem.
+struct ShadowArgs { const unsigned short* Bw; unsigned short* BwT; const unsigned short* Aw[MOKA_MAX_MOD]; unsigned short* AT; int C, Cin; };
+struct ShadowBatch { ShadowArgs z[MOKA_MAX_SHADOW_BATCH]; int r, M; };
+template <int RP>
+__global__ void __launch_bounds__(256) moka_shadows_batch_kernel(const ShadowBatch sb) {
+    const ShadowArgs& p = sb.z[blockIdx.z];
+    CrossArgs a;
+    a.Bw = p.Bw; a.BwT = p.BwT; a.AT = p.AT; a.C = p.C; a.Cin = p.Cin; a.r = sb.r; a.M = sb.M;
+#pragma unroll
+    for (int m = 0; m < MOKA_MAX_MOD; ++m) a.Aw[m] = p.Aw[m];
+    cross_weight_shadows<RP>(a, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, 256);
+}
+
 // Backward, part a.  Block = 4 waves on ONE tile of 16 consecutive token rows; the four waves split the KEYS of a chunk
 // (wave w <-> key tile w, keys 16 w .. 16 w + 15), so the MFMA chain of a query tile is a quarter as long and runs on all four
 // SIMDs of the CU (the blocks are latency-, not throughput-bound: only ~1/5 of the tiles hold query rows).  Per tile with queries:
@@ -4764,6 +4777,43 @@ int moka_weight_shadows_group(const void* const* Bw, const int* d_out, const voi
     else if (RP == 32) hipLaunchKernelGGL(moka_shadows_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, ab);
     else hipLaunchKernelGGL(moka_shadows_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, ab);
     return check_launch("moka_weight_shadows");
+}
+
+// BwT / AT of n (1..MOKA_MAX_SHADOW_BATCH) projections of ANY widths in one launch: what a trainer rewrites behind an optimizer step for a
+// whole gradient bucket (the per-unit launches are ~6 us each for ~0 bytes: 128 of them per step at the 7B widths).
+int moka_weight_shadows_batch(const void* const* Bw, const int* d_out, const void* const* A, const int* d_in,
+                              void* const* BwT, void* const* AT, int n, int r, int M, moka_stream_t stream) {
+    if (n < 1 || n > MOKA_MAX_SHADOW_BATCH) return fail(MOKA_EINVAL, "moka_weight_shadows_batch: n=%d not in 1..%d", n, MOKA_MAX_SHADOW_BATCH);
+    const int RP = rank_pad(r);
+    if (RP < 0) return fail(MOKA_EINVAL, "moka_weight_shadows_batch: rank %d not in 1..64", r);
+    if (M < 1 || M > MOKA_MAX_MOD) return fail(MOKA_EINVAL, "moka_weight_shadows_batch: M=%d not in 1..%d", M, MOKA_MAX_MOD);
+    ShadowBatch sb;
+    memset(&sb, 0, sizeof(sb));
+    sb.r = r; sb.M = M;
+    long items = 0;
+    for (int i = 0; i < n; ++i) {
+        ShadowArgs& a = sb.z[i];
+        if (BwT && BwT[i]) {
+            if (!Bw || !Bw[i] || !d_out || d_out[i] < 32 || (d_out[i] % 32)) return fail(MOKA_EINVAL, "moka_weight_shadows_batch: BwT requested without Bw / d_out");
+            a.Bw = (const unsigned short*)Bw[i]; a.BwT = (unsigned short*)BwT[i]; a.C = d_out[i];
+            items = a.C > items ? a.C : items;
+        }
+        if (AT && AT[i]) {
+            if (!A || !d_in || d_in[i] < 32 || (d_in[i] % 32)) return fail(MOKA_EINVAL, "moka_weight_shadows_batch: AT requested without A / d_in");
+            a.AT = (unsigned short*)AT[i]; a.Cin = d_in[i];
+            for (int m = 0; m < M; ++m) {
+                if (!A[i * M + m]) return fail(MOKA_EINVAL, "moka_weight_shadows_batch: A[%d] is null", i * M + m);
+                a.Aw[m] = (const unsigned short*)A[i * M + m];
+            }
+            items = (long)M * d_in[i] > items ? (long)M * d_in[i] : items;
+        }
+    }
+    if (items == 0) return MOKA_OK;
+    const dim3 grid((unsigned)((items + 255) / 256), 1, n);
+    if (RP == 16) hipLaunchKernelGGL(moka_shadows_batch_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, sb);
+    else if (RP == 32) hipLaunchKernelGGL(moka_shadows_batch_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, sb);
+    else hipLaunchKernelGGL(moka_shadows_batch_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, sb);
+    return check_launch("moka_weight_shadows_batch");
 }
 
 int moka_weight_shadows(const void* Bw, int d_out, const void* const* A, int d_in, void* BwT, void* AT, int r, int M, moka_stream_t stream) {

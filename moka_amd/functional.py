@@ -234,6 +234,19 @@ def _u64s(vals: Sequence[int]):
     return (ctypes.c_ulonglong * len(vals))(*[int(v) for v in vals])
 
 
+def weight_shadows_batch_(Bws: Sequence[torch.Tensor], As: Sequence[Sequence[torch.Tensor]], r: int,
+                          BwTs: Sequence[torch.Tensor], ATs: Sequence[torch.Tensor]) -> None:
+    """Rewrite the shadows (BwT [RP, d_out], AT [M, d_in, RP]) of n projections of ANY widths in place, one launch per MOKA_MAX_SHADOW_BATCH
+    of them: what a trainer that keeps persistent shadows runs behind an optimizer step (moka_weight_shadows_batch)."""
+    lib = _lib.load()
+    M = len(As[0])
+    for i in range(0, len(Bws), _lib.MOKA_MAX_SHADOW_BATCH):
+        j = min(len(Bws), i + _lib.MOKA_MAX_SHADOW_BATCH)
+        _lib.check(lib.moka_weight_shadows_batch(_ptrs(Bws[i:j]), _ints([b.shape[0] for b in Bws[i:j]]), _ptrs([a for Ag in As[i:j] for a in Ag]),
+                                                 _ints([Ag[0].shape[1] for Ag in As[i:j]]), _ptrs(BwTs[i:j]), _ptrs(ATs[i:j]), j - i, r, M,
+                                                 _stream_ptr(Bws[0].device)), "moka_weight_shadows_batch")
+
+
 def _optptrs(tensors: Sequence[Optional[torch.Tensor]]):
     return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 

@@ -170,6 +170,25 @@ def test_fused_random_groups(seed):
     _group_fused(_random_group_cfg(seed))
 
 
+@pytest.mark.parametrize("r", [8, 24, 64])
+def test_weight_shadows_of_many_projections_in_one_launch(r):
+    """moka_weight_shadows_batch: 19 projections of different input / output widths (two launches: 16 + 3) against moka_weight_shadows
+    per projection -- the same bits."""
+    from moka_amd import functional as F
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    widths = [(256, 96), (256, 96), (160, 1376), (704, 64), (32, 32)] * 4
+    widths = widths[:19]
+    Bws = [torch.randn(do, r, generator=g).to(dev, torch.bfloat16) for _, do in widths]
+    As = [[torch.randn(r, di, generator=g).to(dev, torch.bfloat16) for _ in range(3)] for di, _ in widths]
+    ref = [F.weight_shadows(Bws[i], As[i], r) for i in range(len(widths))]
+    BwTs = [torch.full_like(b, 7.0) for b, _ in ref]
+    ATs = [torch.full_like(a, 7.0) for _, a in ref]
+    F.weight_shadows_batch_(Bws, As, r, BwTs, ATs)
+    for i in range(len(widths)):
+        assert torch.equal(BwTs[i], ref[i][0]) and torch.equal(ATs[i], ref[i][1]), i
+
+
 def test_fused_refuses_what_it_was_not_built_for():
     from moka_amd import _lib
     lib = _lib.load()
