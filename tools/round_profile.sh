@@ -15,9 +15,10 @@ for b in 1 2 8; do python bench.py --steps 5 --batch $b $N > $OUT/bench_b$b.json
 python bench.py --steps 4 --dropout 0 $N > $OUT/bench_nodrop.json 2>> $OUT/bench.err
 python bench.py --steps 4 --no-group $N > $OUT/bench_nogroup.json 2>> $OUT/bench.err
 python bench.py --steps 6 --defer-da off $N > $OUT/bench_nodefer.json 2>> $OUT/bench.err
+python bench.py --steps 20 --defer-da side --shadows-batch off $N > $OUT/bench_unbatched.json 2>> $OUT/bench.err   # one dA launch per unit, one shadows launch per unit (896 launches per step)
 python bench.py --steps 3 --e2e $N > $OUT/bench_e2e.json 2>> $OUT/bench.err
 tools/prof_run.sh $TAG > /dev/null 2>&1
-for f in bench bench_driver_command bench_unfused bench_forcecomm bench_graph_bwd bench_graph_off bench_vt bench_b1 bench_b2 bench_b8 bench_nodrop bench_nogroup bench_nodefer bench_e2e; do python - $OUT/$f.json $f <<'PY'
+for f in bench bench_driver_command bench_unfused bench_unbatched bench_forcecomm bench_graph_bwd bench_graph_off bench_vt bench_b1 bench_b2 bench_b8 bench_nodrop bench_nogroup bench_nodefer bench_e2e; do python - $OUT/$f.json $f <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
