@@ -1705,6 +1705,143 @@ __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, 
 }
 
 // ------------------------------------------------------------------------------------------
+// E (rank pads 32 / 64, G > 1): moka_dxg_kernel in the lean form of moka_dxt_kernel -- one walk over the workgroup's columns per MODALITY of its
+// token run (a lane stores only if its token has the walk's modality, so the fp32 sum over the G projections of a 32-column block lives in 8
+// registers instead of a [4][8] array that has to survive the modality loop), the G products of a block formed back to back.
+// ------------------------------------------------------------------------------------------
+template <int RP, int G>
+__global__ void __launch_bounds__(512, 3) moka_dxgt_kernel(const ExpandBatch ab, int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;
+    constexpr int PG = NF * 64 / 512, PER = G * PG;
+    bf16x8* wl = (bf16x8*)smem;                                              // [G][NQ][2][KH][64]
+    __shared__ unsigned s_wpm[8];
+    const ExpandArgs& a = ab.z[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ntiles = (a.T + 15) >> 4;
+    const int tile = blockIdx.y * 8 + wave;
+    const bool live = tile < ntiles;
+    const int t = min((min(tile, ntiles - 1) << 4) + i, a.T - 1);
+    const bool valid = live && ((tile << 4) + i) < a.T;
+    const int nch = (a.C + CWK - 1) / CWK;
+    const int ch0 = blockIdx.x * chunks_per_block, ch1 = min(nch, ch0 + chunks_per_block);
+    if (ch0 >= ch1) return;
+
+    const int mrow = live ? (int)a.tok_mod[(tile << 4) + i] : MOKA_MOD_NONE;
+    unsigned pm = 0;
+#pragma unroll
+    for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+    if (lane == 0) s_wpm[wave] = pm;
+    unsigned char* orow0 = a.out + ((size_t)t * a.C + 8 * g) * 2;
+    bf16x8 oA[NQ], oB[NQ];
+    auto issue_o = [&](bf16x8 (&o)[NQ], int ch_) {
+        const int cb = min(ch_, ch1 - 1) * CWK;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
+    };
+    bf16x8 bh[G][KH], bl[G][KH];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const unsigned char* prp = (const unsigned char*)ab.z[gi].pack + (size_t)t * (2 * RP * 2);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+            bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+        }
+    }
+    __syncthreads();
+    unsigned pmB = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
+    if (pmB == 0) return;
+    unsigned trow = (unsigned)t;
+
+    unsigned rest = pmB;
+    while (rest) {                                                           // block uniform: one walk per modality of the run
+        const int m = __builtin_ctz(rest);
+        rest &= rest - 1;
+        const bool wmine = (pm >> m) & 1u;
+        const bool mine = valid && mrow == m;
+        bf16x8 wp[PER];
+        auto wload = [&](int ch) {
+            const int cb = ch * CWK;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const unsigned char* wm = ab.z[u / PG].W[0] + (size_t)m * a.C * RP * 2;
+                const int e = tid + 512 * (u % PG);
+                const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
+                const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);
+                wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + 32 * kh + 8 * (ln >> 4)) * 2);
+            }
+        };
+        auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+            const int cb = ch * CWK;
+            if (wmine) issue_o(onext, ch + 1);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+            __syncthreads();
+            if (ch + 1 < ch1) wload(ch + 1);
+            if (!wmine) return;
+            asm volatile("" : "+v"(trow));                                   // (the masks are made where they are used: see moka_dxg_kernel)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float sum[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    const ExpandArgs& ag = ab.z[gi];
+                    f32x4 d[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kh = 0; kh < KH; ++kh) {
+                            const bf16x8 wf = wl[(((size_t)gi * NQ + q) * 2 + p) * KH * 64 + kh * 64 + lane];
+                            d[p] = MFMA16(wf, bh[gi][kh], d[p]);
+                            d[p] = MFMA16(wf, bl[gi][kh], d[p]);
+                        }
+                    }
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
+                    float dsc = 1.f;
+                    if (ag.drop.thr) {
+                        const KeepMask keep = drop_keep8(ag.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+                        dsc = ag.drop.inv_keep;
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
+                            v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
+                            v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum[e] = fmaf(v[e], dsc, sum[e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (cb + 32 * q >= a.C) continue;
+                union { bf16x8 b; unsigned u[4]; } ou, res;
+                ou.b = o[q];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2)
+                    res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[2 * w2 + 1]);
+                if (mine) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+            }
+        };
+        if (wmine) issue_o(oA, ch0);
+        wload(ch0);
+        for (int ch = ch0; ch < ch1; ch += 2) {
+            step(oA, oB, ch);
+            if (ch + 1 < ch1) step(oB, oA, ch + 1);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // X + E (round 4): y += (s_out[mod] hp) . Bw^T with the cross-modal interaction computed INSIDE the token-owning y kernel -- the
 // rank-space launch (moka_cross_fwd) leaves the forward's dependency chain.  A workgroup owns 128 tokens (wave w the 16-token tile w)
 // and, before it walks its column range exactly like moka_yt_kernel, builds the MFMA B operand of its tile itself:
@@ -3975,9 +4112,14 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
             ensure_lds((const void*)kernel, lds);
             hipLaunchKernelGGL(kernel, grid, dim3(512), lds, st, ab, cpb);
         };
-        if (RP == 64) { if (nz == 2) go(moka_dxg_kernel<64, 2>, (size_t)2 * 16 * 1024); else go(moka_dxg_kernel<64, 3>, (size_t)3 * 16 * 1024); }
-        else          { if (nz == 2) go(moka_dxg_kernel<32, 2>, (size_t)2 * 8 * 1024); else go(moka_dxg_kernel<32, 3>, (size_t)3 * 8 * 1024); }
-        return check_launch("moka_dxg_kernel");
+        if (g_tune_g32_dx == 3) {                        // ("g32_dx" 3: the first form, moka_dxg_kernel -- A/B)
+            if (RP == 64) { if (nz == 2) go(moka_dxg_kernel<64, 2>, (size_t)2 * 16 * 1024); else go(moka_dxg_kernel<64, 3>, (size_t)3 * 16 * 1024); }
+            else          { if (nz == 2) go(moka_dxg_kernel<32, 2>, (size_t)2 * 8 * 1024); else go(moka_dxg_kernel<32, 3>, (size_t)3 * 8 * 1024); }
+            return check_launch("moka_dxg_kernel");
+        }
+        if (RP == 64) { if (nz == 2) go(moka_dxgt_kernel<64, 2>, (size_t)2 * 16 * 1024); else go(moka_dxgt_kernel<64, 3>, (size_t)3 * 16 * 1024); }
+        else          { if (nz == 2) go(moka_dxgt_kernel<32, 2>, (size_t)2 * 8 * 1024); else go(moka_dxgt_kernel<32, 3>, (size_t)3 * 8 * 1024); }
+        return check_launch("moka_dxgt_kernel");
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
         // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass;
         //  the token-owning form of rank pad 64, moka_dxg_kernel<16, G>, loses here: q+k+v dx + dA 88.9 -> 106.4 us, gate+up 70.3 -> 84.9)
