@@ -1710,7 +1710,7 @@ __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, 
 // registers instead of a [4][8] array that has to survive the modality loop), the G products of a block formed back to back.
 // ------------------------------------------------------------------------------------------
 template <int RP, int G>
-__global__ void __launch_bounds__(512, 3) moka_dxgt_kernel(const ExpandBatch ab, int chunks_per_block) {
+__global__ void __launch_bounds__(512, RP == 16 ? 4 : 3) moka_dxgt_kernel(const ExpandBatch ab, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;
     constexpr int PG = NF * 64 / 512, PER = G * PG;
@@ -1746,8 +1746,11 @@ __global__ void __launch_bounds__(512, 3) moka_dxgt_kernel(const ExpandBatch ab,
         const unsigned char* prp = (const unsigned char*)ab.z[gi].pack + (size_t)t * (2 * RP * 2);
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
-            bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
-            bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            if constexpr (RP == 16) { bh[gi][kh] = *(const bf16x8*)(prp + 16 * g); bl[gi][kh] = bh[gi][kh]; }      // K = 32 is [hi(16) | lo(16)]: one MFMA
+            else {
+                bh[gi][kh] = *(const bf16x8*)(prp + (32 * kh + 8 * g) * 2);
+                bl[gi][kh] = *(const bf16x8*)(prp + (RP + 32 * kh + 8 * g) * 2);
+            }
         }
     }
     __syncthreads();
@@ -1772,7 +1775,8 @@ __global__ void __launch_bounds__(512, 3) moka_dxgt_kernel(const ExpandBatch ab,
                 const int e = tid + 512 * (u % PG);
                 const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
                 const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);
-                wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + 32 * kh + 8 * (ln >> 4)) * 2);
+                if constexpr (RP == 16) wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + 8 * ((ln >> 4) & 1)) * 2);
+                else wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + 32 * kh + 8 * (ln >> 4)) * 2);
             }
         };
         auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
@@ -1801,7 +1805,7 @@ __global__ void __launch_bounds__(512, 3) moka_dxgt_kernel(const ExpandBatch ab,
                         for (int kh = 0; kh < KH; ++kh) {
                             const bf16x8 wf = wl[(((size_t)gi * NQ + q) * 2 + p) * KH * 64 + kh * 64 + lane];
                             d[p] = MFMA16(wf, bh[gi][kh], d[p]);
-                            d[p] = MFMA16(wf, bl[gi][kh], d[p]);
+                            if constexpr (RP != 16) d[p] = MFMA16(wf, bl[gi][kh], d[p]);
                         }
                     }
                     float v[8];
@@ -4123,6 +4127,19 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
         // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass;
         //  the token-owning form of rank pad 64, moka_dxg_kernel<16, G>, loses here: q+k+v dx + dA 88.9 -> 106.4 us, gate+up 70.3 -> 84.9)
+        // ("g32_dx" 4: the token-owning lean form, moka_dxgt_kernel<16, G>, at r <= 16 too: dx + dA of q+k+v 88.7 -> 93.0 us, gate+up 70.8 -> 75.8,
+        //  step 32.6 -> 33.0-33.2 ms -- the column-owning form with resident weights stays)
+        if (g_tune_g32_dx == 4) {
+            const int T = ab.z[0].T, C = ab.z[0].C;
+            const int nch = (C + 127) / 128, ntb = (T + 127) / 128;
+            int want = ((g_tune_dx_group >= 2 ? g_tune_dx_group - 1 : 4) * num_cu() + ntb - 1) / ntb;
+            want = want < 1 ? 1 : (want > nch ? nch : want);
+            const int cpb = (nch + want - 1) / want;
+            const dim3 grid((nch + cpb - 1) / cpb, ntb);
+            if (nz == 2) { ensure_lds((const void*)moka_dxgt_kernel<16, 2>, (size_t)2 * 8 * 1024); hipLaunchKernelGGL((moka_dxgt_kernel<16, 2>), grid, dim3(512), (size_t)2 * 8 * 1024, st, ab, cpb); }
+            else { ensure_lds((const void*)moka_dxgt_kernel<16, 3>, (size_t)3 * 8 * 1024); hipLaunchKernelGGL((moka_dxgt_kernel<16, 3>), grid, dim3(512), (size_t)3 * 8 * 1024, st, ab, cpb); }
+            return check_launch("moka_dxgt_kernel");
+        }
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);
         else launch_expand_t<16, 2, false, 3, 2>(ab, 1, st);
     }
