@@ -372,24 +372,34 @@ static __device__ __forceinline__ f32x4 sum_slices4(const float* p, size_t strid
 // owns IPT float4 elements of each array; per batch SB slices of both arrays are requested before anything is consumed
 // (16 loads of 16 bytes in flight per thread), so a 4096-wide input (8 slices) costs one memory round trip instead of the
 // five a load-wait-load-wait sequence took, a 11008-wide one three instead of thirteen.  Sums run in slice order.
-template <int IPT, int SB, bool KEYS>
-static __device__ __forceinline__ void sum_rows_and_keys(const float* part, size_t sstride, int ks, const size_t (&offR)[IPT], const size_t (&offK)[IPT],
-                                                         f32x4 (&accR)[IPT], f32x4 (&accK)[IPT]) {
+template <int IPT, int SB, bool KEYS, int IPTK = IPT>
+static __device__ __forceinline__ void sum_rows_and_keys(const float* part, size_t sstride, int ks, const size_t (&offR)[IPT], const size_t (&offK)[IPTK],
+                                                         f32x4 (&accR)[IPT], f32x4 (&accK)[IPTK]) {
 #pragma unroll
-    for (int u = 0; u < IPT; ++u) { accR[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; accK[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int u = 0; u < IPT; ++u) accR[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < IPTK; ++u) accK[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < ks; s0 += SB) {
-        f32x4 xr[IPT][SB], xk[IPT][SB];
+        f32x4 xr[IPT][SB], xk[IPTK][SB];
 #pragma unroll
         for (int q = 0; q < SB; ++q) {
             const size_t so = (size_t)min(s0 + q, ks - 1) * sstride;
 #pragma unroll
-            for (int u = 0; u < IPT; ++u) { xr[u][q] = *(const f32x4*)(part + offR[u] + so); if (KEYS) xk[u][q] = *(const f32x4*)(part + offK[u] + so); }
+            for (int u = 0; u < IPT; ++u) xr[u][q] = *(const f32x4*)(part + offR[u] + so);
+            if (KEYS) {
+#pragma unroll
+                for (int u = 0; u < IPTK; ++u) xk[u][q] = *(const f32x4*)(part + offK[u] + so);
+            }
         }
 #pragma unroll
         for (int q = 0; q < SB; ++q) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < IPT; ++u) { accR[u] += (s0 + q < ks) ? xr[u][q] : z; if (KEYS) accK[u] += (s0 + q < ks) ? xk[u][q] : z; }
+            for (int u = 0; u < IPT; ++u) accR[u] += (s0 + q < ks) ? xr[u][q] : z;
+            if (KEYS) {
+#pragma unroll
+                for (int u = 0; u < IPTK; ++u) accK[u] += (s0 + q < ks) ? xk[u][q] : z;
+            }
         }
     }
 }
@@ -405,9 +415,12 @@ static __device__ __forceinline__ void write_pack_tok(unsigned short* pack_tok, 
 // Forward.  Block = NWV waves on RB = 16 NWV consecutive token rows of one sample.  Latency structure: ONE batch of global
 // loads (routing bytes, the rows' split-K slices), one dependent batch (key token indices -> key rows), then LDS / MFMA work.
 // The blocks behind the row blocks write the weight shadows (cross_weight_shadows).
-template <int RP, int NWV>
-__global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBatch ab) {
-    constexpr int NTH = NWV * 64, RB = NWV * 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
+// NLW >= NWV: waves per workgroup.  The first NWV of them own the RB = 16 NWV rows in the attention; all NLW load, sum and store (rank pad 64:
+// 32-row workgroups of four waves -- twice as many workgroups for the same loads in flight per thread, the launch has 128 row blocks per
+// projection at 64 rows).
+template <int RP, int NWV, int NLW = NWV>
+__global__ void __launch_bounds__(NLW * 64) moka_cross_fwd_kernel(const CrossBatch ab) {
+    constexpr int NTH = NLW * 64, RB = NWV * 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Hs = (float*)smem;                  // [RB][KP]  h rows
@@ -425,35 +438,38 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
     const int nrow = min(RB, a.S - r0);
     const size_t sstride = (size_t)a.T * RP;
     // ---- round trip 1: routing (sample's key count, my row's modality, the key tokens of the first chunk)
-    constexpr int IPT = (RB * R4) / NTH, SB = (IPT >= 4) ? 4 : 8 / IPT;      // 16 (r <= 32) / 32 (rank pad 64) loads in flight per thread
-    static_assert(RB * R4 == KC * R4 && (RB * R4) % NTH == 0, "one element of each array per thread and round");
+    constexpr int IPT = (RB * R4) / NTH, IPTK = (KC * R4) / NTH;             // float4 elements per thread: of the rows / of a key chunk
+    constexpr int SB = (IPT + IPTK >= 6) ? 4 : 16 / (IPT + IPTK);             // 16 (r <= 32) / 24-32 (rank pad 64) loads in flight per thread
+    static_assert((RB * R4) % NTH == 0 && (KC * R4) % NTH == 0 && IPT >= 1, "whole elements of each array per thread and round");
     const int Lk = a.klen[b];
     int my_mod = MOKA_MOD_NONE;
     if (tid < nrow) my_mod = a.tok_mod[b * a.S + r0 + tid];
-    int tk[IPT], rmod[IPT];                                       // key token / modality of the row of my u-th element
+    int tk[IPTK], rmod[IPT];                                      // key token of my u-th key element / modality of the row of my u-th row element
 #pragma unroll
-    for (int u = 0; u < IPT; ++u) {
-        const int row = (tid + u * NTH) / R4;
-        tk[u] = a.ktok[b * a.Lkp + min(row, a.Lkp - 1)];
-        rmod[u] = a.tok_mod[b * a.S + r0 + min(row, nrow - 1)];
-    }
+    for (int u = 0; u < IPTK; ++u) tk[u] = a.ktok[b * a.Lkp + min((tid + u * NTH) / R4, a.Lkp - 1)];
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) rmod[u] = a.tok_mod[b * a.S + r0 + min((tid + u * NTH) / R4, nrow - 1)];
     const int anyq0 = __syncthreads_or(my_mod != 0 && my_mod != MOKA_MOD_NONE) && (Lk > 0);
     // ---- round trip 2 (.. 1 + ks / SB): the rows' and the first chunk's key rows' split-K slices, all in flight together
     {
-        size_t offR[IPT], offK[IPT];
+        size_t offR[IPT], offK[IPTK];
 #pragma unroll
         for (int u = 0; u < IPT; ++u) {
             const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
-            if (row >= Lk) tk[u] = -1;                            // (row = key slot of the first chunk)
             if (row >= nrow) rmod[u] = MOKA_MOD_NONE;
             offR[u] = ((size_t)(b * a.S + r0 + min(row, nrow - 1))) * RP + 4 * k4;
+        }
+#pragma unroll
+        for (int u = 0; u < IPTK; ++u) {
+            const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
+            if (row >= Lk) tk[u] = -1;                            // (row = key slot of the first chunk)
             offK[u] = (size_t)max(tk[u], 0) * RP + 4 * k4;
         }
-        f32x4 accR[IPT], accK[IPT];
+        f32x4 accR[IPT], accK[IPTK];
         // (the key rows only where the block holds query rows -- block uniform, known from the routing bytes of round trip 1: three
         //  blocks in four of the bench layout skip half of their loads; at rank pad 64 the slices are 256 bytes per token each)
-        if (anyq0) sum_rows_and_keys<IPT, SB, true>(a.part, sstride, a.ks, offR, offK, accR, accK);
-        else sum_rows_and_keys<IPT, SB, false>(a.part, sstride, a.ks, offR, offK, accR, accK);
+        if (anyq0) sum_rows_and_keys<IPT, SB, true, IPTK>(a.part, sstride, a.ks, offR, offK, accR, accK);
+        else sum_rows_and_keys<IPT, SB, false, IPTK>(a.part, sstride, a.ks, offR, offK, accR, accK);
 #pragma unroll
         for (int u = 0; u < IPT; ++u) {
             const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
@@ -463,17 +479,22 @@ __global__ void __launch_bounds__(NWV * 64) moka_cross_fwd_kernel(const CrossBat
                 const float hv = (rmod[u] == MOKA_MOD_NONE) ? 0.f : accR[u][c];
                 Hs[row * KP + 4 * k4 + c] = hv;
                 Hp[row * KP + 4 * k4 + c] = hv;
-                Ks[row * KP + 4 * k4 + c] = (tk[u] < 0) ? 0.f : accK[u][c];   // zero key row (still enters the softmax when slot < Lk)
             }
+        }
+#pragma unroll
+        for (int u = 0; u < IPTK; ++u) {
+            const int e = tid + u * NTH, row = e / R4, k4 = e % R4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Ks[row * KP + 4 * k4 + c] = (tk[u] < 0) ? 0.f : accK[u][c];   // zero key row (still enters the softmax when slot < Lk)
         }
     }
     if (tid < RB) s_mod[tid] = my_mod;
     __syncthreads();
     const int anyq = anyq0;
     if (anyq) {
-        const int qrow = wave * 16 + i;                           // the lane's query row inside the block
+        const int qrow = min(wave, NWV - 1) * 16 + i;             // the lane's query row inside the block (waves >= NWV own none: they only move data)
         const int mq = s_mod[qrow];
-        const bool isq = (mq != 0 && mq != MOKA_MOD_NONE);
+        const bool isq = wave < NWV && (mq != 0 && mq != MOKA_MOD_NONE);
         const bool wq = __any(isq);                               // this wave's 16 rows contain query rows
         float m_run = -INFINITY, l_run = 0.f;
         f32x4 O[NT];
@@ -3945,12 +3966,15 @@ static int check_common(const char* fn, int T, int C, int r, int M, int dtype) {
 
 template <int RP>
 static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t st) {
-    constexpr int NWV = 4, RB = 16 * NWV, KC = 64, KP = RP + 1;
+    constexpr int NWV = 4, KC = 64, KP = RP + 1;
+    // forward: 64-row workgroups; rank pad 64: 32-row workgroups of four waves (two of them own rows in the attention, all four move data):
+    // 13B widths, 8192 tokens: 128 -> 256 row blocks per projection
+    constexpr int NWF = (RP == 64) ? 2 : 4, RB = 16 * NWF;
     const CrossArgs& a = ab.z[0];
     dim3 grid(a.B, (a.S + RB - 1) / RB, nz), block(NWV * 64);
     if (!bwd) {
         const size_t lds = (size_t)(2 * RB + KC) * KP * 4;
-        ensure_lds((const void*)moka_cross_fwd_kernel<RP, NWV>, lds);
+        ensure_lds((const void*)moka_cross_fwd_kernel<RP, NWF, NWV>, lds);
         // + blocks that write the weight shadows (one thread per BwT column / AT row)
         long items = 0;
         for (int z = 0; z < nz; ++z) {
@@ -3958,7 +3982,7 @@ static void launch_cross_t(bool bwd, const CrossBatch& ab, int nz, hipStream_t s
             items = it > items ? it : items;
         }
         dim3 gridf(grid.x, grid.y + (unsigned)((items + (long)block.x * a.B - 1) / ((long)block.x * a.B)), nz);
-        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, NWV>), gridf, block, lds, st, ab);
+        hipLaunchKernelGGL((moka_cross_fwd_kernel<RP, NWF, NWV>), gridf, block, lds, st, ab);
     } else {
         const dim3 gridb(a.B, (a.S + 15) / 16, nz);           // one 16-row tile per block, the four waves split the keys
         const size_t lds = (size_t)((3 + NWV) * 16 + KC) * KP * 4 + (size_t)2 * NWV * 16 * 4 * 4;
