@@ -10,5 +10,7 @@ cd $REPO
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB 40 > gpurun_out/$TAG/kernel_trace.md 2>&1
 python tools/rocpd_timeline.py $DB 0.4 > gpurun_out/$TAG/timeline.md 2>&1
+# graph replays only (the bracketed live passes behind the timed region run the in-chain schedule): dispatches 15 % .. 50 %
+python tools/rocpd_timeline.py $DB 0.85 0.5 > gpurun_out/$TAG/timeline_graph.md 2>&1
 tail -2 gpurun_out/$TAG/prof_run.log | cut -c1-300
 cat gpurun_out/$TAG/timeline.md

@@ -2,7 +2,10 @@
 """Per-dispatch timeline of a rocprofv3 rocpd sqlite result: for every kernel name the summed duration AND the summed gap to
 the end of the previous dispatch (idle time in front of it), over the last `--tail` fraction of the trace.
 
-    python tools/rocpd_timeline.py <results.db> [tail_fraction]
+    python tools/rocpd_timeline.py <results.db> [tail_fraction [skip_fraction]]
+
+skip_fraction: leave out that last part of the trace (bench.py runs bracketed LIVE passes behind the timed graph replays: they use the
+in-chain schedule; a window of graph replays only is e.g. tail 0.8, skip 0.5).
 """
 import re
 import sqlite3
@@ -19,13 +22,13 @@ def demangle(n):
     return re.sub(r"\(.*\)$", "", out).replace("void ", "")
 
 
-def main(path, tail=0.5):
+def main(path, tail=0.5, skip=0.0):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute(f"select start, end, {name_col} from kernels order by start").fetchall()
-    rows = rows[int(len(rows) * (1 - tail)):]
+    rows = rows[int(len(rows) * (1 - tail)):int(len(rows) * (1 - skip))]
     dur, gap, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
     prev_end = rows[0][0]
     for s, e, n in rows:
@@ -34,7 +37,7 @@ def main(path, tail=0.5):
         cnt[n] += 1
         prev_end = max(prev_end, e)
     span = rows[-1][1] - rows[0][0]
-    print(f"# timeline of the last {tail:.0%} of `{path}`: {len(rows)} dispatches over {span/1e6:.3f} ms "
+    print(f"# timeline of the dispatches from {1 - tail:.0%} to {1 - skip:.0%} of `{path}`: {len(rows)} dispatches over {span/1e6:.3f} ms "
           f"(kernels {sum(dur.values())/1e6:.3f} ms, gaps {sum(gap.values())/1e6:.3f} ms)\n")
     print("| kernel | calls | total ms | avg us | gap before: total ms | avg us |")
     print("|---|---:|---:|---:|---:|---:|")
@@ -62,4 +65,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "raw":
         raw(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 60, float(sys.argv[4]) if len(sys.argv) > 4 else 0.5)
     else:
-        main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)
+        main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5, float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
