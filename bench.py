@@ -220,6 +220,7 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
     Tp = _lib.tok_pad(Tc)
     max_ks = max(_lib.ksplit(Tc, ff, r), _lib.ksplit(Tc, d, r), _lib.ksplit_bwd(Tc, ff, r))
     chain_list, keep = [], []
+    shadow_bufs = {}              # (layer, projection) -> (BwT, AT): functions of the weights alone, so every chain reads the same pair
     for ci in range(chains):
         if vt:
             masks = [(tok == 0).reshape(1, S).repeat(Bc, 1).to(dev), (tok == 1).reshape(1, S).repeat(Bc, 1).to(dev), q.reshape(1, S).repeat(Bc, 1).to(dev)]
@@ -252,8 +253,10 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
             members = []
             for pi, pr in enumerate(params[l]):
                 # saved forward -> backward, per projection: h (fp32), the rank-major hp pack, the weight shadows
+                if (l, pi) not in shadow_bufs:
+                    shadow_bufs[(l, pi)] = (torch.empty(RP, pr["d_out"], dtype=bf, device=dev), torch.empty(M, pr["d_in"], RP, dtype=bf, device=dev))
                 members.append(dict(pr, y=ys[pi], h=torch.empty(Tc, RP, dtype=f32, device=dev), hp_kmj=torch.empty(2, RP, Tp, dtype=bf, device=dev),
-                                    BwT=torch.empty(RP, pr["d_out"], dtype=bf, device=dev), AT=torch.empty(M, pr["d_in"], RP, dtype=bf, device=dev)))
+                                    BwT=shadow_bufs[(l, pi)][0], AT=shadow_bufs[(l, pi)][1]))
             for src, pis in unit_defs:
                 mem = [members[pi] for pi in pis]
                 units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch2[len(units) & 1],
@@ -371,7 +374,7 @@ def run_shadows(lib, wl, sp, layers, rec=None):
         _L.check(lib.moka_weight_shadows_batch(*argl, sp), "moka_weight_shadows_batch")
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False):
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False, done_sink=None):
     """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
     defer = (mode, main_stream, side_stream): the dA_m halves of a layer's moka_down_bwd calls leave the dependency chain (only the
     optimizer needs them) and are enqueued after the layer's chain -- "main": on the same stream; "side": on a second stream,
@@ -441,6 +444,8 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
             ev = torch.cuda.Event()
             ev.record(side)
             done[l] = ev
+            if done_sink is not None:
+                done_sink[l] = ev                                # (--chains: the optimizer slice of a bucket waits for EVERY chain's layer)
         if on_layer_done is not None:
             if mode in ("side", "window"):
                 main.wait_event(done[l])                         # (a bucket must not ship before its dA has landed)
@@ -710,6 +715,8 @@ def main():
                     help="fused units: where BwT / AT (functions of the weights alone, read by the backward) are written: opt = where the weights change, "
                          "behind the optimizer update (moka_weight_shadows per gradient bucket on the side / communication stream with --opt-in-backward); "
                          "main = in front of every fused unit on the forward's chain (three-launch units: inside moka_cross_fwd)")
+    ap.add_argument("--probe-forward", action="store_true",
+                    help="also time the forward alone as a hipGraph of its own against the same launches live (HIP events, no profiler) -> `forward_only`")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -770,8 +777,8 @@ def main():
     lib = _lib.load()
     _lib.check(lib.moka_device_check(), "moka_device_check")
     from moka_amd.parallel import FlatGradBucket
-    if args.chains > 1:
-        args.defer_da = "off"                                    # (the part-batch chains already overlap each other)
+    if args.chains > 1 and args.defer_da in ("main", "window"):
+        raise SystemExit("--chains > 1 runs with --defer-da off / side / layer")
     # dB leaves the dependency chain with dA_m where the library computes it in a pass of its own anyway (r > 32)
     global SHADOWS_BATCH
     SHADOWS_BATCH = args.shadows_batch == "on"
@@ -795,7 +802,9 @@ def main():
     L = args.layers
     # the optimizer step per gradient bucket INSIDE the backward (off: one launch behind it): needs the side stream of the deferred dA_m
     # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
-    opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and args.chains == 1 and
+    # (--chains N: every chain defers its dA_m to a side stream of its own; the slice of a bucket goes out on one more stream once the
+    #  bucket's layers have landed in EVERY chain)
+    opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and
                   ((not comm and args.defer_da in ("side", "window", "layer") and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
@@ -842,26 +851,44 @@ def main():
                 #  capture time -- measured round 4 -- so N > 1 and --force-comm use one graph per gradient bucket with the hooks between them)
                 assert not comm, "--graph all: single GPU without collectives only"
                 fwd_bwd_graph = torch.cuda.CUDAGraph()
-                branch = [torch.cuda.Stream(device=dev) for _ in range(args.chains - 1)]
-                da_side = torch.cuda.Stream(device=dev)
+                pri = -1 if args.chain_priority == "high" else 0
+                branch = [torch.cuda.Stream(device=dev, priority=pri) for _ in range(args.chains - 1)]
+                da_sides = [torch.cuda.Stream(device=dev) for _ in range(args.chains)]
+                opt_stream = torch.cuda.Stream(device=dev) if (args.chains > 1 and opt_in_bwd) else None
+                landed = [dict() for _ in range(args.chains)]    # per chain: layer -> event "its chain and its deferred dA_m have been enqueued"
                 with torch.cuda.graph(fwd_bwd_graph, stream=side):
                     cur = torch.cuda.current_stream()
+                    if opt_in_bwd:
+                        # the step's AdamW coefficients, written on the device by a one-thread launch that counts the steps itself:
+                        # every replay advances by one, nothing is read from host memory (FlatAdamW.begin_step)
+                        opt.begin_step(device_counter=True)
+                        opt.t -= 1                   # (the capture is not a step)
                     for st in branch:
                         st.wait_stream(cur)          # fork: the branch streams join the capture
-                    for ch, st in zip(wl["chains"], [cur] + branch):
+                    for ci, (ch, st) in enumerate(zip(wl["chains"], [cur] + branch)):
                         with torch.cuda.stream(st):
                             spg = c_void_p(st.cuda_stream)
-                            if opt_in_bwd and ch is wl["chains"][0]:
-                                # the step's AdamW coefficients, written on the device by a one-thread launch that counts the steps itself:
-                                # every replay advances by one, nothing is read from host memory (FlatAdamW.begin_step)
-                                opt.begin_step(device_counter=True)
-                                opt.t -= 1                   # (the capture is not a step)
                             run_forward(lib, ch, spg, shadows=shadows_main)
-                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_side, args.split_db) if args.defer_da != "off" else None,
-                                         bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None,
-                                         shadows_after_opt=shadows_opt and opt_in_bwd and ch is wl["chains"][0])
+                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_sides[ci], args.split_db) if args.defer_da != "off" else None,
+                                         bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and args.chains == 1) else None,
+                                         shadows_after_opt=shadows_opt and opt_in_bwd and args.chains == 1, done_sink=landed[ci])
                     for st in branch:
                         cur.wait_stream(st)          # join
+                    if opt_stream is not None:
+                        # the chains add into the same gradient accumulators: a bucket's AdamW slice (and its layers' weight shadows for the
+                        # next step) waits for the bucket's first layer in every chain, on a stream of its own, beside the rest of the backward
+                        lpb = bucket.layers_per_bucket
+                        for l in range(L - 1, -1, -1):
+                            if l % lpb:
+                                continue
+                            for ld in landed:
+                                opt_stream.wait_event(ld[l])
+                            blo, bhi = bucket.bucket_bounds(l)
+                            with torch.cuda.stream(opt_stream):
+                                opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
+                                if shadows_opt:
+                                    run_shadows(lib, wl, c_void_p(opt_stream.cuda_stream), range(l, min(L, l + lpb)))
+                        cur.wait_stream(opt_stream)
             else:
                 da_side = torch.cuda.Stream(device=dev)
                 fwd_graph = torch.cuda.CUDAGraph()       # the forward has no hooks: one graph
@@ -878,6 +905,8 @@ def main():
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
+            if args.chains > 1:
+                raise SystemExit(f"bench: hipGraph capture failed ({exc!r}) and --chains {args.chains} exists only as branches of the one graph")
             print(f"bench: hipGraph capture failed ({exc!r}); launching live", file=sys.stderr)
             fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
             torch.cuda.synchronize()
@@ -923,7 +952,7 @@ def main():
             bucket.finish(average=opt is None)       # join the all-reduces; the optimizer kernel averages (grad_scale)
         if opt is not None and not opt_in_bwd:
             opt.step(grad_scale=1.0 / world, zero_grad=True)
-        if shadows_opt and opt is not None and not (opt_in_bwd and not comm) and not shadows_in_cb:
+        if shadows_opt and opt is not None and not (opt_in_bwd and not comm and (fwd_bwd_graph is not None or args.chains == 1)) and not shadows_in_cb:
             run_shadows(lib, wl, sp, range(L))       # (every weight has changed: the shadows of the whole stack, behind the step)
 
     for i in range(args.warmup):
@@ -987,6 +1016,36 @@ def main():
             run_shadows(lib, wl, sp_, range(L), extra)
         torch.cuda.synchronize()
         tot_x, cnt_x, byt_x, per_shape_x = collect(extra.items)
+        # the forward alone, replayed as a hipGraph of its own against the same launches live: HIP events around whole passes, no
+        # profiler (profiles/README.md: do the 8-25 us gaps rocprofv3 shows in front of the forward kernels of a graph replay exist?)
+        fwd_only = None
+        if args.probe_forward and args.chains == 1:
+            try:
+                pst = torch.cuda.Stream(device=dev, priority=-1 if args.chain_priority == "high" else 0)
+                with torch.cuda.stream(pst):
+                    run_forward(lib, wl, c_void_p(pst.cuda_stream), shadows=shadows_main)
+                torch.cuda.synchronize()
+                fg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fg, stream=pst):
+                    run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), shadows=shadows_main)
+                torch.cuda.synchronize()
+
+                def _timed(fn, n=6):
+                    fn()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(n):
+                        fn()
+                    b.record()
+                    torch.cuda.synchronize()
+                    return a.elapsed_time(b) / n
+                g_ms = _timed(fg.replay)
+                l_ms = _timed(lambda: run_forward(lib, wl, sp_, None, shadows=shadows_main))
+                fwd_only = {"graph_ms": round(g_ms, 3), "live_ms": round(l_ms, 3), "launches": sum(2 if u.fused else 3 for u in units_all),
+                            "what": "forward pass alone, 6 passes between two HIP events: replay of a forward-only hipGraph vs the same launches live"}
+                del fg
+            except Exception as exc:                 # a probe, never a requirement
+                fwd_only = {"error": repr(exc)}
         live_items = records.items
         table = {}
         for (n, label, di, dos), (ms, c_, nb) in sorted(per_shape_x.items()):
@@ -1068,6 +1127,7 @@ def main():
                          "where": ("live passes right behind the timed region (the timed region replays a hipGraph: nothing can be bracketed inside it)"
                                    if roof_behind else "HIP events inside the timed region (every %d-th launch)" % args.bracket_every)},
             "entry_point_ms_per_pass": {n: round(tot_x[n], 3) for n in ENTRY},
+            "forward_only": fwd_only,
             "kernels": table,
         }
         if world == 1 and args.e2e:
