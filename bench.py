@@ -247,7 +247,9 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
         scratch = scratch2[0]
         units = []
         defer = getattr(args, "defer_da", "off") != "off"
-        own = [[[torch.empty(M, 2, RP, Tp, dtype=bf, device=dev) for _ in pis] for _, pis in unit_defs] for _ in range(2)] if defer else None
+        # (the deferred dA_m launches read a layer's packs a layer -- "bucket": a whole gradient bucket of layers -- later: 2 / L sets of them)
+        n_own = L if (getattr(args, "defer_da", "off") == "bucket" or getattr(args, "hub", False)) else 2
+        own = [[[torch.empty(M, 2, RP, Tp, dtype=bf, device=dev) for _ in pis] for _, pis in unit_defs] for _ in range(n_own)] if defer else None
         for l in range(L):
             acts, dacts, ys = sets[l % nset]
             members = []
@@ -262,7 +264,7 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                 units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch2[len(units) & 1],
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
-                                  own_dh_kmj=own[l & 1][len(units) % len(unit_defs)] if defer else None, fused=fused))
+                                  own_dh_kmj=own[l % n_own][len(units) % len(unit_defs)] if defer else None, fused=fused))
         layer_da, layer_db = [], []
         if defer:
             per = len(unit_defs)
@@ -278,9 +280,9 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                 layer_db.append(((c_void_p * n)(*[it[0].data_ptr() for it in dbi]), (c_void_p * n)(*[it[1].data_ptr() for it in dbi]),
                                  (ctypes.c_int * n)(*[it[2] for it in dbi]), rt.tok_mod.data_ptr(), (c_void_p * n)(*[it[3].data_ptr() for it in dbi]),
                                  n, Tc, r, M, 0, None))
-        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db, rank=r))
+        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db, rank=r, reuse_wait=(n_own < L)))
         keep.append((sets, masks, scratch2, own))
-    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], rank=r, chains=chain_list, master=master, work=work,
+    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], rank=r, chains=chain_list, master=master, work=work, reuse_wait=chain_list[0]["reuse_wait"],
                 gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
@@ -374,11 +376,14 @@ def run_shadows(lib, wl, sp, layers, rec=None):
         _L.check(lib.moka_weight_shadows_batch(*argl, sp), "moka_weight_shadows_batch")
 
 
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False, done_sink=None):
+def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False, state=None, join=True,
+                 flush=False):
     """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
     defer = (mode, main_stream, side_stream): the dA_m halves of a layer's moka_down_bwd calls leave the dependency chain (only the
     optimizer needs them) and are enqueued after the layer's chain -- "main": on the same stream; "side": on a second stream,
-    beside the NEXT layer's chain (whose rank-space kernels leave most of the chip idle), joined before the gradients are used."""
+    beside the NEXT layer's chain (whose rank-space kernels leave most of the chip idle), joined before the gradients are used.
+    state / join: the walk in pieces (--chains captures the chains layer by layer, interleaved): `state` carries the buffer-reuse events
+    from call to call, join=False leaves the side stream unjoined."""
     units, per = wl["units"], wl["units_per_layer"]
     if defer is None:
         for l in range(n_layers - 1, lo - 1, -1):
@@ -393,17 +398,64 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
     split_db = len(defer) > 3 and defer[3]                       # dB off the chain too (where it is a pass of its own)
     up = "moka_up_bwd:g" if split_db else "moka_up_bwd"
     sps = c_void_p(side.cuda_stream)
-    done = {}                                                    # layer -> event "its deferred dA launches have finished" (side mode)
+    done = state if state is not None else {}                    # layer -> event "its deferred dA launches have finished" (side mode)
+    flush_at = None
     if mode == "layer":
         mode, batched = "side", True                             # the side schedule with ONE dA launch per layer
+    elif mode == "bucket":
+        # one fork per gradient BUCKET of layers (every cross-stream edge of a hipGraph costs its replay host time): the batched dA launches
+        # of the bucket's layers go out together when its first layer's chain has been enqueued; every layer owns its pack buffers
+        mode, batched, flush_at = "side", True, defer[4]
     else:
         batched = False
+    held = []                                                    # layers whose deferred launches wait for the bucket's flush
+    # CHAIN_FIRST (captures only): a layer's side-stream launches are enqueued AFTER the first launch of the next layer's chain.  The DAG is
+    # the same; what changes is the order of a fork node's out-edges, and the hipGraph executor (ROCm 7.2) derives its execution streams
+    # from a depth-first walk that follows the FIRST out-edge: side-first lets the walk leave the chain at every fork
+    reuse = wl.get("reuse_wait", True) and flush_at is None      # (pack buffers of layer l + 2 reused by layer l: the chain waits for that dA)
+    late = CHAIN_FIRST and on_layer_done is None and mode == "side"
+    post = done.pop("post", None) if late else None              # (layer, held layers, event on main) of the fork not yet emitted
+
+    def emit(l, held_, ev_main, pending_u):
+        side.wait_event(ev_main)
+        for u in reversed(units[l * per:(l + 1) * per]):
+            if split_db and not batched:
+                _call(lib, "moka_up_bwd:dB", u, sps, None)
+            if batched or (mode == "window" and u is not pending_u):
+                continue                                        # (already out, beside the next unit's rank-space backward)
+            _call(lib, "moka_down_bwd:dA", u, sps, None)
+        if batched:
+            from moka_amd import _lib as _L
+            for ll in held_ + [l]:
+                if split_db:
+                    _L.check(lib.moka_up_bwd_db_batch(*wl["layer_db"][ll], sps), "moka_up_bwd_db_batch")
+                _L.check(lib.moka_down_bwd_da_batch(*wl["layer_da"][ll], sps), "moka_down_bwd_da_batch")
+        if bucket_opt is not None and mode in ("side", "window"):
+            # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the
+            # update of the finished layers overlaps the backward of the earlier ones (FlatAdamW.step_range, coefficients in device memory)
+            opt_, bucket_, scale_ = bucket_opt
+            if bucket_.is_bucket_first(l):
+                blo, bhi = bucket_.bucket_bounds(l)
+                with torch.cuda.stream(side):
+                    opt_.step_range(blo, bhi, grad_scale=scale_, zero_grad=True)
+                    if shadows_after_opt:
+                        # the bucket's weights have just changed: their shadows for the NEXT step's backward, still off the chain
+                        run_shadows(lib, wl, sps, bucket_.bucket_layers(l))
+        ev = torch.cuda.Event()
+        ev.record(side)
+        done[l] = ev
+
     for l in range(n_layers - 1, lo - 1, -1):
-        if mode in ("side", "window") and (l + 2) in done:
+        if not late and reuse and mode in ("side", "window") and (l + 2) in done:
             main.wait_event(done.pop(l + 2))                     # layer l reuses the pack buffers of layer l + 2
         pending = None
         for u in reversed(units[l * per:(l + 1) * per]):
             _call(lib, up, u, sp, rec)
+            if post is not None:
+                emit(*post)                                      # the layer before's fork, behind this layer's first launch (CHAIN_FIRST)
+                post = None
+            if late and pending is None and reuse and (l + 2) in done:
+                main.wait_event(done.pop(l + 2))                 # (the first writer of the reused pack buffers is this unit's rank-space backward)
             if mode == "window" and pending is not None:
                 # the dA of the unit before goes out HERE, so that it starts with this unit's rank-space backward -- the two launches of
                 # the chain that leave the memory system idle (a unit's dA moves about as many bytes as that window could)
@@ -417,41 +469,30 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
                 if split_db:
                     _call(lib, "moka_up_bwd:dB", u, sp, None)
                 _call(lib, "moka_down_bwd:dA", u, sp, None)
+        elif flush_at is not None and not flush_at(l) and l > lo:
+            held.append(l)                                       # (leaves with its bucket's first layer)
         else:
-            side.wait_stream(main)
-            for u in reversed(units[l * per:(l + 1) * per]):
-                if split_db and not batched:
-                    _call(lib, "moka_up_bwd:dB", u, sps, None)
-                if batched or (mode == "window" and u is not pending):
-                    continue                                        # (already out, beside the next unit's rank-space backward)
-                _call(lib, "moka_down_bwd:dA", u, sps, None)
-            if batched:
-                from moka_amd import _lib as _L
-                if split_db:
-                    _L.check(lib.moka_up_bwd_db_batch(*wl["layer_db"][l], sps), "moka_up_bwd_db_batch")
-                _L.check(lib.moka_down_bwd_da_batch(*wl["layer_da"][l], sps), "moka_down_bwd_da_batch")
-            if bucket_opt is not None and mode in ("side", "window"):
-                # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the
-                # update of the finished layers overlaps the backward of the earlier ones (FlatAdamW.step_range, coefficients in device memory)
-                opt_, bucket_, scale_ = bucket_opt
-                if l % bucket_.layers_per_bucket == 0:
-                    blo, bhi = bucket_.bucket_bounds(l)
-                    with torch.cuda.stream(side):
-                        opt_.step_range(blo, bhi, grad_scale=scale_, zero_grad=True)
-                        if shadows_after_opt:
-                            # the bucket's weights have just changed: their shadows for the NEXT step's backward, still off the chain
-                            run_shadows(lib, wl, sps, range(l, min(n_layers, l + bucket_.layers_per_bucket)))
-            ev = torch.cuda.Event()
-            ev.record(side)
-            done[l] = ev
-            if done_sink is not None:
-                done_sink[l] = ev                                # (--chains: the optimizer slice of a bucket waits for EVERY chain's layer)
+            ev_main = torch.cuda.Event()
+            ev_main.record(main)
+            if late:
+                post = (l, held, ev_main, pending)
+            else:
+                emit(l, held, ev_main, pending)
+            held = []
         if on_layer_done is not None:
-            if mode in ("side", "window"):
+            if mode in ("side", "window") and l in done:
                 main.wait_event(done[l])                         # (a bucket must not ship before its dA has landed)
             on_layer_done(l)
-    if mode in ("side", "window"):
+    if post is not None:
+        if join or flush or lo == 0:
+            emit(*post)                                          # nothing follows on the chain
+        else:
+            done["post"] = post                                  # (the next piece of the walk emits it)
+    if mode in ("side", "window") and join:
         main.wait_stream(side)
+
+
+CHAIN_FIRST = True            # --capture-order side-first: A/B
 
 
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
@@ -680,13 +721,14 @@ def main():
                          "of a layer, so the sample covers them evenly)")
     ap.add_argument("--comm-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (153 instead of 306 MB per step at 7B r=16; accumulation stays fp32)")
     ap.add_argument("--no-traffic", action="store_true", help="leave roofline.traffic null instead of reading the PMC summary under profiles/")
-    ap.add_argument("--chains", type=int, default=1,
-                    help="process the micro-batch as this many part-batches (batch / chains sequences each) whose launch chains run on "
-                         "separate HIP streams of the one hipGraph: nothing in the model mixes tokens of different samples, so the chains "
-                         "are independent, and the fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide "
-                         "behind the streaming kernels of the other.  Single GPU with --graph all only; per-kernel durations (`roofline`, "
-                         "`kernels`) are then taken with the chains back to back on one stream")
-    ap.add_argument("--defer-da", choices=("off", "main", "side", "window", "layer"), default="layer",
+    ap.add_argument("--chains", type=int, default=0,
+                    help="process the micro-batch as this many part-batches (batch / chains sequences each) whose launch chains are branches of "
+                         "the captured graph(s): nothing in the model mixes tokens of different samples, so the chains are independent, and the "
+                         "fixed costs of one (kernel boundaries, ramps, the latency-bound rank-space kernels) hide behind the streaming kernels "
+                         "of the other; they share the parameters, the gradient accumulators and the optimizer slices.  0 (default) = 2 where the "
+                         "batch splits evenly and the step is replayed as graphs, else 1.  Per-kernel durations (`roofline`, `kernels`) are "
+                         "taken with the chains back to back on one stream")
+    ap.add_argument("--defer-da", choices=("off", "main", "side", "window", "layer", "bucket"), default="layer",
                     help="the dA_m halves of moka_down_bwd are needed by the optimizer only: layer (default, what moka_amd.parallel.attach does) = "
                          "a layer's worth of them goes out as ONE launch (moka_down_bwd_da_batch: 4 -> 1 launches per layer) on a second stream when "
                          "the layer's chain has been enqueued, and runs beside the next layer's chain (joined before a gradient bucket ships and before "
@@ -715,6 +757,14 @@ def main():
                     help="fused units: where BwT / AT (functions of the weights alone, read by the backward) are written: opt = where the weights change, "
                          "behind the optimizer update (moka_weight_shadows per gradient bucket on the side / communication stream with --opt-in-backward); "
                          "main = in front of every fused unit on the forward's chain (three-launch units: inside moka_cross_fwd)")
+    ap.add_argument("--graph-topology", choices=("auto", "hub", "chain"), default="auto",
+                    help="shape of the one captured graph: hub (default) = the chain(s) on forked streams, everything off the chains (deferred dA_m, optimizer "
+                         "slices, weight shadows) on the capture's origin stream, no edge from the hub back into a chain (every layer owns its pack "
+                         "buffers) -- the hipGraph executor then runs 1 + chains lists; chain = round 4's shape (the chain on the origin, a side stream "
+                         "forked and joined per layer)")
+    ap.add_argument("--capture-order", choices=("chain-first", "side-first"), default="chain-first",
+                    help="order in which a fork's two successors are captured (same DAG): the hipGraph executor follows a fork node's FIRST out-edge "
+                         "when it cuts the graph into execution streams")
     ap.add_argument("--probe-forward", action="store_true",
                     help="also time the forward alone as a hipGraph of its own against the same launches live (HIP events, no profiler) -> `forward_only`")
     ap.add_argument("--no-group", action="store_true",
@@ -724,6 +774,14 @@ def main():
         args.layers = MODELS[args.model]["layers"]
     if args.graph == "auto":
         args.graph = "all" if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.force_comm) else "bwd"
+    if args.chains == 0:
+        # auto: two part-batch chains where the step is replayed as hipGraphs, the batch splits evenly and the launches are short enough to
+        # leave gaps (7B widths, rank pad <= 32: 32.2 -> 30.5 ms at r = 16, 41.7 -> 40.9 at r = 32; the 70B widths lose, 160.3 -> 166.1 ms, and
+        # so does rank 64 at the 13B widths, 78.6 -> 79.5: their launches fill the chip on their own)
+        args.chains = 2 if (args.graph != "off" and args.batch % 2 == 0 and args.model == "7b" and args.rank <= 32) else 1
+    if args.graph_topology == "auto":
+        args.graph_topology = "hub" if args.chains > 1 else "chain"      # (one chain: 32.15-32.27 ms in round 4's shape, 32.39 as hub + 1 chain)
+    args.hub = args.graph != "off" and (args.graph_topology == "hub" or args.chains > 1)
     if args.chain_priority == "auto":
         args.chain_priority = "high" if args.graph == "all" else "normal"
 
@@ -777,14 +835,15 @@ def main():
     lib = _lib.load()
     _lib.check(lib.moka_device_check(), "moka_device_check")
     from moka_amd.parallel import FlatGradBucket
-    if args.chains > 1 and args.defer_da in ("main", "window"):
-        raise SystemExit("--chains > 1 runs with --defer-da off / side / layer")
+    if args.chains > 1 and args.defer_da == "window":
+        raise SystemExit("--chains > 1 runs with --defer-da off / main / side / layer / bucket")
     # dB leaves the dependency chain with dA_m where the library computes it in a pass of its own anyway (r > 32)
-    global SHADOWS_BATCH
+    global SHADOWS_BATCH, CHAIN_FIRST
     SHADOWS_BATCH = args.shadows_batch == "on"
+    CHAIN_FIRST = args.capture_order == "chain-first"
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
-    if args.chains > 1 and (comm or args.graph != "all"):
-        raise SystemExit("--chains > 1 needs a single GPU and --graph all (the chains are branches of the one captured graph)")
+    if args.chains > 1 and args.graph == "off":
+        raise SystemExit("--chains > 1 exists as branches of captured graphs (--graph all / bwd)")
     wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None,
                                                                        force_comm=args.force_comm),
                         chains=args.chains)
@@ -805,7 +864,8 @@ def main():
     # (--chains N: every chain defers its dA_m to a side stream of its own; the slice of a bucket goes out on one more stream once the
     #  bucket's layers have landed in EVERY chain)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and
-                  ((not comm and args.defer_da in ("side", "window", "layer") and args.graph in ("auto", "all", "off")) or (comm and not args.comm_bf16)))
+                  ((not comm and (args.defer_da in ("side", "window", "layer", "bucket") or args.chains > 1) and args.graph in ("auto", "all", "off"))
+                   or (comm and not args.comm_bf16)))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
     shadows_main = bool(args.fused and args.shadows == "main")
@@ -846,62 +906,121 @@ def main():
                     run_forward(lib, ch, spw)
                     run_backward(lib, ch, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
             torch.cuda.synchronize()
+            pri = -1 if args.chain_priority == "high" else 0
+            anchor = torch.zeros(64, device=dev)
+
+            def capture_hub(graph, forward, pieces, with_opt):
+                """One graph in the hub shape: the N part-batch chains on N forked streams, everything off the chains (every chain's deferred
+                dA_m / dB launches, the optimizer slices, the weight shadows) on the capture's origin stream.
+                * hipStreamEndCapture (ROCm 7.2) segfaults on ANY dependency between two streams that are both forks
+                  (tools/probes/capture_topology.py): every edge has to touch the origin, so the origin is the hub;
+                * the executor does not run a graph on the capture's streams: it cuts the DAG into lists by a depth-first walk from the roots
+                  that follows every node's FIRST out-edge, gives every list a stream of its own and maps those onto a handful of in-order
+                  hardware queues (a list that waits for another list blocks whatever shares its queue).  Round 4's side-first forks made
+                  every layer's dA_m a list of its own and cut the chain at every fork.  This graph is SHAPED for that walk: the hub's
+                  launches are the root's first path (an anchor node captured in front of the forks' first launches), nothing on a chain ever
+                  waits for the hub (every layer owns its pack buffers: no reuse edges), so the walk yields exactly 1 + N lists;
+                * the walk of the backward is captured piece by piece (a layer; --defer-da bucket: a gradient bucket), chain by chain, so that
+                  the hub's stream order is "piece p of every chain, then the bucket's optimizer slice"."""
+                hub = torch.cuda.Stream(device=dev)
+                branch = [torch.cuda.Stream(device=dev, priority=pri) for _ in wl["chains"]]
+                with torch.cuda.graph(graph, stream=hub):
+                    cur = torch.cuda.current_stream()
+                    if with_opt:
+                        # the step's AdamW coefficients, written on the device by a one-thread launch that counts the steps itself:
+                        # every replay advances by one, nothing is read from host memory (FlatAdamW.begin_step)
+                        opt.begin_step(device_counter=True)
+                        opt.t -= 1                       # (the capture is not a step)
+                    else:
+                        anchor.zero_()                   # (the root)
+                    for st in branch:
+                        st.wait_stream(cur)              # fork
+                    anchor.zero_()                       # the root's FIRST successor is on the hub: the walk runs down the hub before it sees a chain
+                    if forward:
+                        for ch, st in zip(wl["chains"], branch):
+                            run_forward(lib, ch, c_void_p(st.cuda_stream), shadows=shadows_main)
+                    states = [dict() for _ in branch]
+                    pend_opt = None
+
+                    def hub_opt(lb, evs):
+                        # the chains add into the same gradient accumulators: the bucket's AdamW slice (and its layers' weight shadows for
+                        # the next step) goes out on the hub, behind the dA_m launches of the bucket's first layer of EVERY chain
+                        for ev in evs:
+                            cur.wait_event(ev)           # (the in-chain gradients of the layer: dB rides with the pass over gy)
+                        blo, bhi = bucket.bucket_bounds(lb)
+                        opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
+                        if shadows_opt:
+                            run_shadows(lib, wl, c_void_p(cur.cuda_stream), bucket.bucket_layers(lb))
+                    for pi_, (l, l_hi) in enumerate(pieces):
+                        for ch, st, stt in zip(wl["chains"], branch, states):
+                            run_backward(lib, ch, c_void_p(st.cuda_stream), l_hi, lo=l, state=stt, join=False, flush=pi_ == len(pieces) - 1,
+                                         defer=(args.defer_da, st, cur, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None)
+                        if pend_opt is not None:
+                            hub_opt(*pend_opt)           # (chain-first: behind the first launches of the chains' next piece)
+                            pend_opt = None
+                        if with_opt and bucket.is_bucket_first(l):
+                            evs = []
+                            for st in branch:
+                                ev = torch.cuda.Event()
+                                ev.record(st)
+                                evs.append(ev)
+                            if CHAIN_FIRST and pi_ < len(pieces) - 1:
+                                pend_opt = (l, evs)
+                            else:
+                                hub_opt(l, evs)
+                    for st in branch:
+                        cur.wait_stream(st)              # join
+                return hub, branch                       # (kept alive with the graph)
+
+            def pieces_of(lo_, hi_):
+                # (pieces of the walk: a layer; with --defer-da bucket a whole gradient bucket, whose dA_m launches leave together)
+                if args.defer_da == "bucket":
+                    return [(f, bucket.bucket_layers(f).stop) for f in reversed(bucket.bucket_firsts()) if lo_ <= f < hi_]
+                return [(l, l + 1) for l in range(hi_ - 1, lo_ - 1, -1)]
+
+            graph_keep = []
             if args.graph == "all":
                 # (collectives cannot ride inside the graph: capturing the one-rank RCCL all-reduce with torch 2.10 / RCCL 2.26.6 segfaults at
                 #  capture time -- measured round 4 -- so N > 1 and --force-comm use one graph per gradient bucket with the hooks between them)
                 assert not comm, "--graph all: single GPU without collectives only"
                 fwd_bwd_graph = torch.cuda.CUDAGraph()
-                pri = -1 if args.chain_priority == "high" else 0
-                branch = [torch.cuda.Stream(device=dev, priority=pri) for _ in range(args.chains - 1)]
-                da_sides = [torch.cuda.Stream(device=dev) for _ in range(args.chains)]
-                opt_stream = torch.cuda.Stream(device=dev) if (args.chains > 1 and opt_in_bwd) else None
-                landed = [dict() for _ in range(args.chains)]    # per chain: layer -> event "its chain and its deferred dA_m have been enqueued"
-                with torch.cuda.graph(fwd_bwd_graph, stream=side):
-                    cur = torch.cuda.current_stream()
-                    if opt_in_bwd:
-                        # the step's AdamW coefficients, written on the device by a one-thread launch that counts the steps itself:
-                        # every replay advances by one, nothing is read from host memory (FlatAdamW.begin_step)
-                        opt.begin_step(device_counter=True)
-                        opt.t -= 1                   # (the capture is not a step)
-                    for st in branch:
-                        st.wait_stream(cur)          # fork: the branch streams join the capture
-                    for ci, (ch, st) in enumerate(zip(wl["chains"], [cur] + branch)):
-                        with torch.cuda.stream(st):
-                            spg = c_void_p(st.cuda_stream)
-                            run_forward(lib, ch, spg, shadows=shadows_main)
-                            run_backward(lib, ch, spg, L, defer=(args.defer_da, st, da_sides[ci], args.split_db) if args.defer_da != "off" else None,
-                                         bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and args.chains == 1) else None,
-                                         shadows_after_opt=shadows_opt and opt_in_bwd and args.chains == 1, done_sink=landed[ci])
-                    for st in branch:
-                        cur.wait_stream(st)          # join
-                    if opt_stream is not None:
-                        # the chains add into the same gradient accumulators: a bucket's AdamW slice (and its layers' weight shadows for the
-                        # next step) waits for the bucket's first layer in every chain, on a stream of its own, beside the rest of the backward
-                        lpb = bucket.layers_per_bucket
-                        for l in range(L - 1, -1, -1):
-                            if l % lpb:
-                                continue
-                            for ld in landed:
-                                opt_stream.wait_event(ld[l])
-                            blo, bhi = bucket.bucket_bounds(l)
-                            with torch.cuda.stream(opt_stream):
-                                opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
-                                if shadows_opt:
-                                    run_shadows(lib, wl, c_void_p(opt_stream.cuda_stream), range(l, min(L, l + lpb)))
-                        cur.wait_stream(opt_stream)
-            else:
+                if not args.hub:
+                    da_side = torch.cuda.Stream(device=dev)
+                    with torch.cuda.graph(fwd_bwd_graph, stream=side):
+                        cur = torch.cuda.current_stream()
+                        spg = c_void_p(cur.cuda_stream)
+                        if opt_in_bwd:
+                            opt.begin_step(device_counter=True)
+                            opt.t -= 1                   # (the capture is not a step)
+                        run_forward(lib, wl, spg, shadows=shadows_main)
+                        run_backward(lib, wl, spg, L, defer=(args.defer_da, cur, da_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None,
+                                     bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None, shadows_after_opt=shadows_opt and opt_in_bwd)
+                else:
+                    graph_keep.append(capture_hub(fwd_bwd_graph, True, pieces_of(0, L), opt_in_bwd))
+            elif not args.hub:
                 da_side = torch.cuda.Stream(device=dev)
                 fwd_graph = torch.cuda.CUDAGraph()       # the forward has no hooks: one graph
                 with torch.cuda.graph(fwd_graph, stream=side):
                     run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), shadows=shadows_main)
-                lpb = bucket.layers_per_bucket
                 bwd_graphs = []
-                for hi in range(L, 0, -lpb):             # buckets are aligned groups of layers, walked last -> first
-                    lo = max(0, (hi - 1) // lpb * lpb)
+                for lo in reversed(bucket.bucket_firsts()):      # buckets are contiguous groups of layers, walked last -> first
+                    hi = bucket.bucket_layers(lo).stop
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
                         cs = torch.cuda.current_stream()
-                        run_backward(lib, wl, c_void_p(cs.cuda_stream), hi, lo=lo, defer=(args.defer_da, cs, da_side, args.split_db) if args.defer_da != "off" else None)
+                        run_backward(lib, wl, c_void_p(cs.cuda_stream), hi, lo=lo,
+                                     defer=(args.defer_da, cs, da_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None)
+                    bwd_graphs.append((g, lo, hi))
+            else:
+                # N > 1 with part-batch chains: the forward as one hub-shaped graph, one hub-shaped graph per gradient bucket of the backward (the
+                # chains meet at every graph's end: that is where the bucket's all-reduce is handed to RCCL)
+                fwd_graph = torch.cuda.CUDAGraph()
+                graph_keep.append(capture_hub(fwd_graph, True, [], False))
+                bwd_graphs = []
+                for lo in reversed(bucket.bucket_firsts()):
+                    hi = bucket.bucket_layers(lo).stop
+                    g = torch.cuda.CUDAGraph()
+                    graph_keep.append(capture_hub(g, False, pieces_of(lo, hi), False))
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
@@ -939,7 +1058,7 @@ def main():
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
                 run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
-                             defer=(args.defer_da, main_stream, live_side, args.split_db) if args.defer_da != "off" else None,
+                             defer=(args.defer_da, main_stream, live_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None,
                              bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and not comm) else None,
                              shadows_after_opt=shadows_opt and opt_in_bwd and not comm)
         if comm_ev is not None and i >= args.warmup:
@@ -975,6 +1094,22 @@ def main():
         el = tt.item()
     ms_per_step = el * 1e3 / args.steps
     tokens_per_s = world * T * args.steps / el
+
+    # host side of a replay: how long hipGraphLaunch keeps the launching thread for ONE step (idle GPU in front of it, so nothing blocks on
+    # a full queue) against the step on the GPU -- a multi-branch graph is replayed node by node, and a step whose replay takes the host
+    # longer than the GPU needs is host-bound
+    replay_host_ms = None
+    if fwd_bwd_graph is not None and rank == 0:
+        hs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            fwd_bwd_graph.replay()
+            hs.append((time.perf_counter() - th) * 1e3)
+            torch.cuda.synchronize()
+            if opt_in_bwd:
+                opt.t += 1
+        replay_host_ms = round(min(hs), 3)
 
     out = None
     if rank == 0:
@@ -1109,7 +1244,7 @@ def main():
                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
                             "adapter_params": wl["n_params"]},
-            "graph": args.graph,
+            "graph": args.graph, "graph_replay_host_ms": replay_host_ms,
             "fused_forward": ("all units" if all(u.fused for u in units_all) else ("units " + ", ".join(sorted({u.label for u in units_all if u.fused})) if any(u.fused for u in units_all) else False)) if args.fused else False,
             "chains": args.chains,
             "defer_dA": args.defer_da,

@@ -32,8 +32,12 @@ class FlatGradBucket:
     """Flat fp32 gradient buffer + per-layer slice boundaries + bucketed asynchronous all-reduce."""
 
     def __init__(self, numel: int, layer_end: Sequence[int], device, n_buckets: int = 8,
-                 process_group=None, dtype=torch.float32, comm_dtype: Optional[torch.dtype] = None, force_comm: bool = False):
-        """comm_dtype: payload type of the all-reduce (None = the buffer's own fp32).  torch.bfloat16 halves the bytes on
+                 process_group=None, dtype=torch.float32, comm_dtype: Optional[torch.dtype] = None, force_comm: bool = False,
+                 tail_layers: Optional[int] = None):
+        """tail_layers: the backward walks the layers last -> first, so the bucket that holds layer 0 is the one whose all-reduce nothing
+        is left to hide; ``tail_layers = t`` makes that bucket layers [0, t) and splits the other layers evenly over the remaining
+        ``n_buckets - 1`` buckets (None: ``n_buckets`` equal groups) -- the exposed tail of the step is one small collective.
+        comm_dtype: payload type of the all-reduce (None = the buffer's own fp32).  torch.bfloat16 halves the bytes on
         xGMI (7B r=16: 153 instead of 306 MB per step -- the figure SURVEY.md 8(e) sized): a bucket is rounded to bf16 into a
         staging buffer, summed there and widened back; accumulation across micro-batches stays fp32.
         force_comm: run the collectives even in a process group of ONE rank (default: a single rank short-circuits them).  A
@@ -52,6 +56,15 @@ class FlatGradBucket:
             raise RuntimeError("FlatGradBucket(force_comm=True) needs an initialised process group (one rank is enough)")
         self.comm = self.world > 1 or bool(force_comm)      # do the collectives run?
         self.layers_per_bucket = max(1, -(-self.n_layers // max(1, n_buckets)))
+        # buckets = contiguous groups of layers [first, end); a bucket ships when its FIRST layer reports (layers arrive last -> first)
+        if tail_layers is not None and 0 < int(tail_layers) < self.n_layers and n_buckets > 1:
+            t = int(tail_layers)
+            per = max(1, -(-(self.n_layers - t) // (n_buckets - 1)))
+            firsts = [0] + list(range(t, self.n_layers, per))
+            self.layers_per_bucket = per             # (the even groups; the tail bucket is smaller)
+        else:
+            firsts = list(range(0, self.n_layers, self.layers_per_bucket))
+        self._bucket_end = {f: (firsts[i + 1] if i + 1 < len(firsts) else self.n_layers) for i, f in enumerate(firsts)}
         self.is_cuda = self.flat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and self.comm) else None
         self.on_reduced = None       # callable(lo, hi), run on the communication stream behind a bucket's all-reduce (fp32 payload only)
@@ -62,11 +75,27 @@ class FlatGradBucket:
         lo = self.layer_end[l - 1] if l > 0 else 0
         return self.flat[lo:self.layer_end[l]]
 
+    def is_bucket_first(self, l: int) -> bool:
+        """Is l the first (lowest) layer of a bucket, i.e. the layer whose backward completes the bucket?"""
+        return l in self._bucket_end
+
+    def bucket_layers(self, l: int) -> range:
+        """The layers of the bucket whose FIRST layer is l."""
+        return range(l, self._bucket_end[l])
+
+    def bucket_firsts(self) -> List[int]:
+        return sorted(self._bucket_end)
+
     def bucket_bounds(self, l: int):
-        """Slice [lo, hi) of the bucket whose FIRST layer is l (buckets are aligned groups of layers)."""
-        hi_layer = min(self.n_layers, l + self.layers_per_bucket)
+        """Slice [lo, hi) of the bucket whose FIRST layer is l (buckets are contiguous groups of layers)."""
+        hi_layer = self._bucket_end[l]
         lo = self.layer_end[l - 1] if l > 0 else 0
         return lo, self.layer_end[hi_layer - 1]
+
+    def last_bucket_bytes(self) -> int:
+        """Payload of the bucket that ships last (the one that holds layer 0): what the step's exposed communication tail moves."""
+        lo, hi = self.bucket_bounds(0)
+        return (hi - lo) * (self._stage.element_size() if self._stage is not None else self.flat.element_size())
 
     def zero_(self):
         self.flat.zero_()
@@ -74,7 +103,7 @@ class FlatGradBucket:
     # ---------------------------------------------------------------- backward hooks
     def layer_done(self, l: int):
         """Call after layer l's backward launches are enqueued (layers arrive last -> first)."""
-        if not self.comm or (l % self.layers_per_bucket) != 0:
+        if not self.comm or not self.is_bucket_first(l):
             return
         lo, hi = self.bucket_bounds(l)
         sl = self.flat[lo:hi]
@@ -86,20 +115,39 @@ class FlatGradBucket:
                 if self._stage is not None:
                     st = self._stage[lo:hi]
                     st.copy_(sl)                                   # fp32 -> bf16 on the side stream
-                    self._pending.append((dist.all_reduce(st, group=self.group, async_op=True), lo, hi))
+                    wk = dist.all_reduce(st, group=self.group, async_op=True)
+                    if self.on_reduced is not None:
+                        wk.wait()
+                        sl.copy_(st)                               # the summed bf16 payload widened back, still on the communication stream
+                        self.on_reduced(lo, hi)                    # (the slice's update reads the fp32 buffer as with the fp32 payload)
+                        self._pending.append((wk, lo, hi, True))
+                    else:
+                        self._pending.append((wk, lo, hi, False))
                 else:
                     wk = dist.all_reduce(sl, group=self.group, async_op=True)
                     if self.on_reduced is not None:
                         wk.wait()                                  # (the communication stream waits, not the host)
                         self.on_reduced(lo, hi)                    # e.g. FlatAdamW.step_range: the bucket's update overlaps the rest of the backward
-                    self._pending.append((wk, lo, hi))
+                    self._pending.append((wk, lo, hi, True))
         else:
+            # CPU tensors (gloo; tests): the same order of events, synchronously where a callback needs the sum
             if self._stage is not None:
                 st = self._stage[lo:hi]
                 st.copy_(sl)
-                self._pending.append((dist.all_reduce(st, group=self.group, async_op=True), lo, hi))
+                wk = dist.all_reduce(st, group=self.group, async_op=True)
+                if self.on_reduced is not None:
+                    wk.wait()
+                    sl.copy_(st)
+                    self.on_reduced(lo, hi)
+                    self._pending.append((wk, lo, hi, True))
+                else:
+                    self._pending.append((wk, lo, hi, False))
             else:
-                self._pending.append((dist.all_reduce(sl, group=self.group, async_op=True), lo, hi))
+                wk = dist.all_reduce(sl, group=self.group, async_op=True)
+                if self.on_reduced is not None:
+                    wk.wait()
+                    self.on_reduced(lo, hi)
+                self._pending.append((wk, lo, hi, True))
 
     def finish(self, average: bool = True):
         """Join the outstanding collectives; afterwards ``flat`` holds the (averaged) global gradient."""
@@ -108,16 +156,16 @@ class FlatGradBucket:
         if self.is_cuda:
             done = torch.cuda.Event()
             with torch.cuda.stream(self.comm_stream):
-                for wk, lo, hi in self._pending:
+                for wk, lo, hi, widened in self._pending:
                     wk.wait()
-                    if self._stage is not None:
+                    if self._stage is not None and not widened:
                         self.flat[lo:hi].copy_(self._stage[lo:hi])     # widen the summed payload back
                 done.record(self.comm_stream)
             torch.cuda.current_stream(self.flat.device).wait_event(done)
         else:
-            for wk, lo, hi in self._pending:
+            for wk, lo, hi, widened in self._pending:
                 wk.wait()
-                if self._stage is not None:
+                if self._stage is not None and not widened:
                     self.flat[lo:hi].copy_(self._stage[lo:hi])
         self._pending.clear()
         if average and self.world > 1:
@@ -380,10 +428,10 @@ class AdapterDataParallel:
         if not self.sync or l in self._done:
             return
         self._done.add(l)
-        if self.bucket.comm and (l % self.bucket.layers_per_bucket) == 0:
+        if self.bucket.comm and self.bucket.is_bucket_first(l):
             self._join_deferred()                    # a bucket must not ship before its dA_m have landed
         self.bucket.layer_done(l)                    # (collectives on, opt_in_backward: bucket.on_reduced runs the bucket's AdamW slice behind its all-reduce)
-        if self.opt_in_backward and not self.bucket.comm and (l % self.bucket.layers_per_bucket) == 0:
+        if self.opt_in_backward and not self.bucket.comm and self.bucket.is_bucket_first(l):
             dev = self.bucket.flat.device
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -422,7 +470,7 @@ class AdapterDataParallel:
         gradient over the ranks."""
         self._join_deferred()
         for l in range(self.bucket.n_layers - 1, -1, -1):
-            if l not in self._done and (l % self.bucket.layers_per_bucket) == 0:
+            if l not in self._done and self.bucket.is_bucket_first(l):
                 self.bucket.layer_done(l)
         self._done.clear()
         self._bwd_active = False
@@ -505,7 +553,7 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
            comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True,
            optimizer_in_backward: bool = False, force_comm: bool = False, no_decay="hf",
-           overlap_base: Optional[bool] = None) -> AdapterDataParallel:
+           overlap_base: Optional[bool] = None, tail_layers: Optional[int] = None) -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
     base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
@@ -599,7 +647,8 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
         sizes.append(named[k][1].numel())
         off += (named[k][1].numel() + 7) // 8 * 8                               # 16-byte aligned bf16 / 32-byte fp32 views
     ends.append(off)
-    bucket = FlatGradBucket(off, ends, dev, n_buckets=n_buckets, process_group=process_group, comm_dtype=comm_dtype, force_comm=force_comm)
+    bucket = FlatGradBucket(off, ends, dev, n_buckets=n_buckets, process_group=process_group, comm_dtype=comm_dtype, force_comm=force_comm,
+                            tail_layers=tail_layers)
     master = torch.zeros(off, dtype=torch.float32, device=dev)
     work = torch.zeros(off, dtype=torch.bfloat16, device=dev)
     by_name = dict(named)
@@ -634,8 +683,7 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
     if optimizer_in_backward:
         if opt is None or dev.type != "cuda":
             raise ValueError("attach(optimizer_in_backward=True) needs the built-in optimizer and a GPU")
-        if bucket.comm and bucket.comm_dtype is not None:
-            raise ValueError("attach(optimizer_in_backward=True): the bucket update runs behind an fp32 all-reduce (no comm_dtype)")
+        # (a bf16 payload is widened back into the fp32 buffer on the communication stream before the slice runs)
         dp.opt_in_backward = True
         if bucket.comm:
             bucket.on_reduced = dp._opt_slice
