@@ -765,6 +765,9 @@ def main():
     ap.add_argument("--capture-order", choices=("chain-first", "side-first"), default="chain-first",
                     help="order in which a fork's two successors are captured (same DAG): the hipGraph executor follows a fork node's FIRST out-edge "
                          "when it cuts the graph into execution streams")
+    ap.add_argument("--verify-graph", action="store_true",
+                    help="with --no-optimizer: replay the captured step once and run the same launches live, chain after chain on one stream, from the "
+                         "same activation state; y / dx must agree bit for bit, the flat gradient to its atomics' spread -> `graph_check`")
     ap.add_argument("--probe-forward", action="store_true",
                     help="also time the forward alone as a hipGraph of its own against the same launches live (HIP events, no profiler) -> `forward_only`")
     ap.add_argument("--no-group", action="store_true",
@@ -1111,6 +1114,45 @@ def main():
                 opt.t += 1
         replay_host_ms = round(min(hs), 3)
 
+    # --verify-graph: the captured schedule (chains on forked streams, deferred dA_m on the hub, whatever the executor makes of it) against the
+    # same launches live, one chain after the other on ONE stream, from the same activation state: y and dx bit for bit (deterministic
+    # kernels), the flat gradient to the spread of its fp32 atomics
+    graph_check = None
+    if args.verify_graph and rank == 0:
+        if opt is not None or (fwd_bwd_graph is None and bwd_graphs is None):
+            raise SystemExit("--verify-graph compares gradients: run it with --no-optimizer and a graph mode")
+        mut = [t for k in wl["keep"] for (acts, dacts, ys) in k[0] for t in list(dacts.values()) + list(ys)]
+        snap = [t.clone() for t in mut]
+
+        def restore():
+            for t, s_ in zip(mut, snap):
+                t.copy_(s_)
+            bucket.zero_()
+        restore()
+        torch.cuda.synchronize()
+        if fwd_bwd_graph is not None:
+            fwd_bwd_graph.replay()
+        else:
+            fwd_graph.replay()
+            for g, lo, hi in bwd_graphs:
+                g.replay()
+        torch.cuda.synchronize()
+        g_graph = bucket.flat.clone()
+        got = [t.clone() for t in mut]
+        restore()
+        sp_v = c_void_p(torch.cuda.current_stream().cuda_stream)
+        for ch in wl["chains"]:
+            run_forward(lib, ch, sp_v, None, shadows=shadows_main)
+            run_backward(lib, ch, sp_v, L, None, None)
+        torch.cuda.synchronize()
+        den = float(bucket.flat.abs().max())
+        graph_check = {"activations_bit_identical": all(torch.equal(a_, b_) for a_, b_ in zip(got, mut)), "tensors_compared": len(mut),
+                       "grad_max_abs_diff_over_max": float((g_graph - bucket.flat).abs().max()) / max(den, 1e-30),
+                       "grad_max_abs": den, "grad_nonzero_frac": float((bucket.flat != 0).float().mean()),
+                       "what": "graph replay vs the same launches live, chain after chain on one stream, from the same activation state"}
+        restore()
+        del got, g_graph
+
     out = None
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes_per_token(MODELS[args.model], args.rank, args.layers)
@@ -1244,7 +1286,8 @@ def main():
                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
                             "adapter_params": wl["n_params"]},
-            "graph": args.graph, "graph_replay_host_ms": replay_host_ms,
+            "graph": args.graph, "graph_replay_host_ms": replay_host_ms, "graph_topology": ("hub" if args.hub else "chain") if args.graph != "off" else None,
+            "graph_check": graph_check,
             "fused_forward": ("all units" if all(u.fused for u in units_all) else ("units " + ", ".join(sorted({u.label for u in units_all if u.fused})) if any(u.fused for u in units_all) else False)) if args.fused else False,
             "chains": args.chains,
             "defer_dA": args.defer_da,

@@ -1,0 +1,51 @@
+"""The schedules bench.py captures (part-batch chains on forked streams, deferred dA_m on the hub, per-bucket graphs) compute what
+the same launches compute live on one stream: `bench.py --verify-graph` (graph replay vs live, from the same activation state)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layers", "5", "--seq", "512", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-traffic", "--no-optimizer", "--verify-graph", *extra],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [
+    (),                                                   # the default: 2 chains, hub-shaped one-graph step, dA_m one launch per layer
+    ("--defer-da", "side"),
+    ("--defer-da", "bucket"),
+    ("--defer-da", "off"),
+    ("--chains", "4"),
+    ("--chains", "1"),                                    # round 4's shape with the chain-first capture order
+    ("--chains", "1", "--graph-topology", "hub"),
+    ("--graph", "bwd"),                                   # what N > 1 replays: forward graph + one graph per gradient bucket, 2 chains
+    ("--graph", "bwd", "--chains", "1"),
+    ("--rank", "64", "--batch", "2", "--chains", "2"),    # dB off the chain too (a pass of its own at this rank)
+    ("--variant", "vt"),
+], ids=lambda e: " ".join(e) or "default")
+def test_captured_schedule_equals_live_launches(extra):
+    out = _bench(*extra)
+    chk = out["graph_check"]
+    assert chk is not None and chk["tensors_compared"] > 0
+    assert chk["activations_bit_identical"], (extra, chk)
+    assert chk["grad_nonzero_frac"] > 0.9 and chk["grad_max_abs"] > 0
+    assert chk["grad_max_abs_diff_over_max"] <= 2e-5, (extra, chk)        # fp32 atomics in a different order
+    if "--chains" not in extra and "--rank" not in extra:
+        assert out["chains"] == 2
+
+
+def test_default_line_says_how_it_ran():
+    out = _bench()
+    assert out["graph"] == "all" and out["graph_topology"] == "hub" and out["chains"] == 2 and out["defer_dA"] in ("layer", "side")
