@@ -720,6 +720,9 @@ def main():
                          "packet of its own: bracketing all 128 launches of a step costs 0.7 ms of it; 5 is coprime to the 4 unit shapes "
                          "of a layer, so the sample covers them evenly)")
     ap.add_argument("--comm-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (153 instead of 306 MB per step at 7B r=16; accumulation stays fp32)")
+    ap.add_argument("--tail-layers", type=int, default=-1,
+                    help="layers of the gradient bucket that ships last (it holds layer 0: its all-reduce has nothing left to hide behind); the other "
+                         "layers split evenly over the remaining 7 buckets.  -1 (default) = 1 when collectives run, 0 (8 equal buckets) otherwise")
     ap.add_argument("--no-traffic", action="store_true", help="leave roofline.traffic null instead of reading the PMC summary under profiles/")
     ap.add_argument("--chains", type=int, default=0,
                     help="process the micro-batch as this many part-batches (batch / chains sequences each) whose launch chains are branches of "
@@ -847,8 +850,10 @@ def main():
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
     if args.chains > 1 and args.graph == "off":
         raise SystemExit("--chains > 1 exists as branches of captured graphs (--graph all / bwd)")
+    # (collectives on: the bucket that ships last -- layer 0's -- is one layer, so that the all-reduce nothing is left to hide is small)
+    tail = args.tail_layers if args.tail_layers >= 0 else (1 if comm else 0)
     wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None,
-                                                                       force_comm=args.force_comm),
+                                                                       force_comm=args.force_comm, tail_layers=tail or None),
                         chains=args.chains)
     T = wl["T"]
     torch.cuda.synchronize()
@@ -868,7 +873,7 @@ def main():
     #  bucket's layers have landed in EVERY chain)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and
                   ((not comm and (args.defer_da in ("side", "window", "layer", "bucket") or args.chains > 1) and args.graph in ("auto", "all", "off"))
-                   or (comm and not args.comm_bf16)))
+                   or comm))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
     shadows_main = bool(args.fused and args.shadows == "main")
@@ -1284,7 +1289,8 @@ def main():
                             "backend": (dist.get_backend() if (comm and dist.is_initialized()) else None),
                             "force_comm": bool(args.force_comm),
                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-                            "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", 8),
+                            "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", len(bucket.bucket_firsts())),
+                            "bucket_layers": [len(bucket.bucket_layers(f)) for f in bucket.bucket_firsts()], "last_bucket_bytes": bucket.last_bucket_bytes(),
                             "adapter_params": wl["n_params"]},
             "graph": args.graph, "graph_replay_host_ms": replay_host_ms, "graph_topology": ("hub" if args.hub else "chain") if args.graph != "off" else None,
             "graph_check": graph_check,

@@ -3916,9 +3916,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0;
+static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0, g_tune_cu_div = 0, g_tune_yx_fill = 0;
 #else
-static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0;
+static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0, g_tune_cu_div = 0, g_tune_yx_fill = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -3931,7 +3931,8 @@ static int num_cu() {                                    // per device (a proces
         if (n <= 0) n = 256;
         if (dev < 16) cached[dev] = n;
     }
-    return n;
+    // ("cu_div": size the launch heuristics for a share of the chip -- two part-batch chains run side by side)
+    return g_tune_cu_div > 1 ? (n / g_tune_cu_div > 0 ? n / g_tune_cu_div : 1) : n;
 }
 
 static int rank_pad(int r) {
@@ -4075,7 +4076,9 @@ static int launch_yx(const YxBatch& fb, int nz, hipStream_t st) {
     // gate+up 22 / 16 / 8 chunks per range: 149.6 / 169.2 / 161.1), more only where fewer tokens would leave CUs without a workgroup
     // ("yx_bpc": workgroups per CU instead; "yx_cpb": chunks per range)
     int want = g_tune_yx_bpc > 0 ? (g_tune_yx_bpc * num_cu() + ntb * nz - 1) / (ntb * nz) : 4;
-    if (g_tune_yx_bpc <= 0 && (long)want * ntb * nz < (long)num_cu()) want = (num_cu() + ntb * nz - 1) / (ntb * nz);
+    // ("yx_fill" 1: never more than four ranges; 2: two ranges for single projections)
+    if (g_tune_yx_fill == 2 && nz == 1) want = 2;
+    if (g_tune_yx_bpc <= 0 && g_tune_yx_fill == 0 && (long)want * ntb * nz < (long)num_cu()) want = (num_cu() + ntb * nz - 1) / (ntb * nz);
     want = want < 1 ? 1 : (want > nch ? nch : want);
     const int cpb = g_tune_yx_cpb > 0 ? g_tune_yx_cpb : (nch + want - 1) / want;
     constexpr size_t lds_w = (size_t)4 * 2 * ((RP + 31) / 32) * 1024, lds_p = (size_t)(8 * 2 * 16 + 64) * (RP + 1) * 4;
@@ -4632,6 +4635,8 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "g32_da")) g_tune_g32_da = value;
     else if (!strcmp(key, "gs_dbg")) g_tune_gs_dbg = value;
     else if (!strcmp(key, "g64_da")) g_tune_g64_da = value;
+    else if (!strcmp(key, "cu_div")) g_tune_cu_div = value;
+    else if (!strcmp(key, "yx_fill")) g_tune_yx_fill = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 #else

@@ -528,11 +528,17 @@ def _rccl_one_rank_worker(port, q):
     from moka_amd.parallel import attach
     F.set_deterministic(True, device=dev)
     outs = []
-    for force in (False, True):
+    # (third run: bf16 payload -- the slice behind a bucket's all-reduce reads the bf16-rounded sum widened back into the fp32 buffer --
+    #  and a tail bucket of one layer, the layout bench.py ships with)
+    for force, cd, tail in ((False, None, None), (True, None, None), (True, torch.bfloat16, 1), (True, None, 1), (True, torch.bfloat16, None)):
         st, dims = _build("avt", dev)
-        dp = attach(st, n_buckets=3, lr=1e-2, weight_decay=0.01, defer_dA=True, optimizer_in_backward=True, force_comm=force)
+        dp = attach(st, n_buckets=3, lr=1e-2, weight_decay=0.01, defer_dA=True, optimizer_in_backward=True, force_comm=force, comm_dtype=cd,
+                    tail_layers=tail)
         assert dp.bucket.comm == force and dp.bucket.world == 1
         assert (dp.bucket.comm_stream is not None) == force
+        if tail:
+            assert len(dp.bucket.bucket_layers(0)) == 1
+        assert dp.bucket.comm_dtype == cd
         h, gout, mask_args, sl = _batch("avt", dims, dev)
         for step in range(3):
             if step == 1:
@@ -557,11 +563,21 @@ def test_one_rank_rccl_runs_the_communication_path_bit_for_bit():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
     p.start()
-    backend, outs = q.get(timeout=300)
+    backend, outs = q.get(timeout=100)
     p.join(120)
     assert p.exitcode == 0
     assert backend == "nccl"
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    # bf16 payload: every gradient element rounded to 8 bits once per step before AdamW (which normalises it): the three-step trajectories
+    # agree to the rounding, and differ (the payload really was bf16)
+    import numpy as np
+    ref = outs[1][0]
+    assert (outs[3][0] == ref).all()                       # the tail-bucket layout alone changes nothing (fp32 payload: bit for bit)
+    for k in (2, 4):
+        diff = outs[k][0] - ref
+        rel = float(np.linalg.norm(diff) / np.linalg.norm(ref))
+        assert 0.0 < rel <= 5e-3 and float(np.abs(diff).max()) <= 1.5e-2, (k, rel, float(np.abs(diff).max()))    # lr = 1e-2: at most ~one step's sign on a tiny gradient
+    assert (outs[2][0] == outs[4][0]).all()                # (bf16 payload: the layout changes nothing either)
 
 
 def test_bench_force_comm_prices_the_multi_gpu_configuration_on_one_gpu():

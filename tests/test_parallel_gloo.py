@@ -297,7 +297,7 @@ def _force_comm_worker(port, q):
     plain = FlatGradBucket(200, ends, "cpu", n_buckets=2)
     forced = FlatGradBucket(200, ends, "cpu", n_buckets=2, force_comm=True)
     calls = []
-    forced.on_reduced = lambda lo, hi: calls.append((lo, hi))       # (CPU: on_reduced is a CUDA-stream feature; must stay unused here)
+    forced.on_reduced = lambda lo, hi: calls.append((lo, hi))       # (called behind every shipped bucket, last bucket first)
     g = torch.randn(200, generator=torch.Generator().manual_seed(1))
     out = []
     for b in (plain, forced):
@@ -308,6 +308,7 @@ def _force_comm_worker(port, q):
         b.finish(average=True)
         out.append((b.comm, b.world, pending, b.flat.clone()))
     dist.destroy_process_group()
+    assert calls == [(100, 200), (0, 100)], calls
     q.put([(c, w, p, t.numpy()) for c, w, p, t in out])
 
 
@@ -376,3 +377,70 @@ def test_attach_marks_biases_and_norm_weights_as_no_decay_on_cpu():
     o, sz = by["fc.weight"]
     assert all(not (lo <= o < hi) for lo, hi in dp.optimizer.no_decay_ranges)
     assert attach(Proj().to(torch.bfloat16), weight_decay=0.1, defer_dA=False, no_decay=None).optimizer.no_decay_ranges == []
+
+
+def test_tail_bucket_layout():
+    """tail_layers = t: the bucket that ships LAST (it holds layer 0; nothing of the backward is left to hide its all-reduce) is layers
+    [0, t), the other layers split evenly over the remaining buckets."""
+    from moka_amd.parallel import FlatGradBucket
+    ends = [10 * (i + 1) for i in range(32)]
+    b = FlatGradBucket(320, ends, "cpu", n_buckets=8, tail_layers=1)
+    firsts = b.bucket_firsts()
+    assert firsts[0] == 0 and firsts[1] == 1 and len(firsts) == 8
+    sizes = [len(b.bucket_layers(f)) for f in firsts]
+    assert sizes[0] == 1 and sum(sizes) == 32 and max(sizes[1:]) - min(sizes[1:]) <= 5 and sizes[1] == 5
+    assert b.bucket_bounds(0) == (0, 10) and b.bucket_bounds(1) == (10, 60) and b.bucket_bounds(firsts[-1])[1] == 320
+    assert b.last_bucket_bytes() == 10 * 4
+    # default layout unchanged: equal groups
+    u = FlatGradBucket(320, ends, "cpu", n_buckets=8)
+    assert u.bucket_firsts() == list(range(0, 32, 4)) and u.bucket_bounds(4) == (40, 80) and u.last_bucket_bytes() == 40 * 4
+    assert [u.is_bucket_first(l) for l in range(6)] == [True, False, False, False, True, False]
+
+
+def _payload_worker(rank, world, port, q):
+    """The update of a bucket behind its all-reduce (on_reduced) with the bf16 payload: the callback must see the SUMMED gradient widened
+    back into the fp32 buffer, once, and finish() must not overwrite what the callback left (here: a zeroed slice)."""
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from moka_amd.parallel import FlatGradBucket
+    ends = [40, 100, 164, 200, 260]
+    res = {}
+    for name, cd in (("fp32", None), ("bf16", torch.bfloat16)):
+        b = FlatGradBucket(260, ends, "cpu", n_buckets=3, comm_dtype=cd, tail_layers=1)
+        w = torch.zeros(260)
+        seen = []
+
+        def upd(lo, hi, b=b, w=w, seen=seen):
+            seen.append((lo, hi))
+            w[lo:hi] -= 0.5 * b.flat[lo:hi] / world          # "optimizer": plain SGD on the averaged gradient
+            b.flat[lo:hi].zero_()
+        b.on_reduced = upd
+        for step in range(2):
+            g = torch.randn(260, generator=torch.Generator().manual_seed(7 * step + rank))
+            b.flat.add_(g)
+            for l in range(4, -1, -1):
+                b.layer_done(l)
+            b.finish(average=False)
+            assert float(b.flat.abs().max()) == 0.0          # finish() left the zeroed slices alone
+        assert seen[:3] == [(164, 260), (40, 164), (0, 40)], seen     # layers [3,5), [1,3), [0,1): the tail bucket last
+        res[name] = w
+    exp = torch.zeros(260)
+    for step in range(2):
+        exp -= 0.5 * sum(torch.randn(260, generator=torch.Generator().manual_seed(7 * step + r)) for r in range(world)) / world
+    q.put((rank, float((res["fp32"] - exp).abs().max()), float((res["bf16"] - exp).abs().max() / exp.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_update_behind_a_bf16_payload_world2():
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_payload_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, e32, e16 in res:
+        assert e32 <= 1e-6 and e16 <= 1e-2, res             # bf16 payload: 2^-9 per addend
