@@ -163,9 +163,9 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
     B, S, r, M = args.batch, args.seq, args.rank, (2 if vt else 3)
     dims, L = MODELS[args.model], args.layers
     d, ff = dims["d"], dims["ff"]
-    assert B % chains == 0, "--chains must divide --batch"
-    Bc = B // chains
-    T, Tc = B * S, Bc * S
+    assert 1 <= chains <= B, "--chains: at most one chain per sequence"
+    sizes = [B // chains + (1 if ci < B % chains else 0) for ci in range(chains)]      # (uneven splits: the larger part-batches first)
+    T = B * S
     tok, q = synthetic_layout(S)
     if vt:
         # BASELINE.json configs[1]: visual-text -- the audio span becomes text, bool [B,S] masks (VisualText/train/train.py:206-231)
@@ -217,11 +217,13 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
 
     s = 16.0 / r
     nset = max(1, min(L, args.distinct))
-    Tp = _lib.tok_pad(Tc)
-    max_ks = max(_lib.ksplit(Tc, ff, r), _lib.ksplit(Tc, d, r), _lib.ksplit_bwd(Tc, ff, r))
     chain_list, keep = [], []
     shadow_bufs = {}              # (layer, projection) -> (BwT, AT): functions of the weights alone, so every chain reads the same pair
     for ci in range(chains):
+        Bc = sizes[ci]
+        Tc = Bc * S
+        Tp = _lib.tok_pad(Tc)
+        max_ks = max(_lib.ksplit(Tc, ff, r), _lib.ksplit(Tc, d, r), _lib.ksplit_bwd(Tc, ff, r))
         if vt:
             masks = [(tok == 0).reshape(1, S).repeat(Bc, 1).to(dev), (tok == 1).reshape(1, S).repeat(Bc, 1).to(dev), q.reshape(1, S).repeat(Bc, 1).to(dev)]
             rt = MokaRouting.from_vt_masks(*masks)
@@ -400,8 +402,13 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
     sps = c_void_p(side.cuda_stream)
     done = state if state is not None else {}                    # layer -> event "its deferred dA launches have finished" (side mode)
     flush_at = None
+    per_unit = False
     if mode == "layer":
         mode, batched = "side", True                             # the side schedule with ONE dA launch per layer
+    elif mode == "unit":
+        # a unit's dA_m leaves for the side stream as soon as its rank-space backward (which writes the packs it reads) has been enqueued,
+        # captured behind the unit's dx launch (chain-first).  Hub-shaped graphs only: there a fork per unit does not cut the chain
+        mode, batched, per_unit = "side", False, True
     elif mode == "bucket":
         # one fork per gradient BUCKET of layers (every cross-stream edge of a hipGraph costs its replay host time): the batched dA launches
         # of the bucket's layers go out together when its first layer's chain has been enqueued; every layer owns its pack buffers
@@ -419,9 +426,9 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
     def emit(l, held_, ev_main, pending_u):
         side.wait_event(ev_main)
         for u in reversed(units[l * per:(l + 1) * per]):
-            if split_db and not batched:
+            if split_db and not batched and not per_unit:
                 _call(lib, "moka_up_bwd:dB", u, sps, None)
-            if batched or (mode == "window" and u is not pending_u):
+            if batched or per_unit or (mode == "window" and u is not pending_u):
                 continue                                        # (already out, beside the next unit's rank-space backward)
             _call(lib, "moka_down_bwd:dA", u, sps, None)
         if batched:
@@ -462,7 +469,15 @@ def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
                 side.wait_stream(main)
                 _call(lib, "moka_down_bwd:dA", pending, sps, None)
             _call(lib, "moka_cross_bwd", u, sp, rec)
+            if per_unit:
+                ev_u = torch.cuda.Event()
+                ev_u.record(main)
             _call(lib, "moka_down_bwd:dx", u, sp, None)
+            if per_unit:
+                side.wait_event(ev_u)
+                if split_db:
+                    _call(lib, "moka_up_bwd:dB", u, sps, None)
+                _call(lib, "moka_down_bwd:dA", u, sps, None)
             pending = u
         if mode == "main":
             for u in reversed(units[l * per:(l + 1) * per]):
@@ -498,7 +513,16 @@ CHAIN_FIRST = True            # --capture-order side-first: A/B
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
 # PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
 # in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), never a constant in here.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+
+
+def kernel_source_sha256():
+    """sha256 over the kernel source + the C header: what a PMC traffic summary is stamped with (tools/pmc_traffic.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("moka_amd/csrc/moka_kernels.hip", "include/moka_hip.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
 
 
 def pmc_traffic_per_launch(T, launches_per_layer):
@@ -510,7 +534,18 @@ def pmc_traffic_per_launch(T, launches_per_layer):
               "roofline.traffic is null in this line", file=sys.stderr)
         return None, "missing: " + os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
     d = json.load(open(PMC_TRAFFIC_FILE))
-    return d["traffic_bytes_per_layer"] * (T / float(d["tokens"])) / launches_per_layer, os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
+    rel = os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
+    # the summary must have been measured on THESE kernels: it carries the sha256 of the source it was built from, and the library that is
+    # loaded must not be older than that source (a kernel change without a re-profile would leave a stale figure on the line)
+    from moka_amd import _lib, build as _build
+    if d.get("kernel_source_sha256") != kernel_source_sha256():
+        print(f"bench: {rel} was measured on other kernels (kernel_source_sha256 differs) -- run tools/pmc_traffic.sh on this build; "
+              "roofline.traffic is null in this line", file=sys.stderr)
+        return None, "stale: %s was measured on another kernel source" % rel
+    if os.path.abspath(_lib.LIB_PATH) == os.path.abspath(_build.OUT) and _build.needs_build():
+        print("bench: libmoka_hip.so is older than its source; roofline.traffic is null in this line", file=sys.stderr)
+        return None, "stale: the loaded library is older than the kernel source"
+    return d["traffic_bytes_per_layer"] * (T / float(d["tokens"])) / launches_per_layer, rel
 
 
 def usable_cpus() -> int:
@@ -731,7 +766,9 @@ def main():
                          "of the other; they share the parameters, the gradient accumulators and the optimizer slices.  0 (default) = 2 where the "
                          "batch splits evenly and the step is replayed as graphs, else 1.  Per-kernel durations (`roofline`, `kernels`) are "
                          "taken with the chains back to back on one stream")
-    ap.add_argument("--defer-da", choices=("off", "main", "side", "window", "layer", "bucket"), default="layer",
+    ap.add_argument("--chain-stagger", type=int, default=0,
+                    help="MB of a fill launched in front of the second (third, ...) chain's forward: a phase shift between otherwise identical chains (A/B)")
+    ap.add_argument("--defer-da", choices=("auto", "off", "main", "side", "window", "layer", "bucket", "unit"), default="auto",
                     help="the dA_m halves of moka_down_bwd are needed by the optimizer only: layer (default, what moka_amd.parallel.attach does) = "
                          "a layer's worth of them goes out as ONE launch (moka_down_bwd_da_batch: 4 -> 1 launches per layer) on a second stream when "
                          "the layer's chain has been enqueued, and runs beside the next layer's chain (joined before a gradient bucket ships and before "
@@ -781,12 +818,17 @@ def main():
     if args.graph == "auto":
         args.graph = "all" if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.force_comm) else "bwd"
     if args.chains == 0:
-        # auto: two part-batch chains where the step is replayed as hipGraphs, the batch splits evenly and the launches are short enough to
+        # auto: two part-batch chains where the step is replayed as hipGraphs, the batch has two sequences and the launches are short enough to
         # leave gaps (7B widths, rank pad <= 32: 32.2 -> 30.5 ms at r = 16, 41.7 -> 40.9 at r = 32; the 70B widths lose, 160.3 -> 166.1 ms, and
         # so does rank 64 at the 13B widths, 78.6 -> 79.5: their launches fill the chip on their own)
-        args.chains = 2 if (args.graph != "off" and args.batch % 2 == 0 and args.model == "7b" and args.rank <= 32) else 1
+        args.chains = 2 if (args.graph != "off" and args.batch >= 2 and args.model == "7b" and args.rank <= 32) else 1
     if args.graph_topology == "auto":
         args.graph_topology = "hub" if args.chains > 1 else "chain"      # (one chain: 32.15-32.27 ms in round 4's shape, 32.39 as hub + 1 chain)
+    if args.defer_da == "auto":
+        # one chain: a layer's dA_m as ONE launch (round 4); two chains: one launch per unit, out as soon as the unit's rank-space backward
+        # has been enqueued -- the hub's launches are then short enough to weave between the chains' (same box, per-layer launch / per-unit
+        # launches at the layer's end / per unit at once: 30.94 / 30.86 / 30.76 ms; five more pairs layer vs side: 30.65-31.14 vs 30.41-30.84)
+        args.defer_da = "unit" if (args.chains > 1 and args.graph != "off") else "layer"
     args.hub = args.graph != "off" and (args.graph_topology == "hub" or args.chains > 1)
     if args.chain_priority == "auto":
         args.chain_priority = "high" if args.graph == "all" else "normal"
@@ -872,7 +914,7 @@ def main():
     # (--chains N: every chain defers its dA_m to a side stream of its own; the slice of a bucket goes out on one more stream once the
     #  bucket's layers have landed in EVERY chain)
     opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and
-                  ((not comm and (args.defer_da in ("side", "window", "layer", "bucket") or args.chains > 1) and args.graph in ("auto", "all", "off"))
+                  ((not comm and (args.defer_da in ("side", "window", "layer", "bucket", "unit") or args.chains > 1) and args.graph in ("auto", "all", "off"))
                    or comm))
     # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
     # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
@@ -916,6 +958,7 @@ def main():
             torch.cuda.synchronize()
             pri = -1 if args.chain_priority == "high" else 0
             anchor = torch.zeros(64, device=dev)
+            stagger_buf = torch.empty(max(1, args.chain_stagger * (1 << 20) * max(1, args.chains - 1)), dtype=torch.uint8, device=dev)
 
             def capture_hub(graph, forward, pieces, with_opt):
                 """One graph in the hub shape: the N part-batch chains on N forked streams, everything off the chains (every chain's deferred
@@ -945,7 +988,12 @@ def main():
                         st.wait_stream(cur)              # fork
                     anchor.zero_()                       # the root's FIRST successor is on the hub: the walk runs down the hub before it sees a chain
                     if forward:
-                        for ch, st in zip(wl["chains"], branch):
+                        for ci_, (ch, st) in enumerate(zip(wl["chains"], branch)):
+                            if ci_ and args.chain_stagger > 0:
+                                # (identical chains that start together march in lockstep -- both in a latency-bound launch at the same
+                                #  time; a fill of `--chain-stagger` MB in front of the later chains shifts their phase)
+                                with torch.cuda.stream(st):
+                                    stagger_buf[:ci_ * args.chain_stagger * (1 << 20)].zero_()
                             run_forward(lib, ch, c_void_p(st.cuda_stream), shadows=shadows_main)
                     states = [dict() for _ in branch]
                     pend_opt = None

@@ -49,13 +49,33 @@ def test_usable_cpus_is_positive():
 
 def test_the_pmc_traffic_summary_of_this_round_is_committed():
     """roofline.traffic of the default bench line is read from this file (bench.PMC_TRAFFIC_FILE, written by tools/pmc_traffic.sh on the
-    GPU box); without it the line carries traffic = null."""
+    GPU box); without it the line carries traffic = null.  The summary is stamped with the sha256 of the kernel source it was measured on:
+    a summary of other kernels is refused (traffic = null + a warning), never silently reused."""
     import json
     assert os.path.exists(bench.PMC_TRAFFIC_FILE), bench.PMC_TRAFFIC_FILE
     d = json.load(open(bench.PMC_TRAFFIC_FILE))
-    assert d["tokens"] == 8192 and d["traffic_bytes_per_layer"] > 1.3e9          # >= the algorithmic 1392.5 MB of the four y launches
+    # measured on the launches the default schedule makes: part-batches of 2 sequences (4096 tokens)
+    assert d["tokens"] == 4096 and d["traffic_bytes_per_layer"] > 0.65e9          # >= the algorithmic 696.3 MB of the four y launches
+    assert len(d["kernel_source_sha256"]) == 64 and len(d["library_sha256"]) == 64
     t, src = bench.pmc_traffic_per_launch(8192, 4)
-    assert src == "profiles/" + os.path.basename(bench.PMC_TRAFFIC_FILE) and 3.4e8 < t < 4.2e8
+    if d["kernel_source_sha256"] == bench.kernel_source_sha256():
+        assert src == "profiles/" + os.path.basename(bench.PMC_TRAFFIC_FILE) and 3.4e8 < t < 4.6e8
+    else:
+        assert t is None and src.startswith("stale: ")
+
+
+def test_a_traffic_summary_of_other_kernels_is_refused(monkeypatch, tmp_path, capsys):
+    import json
+    p = tmp_path / "pmc.json"
+    p.write_text(json.dumps({"tokens": 4096, "traffic_bytes_per_layer": 8e8, "kernel_source_sha256": "0" * 64, "library_sha256": "0" * 64}))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(p))
+    t, src = bench.pmc_traffic_per_launch(8192, 4)
+    assert t is None and src.startswith("stale: ")
+    assert "other kernels" in capsys.readouterr().err
+    good = {"tokens": 4096, "traffic_bytes_per_layer": 8e8, "kernel_source_sha256": bench.kernel_source_sha256(), "library_sha256": "0" * 64}
+    p.write_text(json.dumps(good))
+    t, src = bench.pmc_traffic_per_launch(8192, 4)
+    assert t == 8e8 * 2 / 4
 
 
 def test_a_missing_traffic_summary_does_not_kill_the_line(monkeypatch, capsys):

@@ -25,6 +25,7 @@ def _bench(*extra):
 @pytest.mark.parametrize("extra", [
     (),                                                   # the default: 2 chains, hub-shaped one-graph step, dA_m one launch per layer
     ("--defer-da", "side"),
+    ("--defer-da", "layer"),
     ("--defer-da", "bucket"),
     ("--defer-da", "off"),
     ("--chains", "4"),
@@ -48,4 +49,4 @@ def test_captured_schedule_equals_live_launches(extra):
 
 def test_default_line_says_how_it_ran():
     out = _bench()
-    assert out["graph"] == "all" and out["graph_topology"] == "hub" and out["chains"] == 2 and out["defer_dA"] in ("layer", "side")
+    assert out["graph"] == "all" and out["graph_topology"] == "hub" and out["chains"] == 2 and out["defer_dA"] in ("layer", "side", "unit")

@@ -8,10 +8,23 @@ values in KiB per dispatch, FETCH_SIZE doubled (gfx950 reports half of the bytes
 Sums the corrected bytes of every dispatch of `moka_yx_kernel<..>` (and `moka_yt_kernel<..>` / `moka_expand_kernel<.., true, ..>`: the y += hp Bw^T
 kernels behind moka_up_fwd / moka_up_fwd_fused) and divides by the number of decoder layers the profiled run covered: bench.py turns that into bytes per
 launch (a layer has 4 up-projection launches: q+k+v, o, gate+up, down) next to its algorithmic figure."""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha256():
+    """What ties a traffic summary to a build: the sha256 over the kernel source and the C header (bench.py recomputes it and refuses a
+    summary measured on other kernels)."""
+    h = hashlib.sha256()
+    for rel in ("moka_amd/csrc/moka_kernels.hip", "include/moka_hip.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
 
 
 def total(path, counter, pattern):
@@ -38,6 +51,8 @@ def main(fetch_db, write_db, layers, T, launches_per_layer=4):
         "kernel": "moka_yx_kernel<RP> (moka_up_fwd_fused; moka_yt_kernel / moka_expand_kernel<RP,NQ,true> where a unit runs the three-launch forward)",
         "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py; FETCH_SIZE x 2 "
                   "(gfx950 unit correction of MI355X_MICROARCH.md) + WRITE_SIZE; summed over the launches of one decoder layer",
+        "kernel_source_sha256": source_sha256(),
+        "library_sha256": hashlib.sha256(open(os.path.join(ROOT, "moka_amd", "libmoka_hip.so"), "rb").read()).hexdigest(),
         "tokens": T, "layers_profiled": layers, "forward_passes_profiled": passes, "dispatches": fn,
         "traffic_bytes_per_layer": per_layer,
         "fetch_x2_bytes_per_layer": 2.0 * fb / (layers * passes), "write_bytes_per_layer": wb / (layers * passes),
