@@ -86,11 +86,11 @@ class Unit:
         from moka_amd import _lib
         G = len(members)
         # per unit: the library's advice for this shape (moka_up_fwd_fused_pays: e.g. not for the 70B widths' single projections)
-        self.fused = bool(fused and _lib.up_fwd_fused_pays(T, _lib.ksplit(T, members[0]["d_in"], r), [m["d_out"] for m in members], r))
+        self.fused = bool(fused and _lib.up_fwd_fused_pays(T, _lib.ksplit(T, members[0]["d_in"], r, G), [m["d_out"] for m in members], r))
         self.label, self.G, self.T = label, G, T
         self.d_in = members[0]["d_in"]
         self.d_outs = [m["d_out"] for m in members]
-        ks_in = _lib.ksplit(T, self.d_in, r)
+        ks_in = _lib.ksplit(T, self.d_in, r, G)
         ks_out = _lib.ksplit_bwd(T, max(self.d_outs), r)
         P = lambda ts: (c_void_p * len(ts))(*[t.data_ptr() for t in ts])          # noqa: E731
         I = lambda vs: (ctypes.c_int * len(vs))(*vs)                              # noqa: E731
@@ -223,7 +223,7 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
         Bc = sizes[ci]
         Tc = Bc * S
         Tp = _lib.tok_pad(Tc)
-        max_ks = max(_lib.ksplit(Tc, ff, r), _lib.ksplit(Tc, d, r), _lib.ksplit_bwd(Tc, ff, r))
+        max_ks = max(_lib.ksplit(Tc, ff, r, 1), _lib.ksplit(Tc, d, r, 2), _lib.ksplit_bwd(Tc, ff, r))
         if vt:
             masks = [(tok == 0).reshape(1, S).repeat(Bc, 1).to(dev), (tok == 1).reshape(1, S).repeat(Bc, 1).to(dev), q.reshape(1, S).repeat(Bc, 1).to(dev)]
             rt = MokaRouting.from_vt_masks(*masks)

@@ -69,11 +69,12 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      601            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+#define MOKA_VERSION      602            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
                                             at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
                                             0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional;
-                                            0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_weight_shadows_batch, moka_up_fwd_fused at every rank pad */
+                                            0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_weight_shadows_batch, moka_up_fwd_fused at every rank pad;
+                                            0.6.2: moka_ksplit_group() */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MAX_SHADOW_BATCH 16         /* projections of one moka_weight_shadows_batch launch */
@@ -132,6 +133,10 @@ int moka_tok_pad(int T);
  * number of 256-column chunks per slice, chosen from T and the device's CU count so that the launch fills the chip -- at most one
  * per 256 columns, so C / 256 rounded up is an upper bound for any T).  `part` holds ks * T * RP floats. */
 int moka_ksplit(int T, int C, int r);
+/* The same for G (1..MOKA_MAX_GROUP) projections that share the input (moka_down_fwd_group): the slice width may depend on G (it does in
+ * the diagnostics build's "xs_wide" experiment: 1024-column slices for a single projection at r <= 16); callers size `part` with this.
+ * moka_ksplit(T, C, r) == moka_ksplit_group(T, C, r, 1). */
+int moka_ksplit_group(int T, int C, int r, int G);
 /* Number of slices moka_up_bwd writes into g_part for output width C (= d_out; for a group: the largest
  * d_out of the group) -- pass it as `ks` to moka_cross_bwd.  One slice per 512-column block of gy; 32 < r <= 64: a whole number of
  * 256-column chunks per slice chosen from T and the device's CU count, as in moka_ksplit (at most C / 256 rounded up). */

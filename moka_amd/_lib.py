@@ -49,6 +49,7 @@ SYMBOLS = {
     "moka_rank_pad": (c_int, [c_int]),
     "moka_tok_pad": (c_int, [c_int]),
     "moka_ksplit": (c_int, [c_int, c_int, c_int]),
+    "moka_ksplit_group": (c_int, [c_int, c_int, c_int, c_int]),
     "moka_ksplit_bwd": (c_int, [c_int, c_int, c_int]),
     "moka_up_bwd_passes": (c_int, [c_int, c_int]),
     # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, stream
@@ -168,8 +169,10 @@ def rank_pad(r: int) -> int:
     return rp
 
 
-def ksplit(T: int, C: int, r: int) -> int:
-    ks = load().moka_ksplit(int(T), int(C), int(r))
+def ksplit(T: int, C: int, r: int, G: int = 1) -> int:
+    """Split-K slices moka_down_fwd[_group] writes per projection (G = projections that share the input: a single projection at r <= 16
+    gets 1024-column slices, groups 512-column ones)."""
+    ks = load().moka_ksplit_group(int(T), int(C), int(r), int(G))
     if ks < 0:
         raise ValueError(f"unsupported shape for the HIP path: T={T} width={C} r={r} (width must be a multiple of 32)")
     return ks

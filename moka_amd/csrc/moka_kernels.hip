@@ -3258,11 +3258,16 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
 // q+k+v 47.1 -> 34.4, gate+up 29.1 -> 24.9, down 49.5 -> 47.7; bit-identical slices.  Precondition: T % 16 == 0 (else the first form).
 // ------------------------------------------------------------------------------------------
 
-template <int G, int NS>
+// HC = 2 (round 5, single projections): a split-K slice covers 1024 columns -- the workgroup takes the two 512-column halves of a tile as
+// two consecutive steps of the same ring, the accumulators stay in registers across them and the eight waves' partials are summed (and
+// the slice row written) once per TILE: half the slices for the consumers to re-sum (the fused up-projection sums them once per
+// column range of every token block), half the block reductions.  The weight fragments of both halves are resident (G = 1: 12 fragments).
+template <int G, int NS, int HC = 1>
 __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RP = 16, RPITCH = 1040, STAGE = 16 * RPITCH;   // bytes; pitch 260 dwords: the 64 lanes of a ds_read_b128 spread evenly over the banks
     constexpr int SLOT = 16 * RP;                                // floats per (wave, projection) partial tile
+    constexpr int KWS = 512 * HC;                                // columns per slice
     unsigned char* ring = smem;                                  // [NS][16 rows][RPITCH]
     float* slots = (float*)(smem + NS * STAGE);                  // [2][8][G][SLOT]
     unsigned char* smod = (unsigned char*)(slots + 2 * 8 * G * SLOT);
@@ -3274,16 +3279,17 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
     const int t0 = blockIdx.y * tiles_per_block;
     const int nt = min(tiles_per_block, ntile_all - t0);
     if (nt <= 0) return;
-    const int cb0 = blockIdx.x * 512, c0 = cb0 + 64 * wave;
-    const bool wactive = c0 < a.C;
+    const int nstep = nt * HC;                                   // a step = one 16-token x 512-column tile of the ring
+    const int cb0 = blockIdx.x * KWS, c0 = cb0 + 64 * wave;
     for (int e = tid; e < nt * 16; e += 512) smod[e] = a.tok_mod[t0 * 16 + e];
 
     // producer side: wave w brings rows 2w and 2w+1 of every tile; lane l the 16 bytes at column cb0 + 8 l (clamped into the row)
-    const int ccol = min(cb0 + 8 * lane, a.C - 8);
     const unsigned ring_base = (unsigned)(size_t)ring;
-    auto issue = [&](int tile) {
-        const int tl = min(tile, nt - 1);                        // past the run: re-request its last tile (L2 hit) -- every iteration issues the same count
-        const int st = tile % NS;
+    auto issue = [&](int step) {
+        const int sl = min(step, nstep - 1);                     // past the run: re-request its last tile (L2 hit) -- every iteration issues the same count
+        const int st = step % NS;
+        const int tl = HC == 1 ? sl : sl >> 1;
+        const int ccol = min(cb0 + (HC == 1 ? 0 : 512 * (sl & 1)) + 8 * lane, a.C - 8);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * wave + rr;
@@ -3291,32 +3297,36 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
             glds16(src, __builtin_amdgcn_readfirstlane(ring_base + st * STAGE + row * RPITCH));
         }
     };
-    // weights: the fragments of my 64 columns, all modalities / projections, resident (loads the compiler does not track: explicit
-    // waits).  Requested FIRST (a wave's loads return in order and the weights are needed first), then the first NS-1 tiles.
-    bf16x8 wfr[G][MOKA_MAX_MOD][2];
+    // weights: the fragments of my 64 columns (of every half), all modalities / projections, resident (loads the compiler does not track:
+    // explicit waits).  Requested FIRST (a wave's loads return in order and the weights are needed first), then the first NS-1 tiles.
+    bf16x8 wfr[HC][G][MOKA_MAX_MOD][2];
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi)
+    for (int hf = 0; hf < HC; ++hf)
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+        for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = min(c0 + 32 * kk + 8 * g, a.C - 8);
-                const int mm = min(m, a.M - 1);
-                const unsigned char* src = a.A[gi][mm] + ((size_t)min(i, a.r - 1) * a.C + c) * 2;
-                wfr[gi][m][kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(wfr[gi][m][kk]) : "v"(src) : "memory");
-            }
+            for (int m = 0; m < MOKA_MAX_MOD; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int c = min(c0 + 512 * hf + 32 * kk + 8 * g, a.C - 8);
+                    const int mm = min(m, a.M - 1);
+                    const unsigned char* src = a.A[gi][mm] + ((size_t)min(i, a.r - 1) * a.C + c) * 2;
+                    wfr[hf][gi][m][kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(wfr[hf][gi][m][kk]) : "v"(src) : "memory");
+                }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(t);
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi)
+    for (int hf = 0; hf < HC; ++hf)
 #pragma unroll
-        for (int m = 0; m < MOKA_MAX_MOD; ++m)
+        for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wfr[gi][m][kk]) : "n"(2 * (NS - 1)) : "memory");     // the weights have landed, the tiles are still on their way
-                if (m >= a.M || c0 + 32 * kk + 8 * g >= a.C) wfr[gi][m][kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
+            for (int m = 0; m < MOKA_MAX_MOD; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wfr[hf][gi][m][kk]) : "n"(2 * (NS - 1)) : "memory");     // the weights have landed, the tiles are still on their way
+                    if (m >= a.M || c0 + 512 * hf + 32 * kk + 8 * g >= a.C) wfr[hf][gi][m][kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
 
     const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto reduce = [&](int k) {                                   // waves 0..3: sum the eight waves' partials of tile k, write the slice rows
@@ -3334,12 +3344,14 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
             }
         }
     };
-    for (int k = 0; k < nt; ++k) {
+    f32x4 acc[G];
+    for (int s = 0; s < nstep; ++s) {
+        const int k = HC == 1 ? s : s >> 1, hf = HC == 1 ? 0 : (s & 1);
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(2 * (NS - 2)) : "memory");
-        if (k == 1) TRACE(1);
-        if (k > 0) reduce(k - 1);
-        issue(k + NS - 1);
-        const unsigned char* stg = ring + (k % NS) * STAGE;
+        if (s == 1) TRACE(1);
+        if (hf == 0 && k > 0) reduce(k - 1);
+        issue(s + NS - 1);
+        const unsigned char* stg = ring + (s % NS) * STAGE;
         bf16x8 xf[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) xf[kk] = *(const bf16x8*)(stg + i * RPITCH + 128 * wave + 64 * kk + 16 * g);
@@ -3348,9 +3360,10 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
         unsigned pm = 0;
 #pragma unroll
         for (int m = 0; m < MOKA_MAX_MOD; ++m) if (m < a.M && __any(mrow == m)) pm |= 1u << m;
+        const bool wactive = c0 + 512 * hf < a.C;
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (hf == 0) acc[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (wactive && pm) {
                 bf16x8 xg[2];
 #pragma unroll
@@ -3358,19 +3371,26 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
                     xg[kk] = xf[kk];
                     if (a.drop[gi].thr) {
                         const unsigned trow = (unsigned)((t0 + k) * 16 + i);
-                        xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 32 * kk) >> 3) + (unsigned)g));
+                        xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 512 * hf + 32 * kk) >> 3) + (unsigned)g));
                     }
                 }
 #pragma unroll
                 for (int m = 0; m < MOKA_MAX_MOD; ++m) {
                     if (!(pm & (1u << m))) continue;
                     const bool other = (pm != (1u << m)) && mrow != m;
-                    acc = MFMA16(wfr[gi][m][0], other ? z8 : xg[0], acc);
-                    acc = MFMA16(wfr[gi][m][1], other ? z8 : xg[1], acc);
+                    if (HC == 1 || hf == 0) {
+                        acc[gi] = MFMA16(wfr[0][gi][m][0], other ? z8 : xg[0], acc[gi]);
+                        acc[gi] = MFMA16(wfr[0][gi][m][1], other ? z8 : xg[1], acc[gi]);
+                    } else {
+                        acc[gi] = MFMA16(wfr[HC - 1][gi][m][0], other ? z8 : xg[0], acc[gi]);
+                        acc[gi] = MFMA16(wfr[HC - 1][gi][m][1], other ? z8 : xg[1], acc[gi]);
+                    }
                 }
             }
-            MFMA_SETTLE(acc);
-            *(f32x4*)(myslot + (size_t)gi * SLOT + i * RP + 4 * g) = acc;
+            if (hf == HC - 1) {
+                MFMA_SETTLE(acc[gi]);
+                *(f32x4*)(myslot + (size_t)gi * SLOT + i * RP + 4 * g) = acc[gi];
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -3916,9 +3936,9 @@ static void ensure_lds(const void* kernel, size_t lds) {
 // diagnostics build (-DMOKA_DIAGNOSTICS: python -m moka_amd.build --diag -> libmoka_hip_diag.so, selected with MOKA_HIP_LIB);
 // in the product library these are compile-time zeros and moka_tune() refuses.
 #ifdef MOKA_DIAGNOSTICS
-static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0, g_tune_cu_div = 0, g_tune_yx_fill = 0;
+static int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0, g_tune_cu_div = 0, g_tune_yx_fill = 0, g_tune_xs_wide = 0;
 #else
-static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0, g_tune_cu_div = 0, g_tune_yx_fill = 0;
+static constexpr int g_tune_dx_group = 0, g_tune_gy_form = 0, g_tune_xa_form = 0, g_tune_expand_nq = 0, g_tune_xa_ng = 0, g_tune_expand_depth = 0, g_tune_gy_ng = 0, g_tune_wgrad_nw = 0, g_tune_expand_bpc = 0, g_tune_wgrad_ct = 0, g_tune_wgrad_bpc = 0, g_tune_yx_bpc = 0, g_tune_yx_cpb = 0, g_tune_yx_dbg = 0, g_tune_g32_fwd = 0, g_tune_g32_dx = 0, g_tune_g32_da = 0, g_tune_gs_dbg = 0, g_tune_g64_da = 0, g_tune_cu_div = 0, g_tune_yx_fill = 0, g_tune_xs_wide = 0;
 #endif
 
 static int num_cu() {                                    // per device (a process may drive several GPUs)
@@ -4456,17 +4476,17 @@ static void launch_xa_t(const XaArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((moka_xa_kernel<RP, G, NG>), dim3(ncb, ntb), dim3(512), lds, st, a);
 }
 
-template <int G>
+template <int G, int HC = 1>
 static int launch_xs(const XaArgs& a, hipStream_t st) {
     constexpr int NS = 2;
-    const int ncb = (a.C + 511) / 512, ntile = a.T >> 4;
+    const int ncb = (a.C + 512 * HC - 1) / (512 * HC), ntile = a.T >> 4;
     // tiles per workgroup: long runs amortise the resident weights (G x 6 KB per wave), short ones give more workgroups
     int tpb = (G == 3) ? 16 : 8;
     // (three projections: one workgroup of 16 tiles per CU beat two of 8 -- 34.4 vs 40.0 us -- their 18 KB of weights per wave are the start-up)
     while (tpb > 2 && (long)ncb * ((ntile + tpb - 1) / tpb) < (G == 3 ? 1L : 2L) * num_cu()) tpb >>= 1;
     const size_t lds = (size_t)NS * 16 * 1040 + (size_t)2 * 8 * G * 256 * 4 + (size_t)tpb * 16;
-    ensure_lds((const void*)moka_xs_kernel<G, NS>, lds);
-    hipLaunchKernelGGL((moka_xs_kernel<G, NS>), dim3(ncb, (ntile + tpb - 1) / tpb), dim3(512), lds, st, a, tpb);
+    ensure_lds((const void*)moka_xs_kernel<G, NS, HC>, lds);
+    hipLaunchKernelGGL((moka_xs_kernel<G, NS, HC>), dim3(ncb, (ntile + tpb - 1) / tpb), dim3(512), lds, st, a, tpb);
     return check_launch("moka_xs_kernel");
 }
 
@@ -4534,7 +4554,15 @@ static int launch_xwm(const XaArgs& xa, int G, int kw, hipStream_t st) {
 static bool use_xw(int RP) { return g_tune_xa_form == 2 || ((g_tune_xa_form == 0 || g_tune_xa_form == 3) && RP >= 32); }
 // columns per split-K slice of the forward: 512; rank pad 64: a whole number of 256-column chunks, as few slices as still give every CU a
 // workgroup of 128 tokens (moka_xwm_kernel)
-static int fwd_kw(int T, int C, int r) {
+// r <= 16, ONE projection on the LDS-DMA ring (whole 16-token tiles): moka_xs_kernel<1, NS, 2> can walk the two halves of a 1024-column slice,
+// so that the consumers sum half as many slices.  Built, tested, measured (round 5, 2 x 4096 tokens per step) and NOT the default: the fused
+// up-projection gains 0.27 ms per pass (12.63 -> 12.37) and the down-projection loses 0.33 (5.81 -> 6.15: 92 registers instead of 64, two
+// workgroups per CU instead of three; capped at 6 waves per SIMD it spills 12 registers: 6.83) -- step 30.63 vs 30.57 ms.  "xs_wide" 2 turns it on.
+static bool xs_wide(int T, int r, int G) {
+    return G == 1 && rank_pad(r) == 16 && (T & 15) == 0 && !use_xw(16) && g_tune_xa_form != 1 && g_tune_xs_wide == 2;
+}
+static int fwd_kw(int T, int C, int r, int G = 1) {
+    if (xs_wide(T, r, G)) return 1024;
     if (!(use_xw(rank_pad(r)) && (rank_pad(r) == 64 || (rank_pad(r) == 32 && g_tune_g32_fwd == 0)))) return 512;
     if (g_tune_xa_form == 3) return 256;                                  // one chunk per slice (the first form of the kernel, A/B)
     const int nch = (C + 255) / 256, ntb = (T + 127) / 128;
@@ -4543,7 +4571,7 @@ static int fwd_kw(int T, int C, int r) {
     want = want < 1 ? 1 : (want > nch ? nch : want);
     return (nch + want - 1) / want * 256;
 }
-static int fwd_ks(int T, int C, int r) { const int kw = fwd_kw(T, C, r); return (C + kw - 1) / kw; }
+static int fwd_ks(int T, int C, int r, int G = 1) { const int kw = fwd_kw(T, C, r, G); return (C + kw - 1) / kw; }
 
 // number of g_part slices moka_up_bwd writes for output width C
 // the LDS-DMA gy pass (g and dB out of one LDS tile) also at rank pad 32: 13B widths 12.0 -> 10.4 ms per pass.  At rank pad 64 it loses
@@ -4637,6 +4665,7 @@ int moka_tune(const char* key, int value) {
     else if (!strcmp(key, "g64_da")) g_tune_g64_da = value;
     else if (!strcmp(key, "cu_div")) g_tune_cu_div = value;
     else if (!strcmp(key, "yx_fill")) g_tune_yx_fill = value;
+    else if (!strcmp(key, "xs_wide")) g_tune_xs_wide = value;
     else return fail(MOKA_EINVAL, "moka_tune: unknown key %s", key);
     return MOKA_OK;
 #else
@@ -4668,10 +4697,11 @@ int moka_up_bwd_passes(int r, int dtype) {
     return (dtype == MOKA_BF16 && (RP == 16 || gs_wide(RP))) ? 1 : 2;
 }
 
-int moka_ksplit(int T, int C, int r) {
-    if (rank_pad(r) < 0 || C < 32 || (C % 32) != 0 || T < 1) return MOKA_EINVAL;
-    return fwd_ks(T, C, r);
+int moka_ksplit_group(int T, int C, int r, int G) {
+    if (rank_pad(r) < 0 || C < 32 || (C % 32) != 0 || T < 1 || G < 1 || G > MOKA_MAX_GROUP) return MOKA_EINVAL;
+    return fwd_ks(T, C, r, G);
 }
+int moka_ksplit(int T, int C, int r) { return moka_ksplit_group(T, C, r, 1); }
 
 // shared-input groups run as ONE kernel for r <= 16; wider ranks fall back to one launch per projection
 static bool can_group(int r, int G) { return G > 1 && rank_pad(r) == 16; }
@@ -4702,7 +4732,7 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             f32_common(a, tok_mod, T, d_in, r, M);
             a.in = (const float*)x; a.out = part[g]; a.drop = drop[g];
             for (int m = 0; m < M; ++m) { a.W[m] = (const float*)A[g * M + m]; a.s_mod[m] = s_in * drop[g].inv_keep; }
-            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3(fwd_ks(T, d_in, r), (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, fwd_kw(T, d_in, r));
+            hipLaunchKernelGGL(moka_f32_reduce_kernel<false>, dim3(fwd_ks(T, d_in, r, G), (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, fwd_kw(T, d_in, r, G));
             rc = check_launch("moka_f32_reduce_kernel");
             if (rc) return rc;
         }
@@ -4732,7 +4762,8 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
             else rc = launch_xwm<64>(xa, per_launch, fwd_kw(T, d_in, r), (hipStream_t)stream);
         } else
         if (RP == 16 && (T & 15) == 0 && g_tune_xa_form != 1)    // LDS-DMA ring (whole 16-token tiles; "xa_form" 1 forces the first form)
-            rc = G == 1 ? launch_xs<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xs<2>(xa, (hipStream_t)stream) : launch_xs<3>(xa, (hipStream_t)stream));
+            rc = G == 1 ? (xs_wide(T, r, 1) ? launch_xs<1, 2>(xa, (hipStream_t)stream) : launch_xs<1>(xa, (hipStream_t)stream))
+                        : (G == 2 ? launch_xs<2>(xa, (hipStream_t)stream) : launch_xs<3>(xa, (hipStream_t)stream));
         else if (RP == 16) rc = G == 1 ? launch_xa<1>(xa, (hipStream_t)stream) : (G == 2 ? launch_xa<2>(xa, (hipStream_t)stream) : launch_xa<3>(xa, (hipStream_t)stream));
         else rc = RP == 32 ? launch_xa_wide<32>(xa, (hipStream_t)stream) : launch_xa_wide<64>(xa, (hipStream_t)stream);
         if (rc) return rc;

@@ -258,7 +258,7 @@ def down_fwd_group(x2: torch.Tensor, A: Sequence[Sequence[torch.Tensor]], rt: Mo
     T, d_in = x2.shape
     G, M = len(A), len(A[0])
     RP = _lib.rank_pad(r)
-    ks = _lib.ksplit(T, d_in, r)
+    ks = _lib.ksplit(T, d_in, r, G)
     parts = [torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device) for _ in range(G)]
     flat = [a for Ag in A for a in Ag]
     _lib.check(lib.moka_down_fwd_group(x2.data_ptr(), _ptrs(flat), rt.tok_mod.data_ptr(), _ptrs(parts),
@@ -766,7 +766,7 @@ class MokaLinearGroupFn(torch.autograd.Function):
         Bws = [b if b.is_contiguous() else b.contiguous() for b in Bws]
         seeds = [s_.seed for s_ in specs]
         need_x = ctx.needs_input_grad[0]
-        fused = FUSE_FORWARD and _lib.up_fwd_fused_pays(x2.shape[0], _lib.ksplit(x2.shape[0], d_in, sp.r), [b.shape[0] for b in Bws], sp.r)
+        fused = FUSE_FORWARD and _lib.up_fwd_fused_pays(x2.shape[0], _lib.ksplit(x2.shape[0], d_in, sp.r, len(Bws)), [b.shape[0] for b in Bws], sp.r)
         overlap = OVERLAP_BASE and fused
         shadows = None
         if overlap:                                                  # (see MokaLinearFn.forward)

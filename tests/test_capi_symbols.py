@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_rank_pad(lib):
-    assert lib.moka_version() == 601
+    assert lib.moka_version() == 602
     assert [lib.moka_tok_pad(t) for t in (1, 32, 33)] == [32, 32, 64]
     assert [lib.moka_rank_pad(r) for r in (1, 4, 8, 16, 17, 32, 33, 64)] == [16, 16, 16, 16, 32, 32, 64, 64]
     assert lib.moka_rank_pad(0) < 0 and lib.moka_rank_pad(65) < 0
@@ -45,7 +45,10 @@ def test_ksplit_covers_width(lib):
         assert 1 <= ks <= 32
     # slices per projection: one per 512 columns; rank pads 32 (forward) / 64: whole 256-column chunks, as few as still give every CU three
     # (forward) / one (backward) workgroups of 128 tokens (no device here: 256 CUs assumed)
-    assert lib.moka_ksplit(8192, 5120, 16) == 10 and lib.moka_ksplit(8192, 5120, 64) == 10 and lib.moka_ksplit(8192, 13824, 64) == 11
+    assert lib.moka_ksplit(8192, 5120, 16) == 10 and lib.moka_ksplit_group(8192, 5120, 16, 1) == 10 and lib.moka_ksplit_group(8192, 5120, 16, 3) == 10
+    assert lib.moka_ksplit(8190, 5120, 16) == 10 and lib.moka_ksplit(8192, 11008, 16) == 22 and lib.moka_ksplit_group(8192, 11008, 16, 2) == 22
+    assert lib.moka_ksplit_group(8192, 4096, 16, 0) < 0 and lib.moka_ksplit_group(8192, 4096, 16, 4) < 0
+    assert lib.moka_ksplit(8192, 5120, 64) == 10 and lib.moka_ksplit(8192, 13824, 64) == 11
     assert lib.moka_ksplit(128, 5120, 64) == 20 and lib.moka_ksplit(65536, 5120, 64) == 2
     assert lib.moka_ksplit_bwd(8192, 5120, 16) == 10 and lib.moka_ksplit_bwd(8192, 5120, 64) == 4 and lib.moka_ksplit_bwd(8192, 13824, 64) == 4
     assert lib.moka_ksplit_bwd(128, 5120, 64) == 20
