@@ -47,6 +47,29 @@ class MokaRouting:
         self._ws = {}
         self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.ktok.data_ptr(), self.klen.data_ptr(),
                                              self.kslot.data_ptr(), B, S, Lk_max, M)
+        # tokens in MORE than one modality (from_avt_masks): the routing then describes S = S_real + D tokens per sample, the last D being
+        # VIRTUAL tokens -- copies of the rows dup_src [B, D] that carry the token's further memberships (extend / fold below)
+        self.dup_src: Optional[torch.Tensor] = None
+        self.S_real = S
+
+    # ------------------------------------------------------------------ tokens of several modalities
+    def extend(self, x: torch.Tensor) -> torch.Tensor:
+        """[B, S_real, d] -> [B, S, d]: the rows of the virtual tokens appended (differentiable: their input gradients flow back to the
+        rows they copy)."""
+        if self.dup_src is None:
+            return x
+        x3 = x.reshape(self.B, self.S_real, x.shape[-1])
+        idx = self.dup_src[..., None].expand(-1, -1, x3.shape[-1])
+        return torch.cat([x3, x3.gather(1, idx)], dim=1)
+
+    def fold(self, y: torch.Tensor) -> torch.Tensor:
+        """[B, S, d] -> [B, S_real, d]: every virtual token's row added to the row of the token it stands for (the reference sums the
+        modality streams of a token in front of lora_B, ``lora.py:524-530``: the up-projection is linear, so the rows may be summed behind it)."""
+        if self.dup_src is None:
+            return y
+        y3 = y.reshape(self.B, self.S, y.shape[-1])
+        idx = self.dup_src[..., None].expand(-1, -1, y3.shape[-1])
+        return y3[:, :self.S_real].scatter_add(1, idx, y3[:, self.S_real:])
 
     def cross_ws(self, r: int, slot: int = 0) -> torch.Tensor:
         """Scratch of moka_cross_bwd for rank r (no initialisation needed; one per routing, rank pad and
@@ -78,25 +101,47 @@ class MokaRouting:
         (AVT ``unified_arch.py:159-240`` builds them, ``lora.py:462-521`` consumes them).
         Keys = contiguous span first..last question token (``lora.py:489-491``), a key row is
         non-zero only where the token is question AND text (``lora.py:482``).
-        Raises IndexError when a sample has no question token, as ``lora.py:489-490`` does."""
+        Raises IndexError when a sample has no question token, as ``lora.py:489-490`` does.
+
+        A token in SEVERAL masks (never in the reference's data, ``unified_arch.py:159-240`` builds disjoint masks; pinned by
+        tests/golden/avt_dual_modality.npz): ``lora.py:468-477`` runs every adapter on its masked copy of x, so such a token has one
+        rank-space row PER membership, each stream interacts with the question rows on its own (:485-521) and the rows are summed in
+        front of ``lora_B0`` (:524-530).  One modality id per token cannot say that, so the routing is built over S + D tokens per
+        sample: the token keeps its FIRST membership (text before video before audio -- a question-and-text token stays a text key
+        row) and every further membership becomes a virtual token behind the sample's real ones (``dup_src``: the row it copies);
+        ``functional.moka_linear`` feeds the kernels the extended rows and folds the virtual outputs / input gradients back."""
         t, v, a, q = [(m.reshape(m.shape[0], m.shape[1]) == 1) for m in modality_mask[:4]]
         B, S = t.shape
         dev = t.device
         tok = torch.full((B, S), MOD_NONE, dtype=torch.uint8, device=dev)
-        tok[t] = 0
-        tok[v] = 1
         tok[a] = 2
+        tok[v] = 1
+        tok[t] = 0                                               # (a token of several modalities keeps its FIRST membership)
         idx = torch.arange(S, device=dev).expand(B, S)
         first = torch.where(q, idx, S).min(dim=1).values
         last = torch.where(q, idx, -1).max(dim=1).values
         klen = (last - first + 1)
-        overlap = ((t.int() + v.int() + a.int()) > 1).any()
-        stats = torch.stack([overlap.int(), (klen <= 0).any().int(), klen.max().int()]).tolist()   # the one sync
-        if stats[1]:
-            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+        extra = [v & t, a & (t | v)]                             # memberships behind a token's first one (video, audio)
+        n_extra = extra[0].sum(dim=1) + extra[1].sum(dim=1)
+        stats = torch.stack([(klen <= 0).any().int(), klen.max().int(), n_extra.max().int()]).tolist()   # the one sync
         if stats[0]:
-            raise ValueError("modality masks overlap: a token belongs to more than one modality")
-        Lk = int(stats[2])
+            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+        if stats[2] > 0:
+            D = (int(stats[2]) + 15) // 16 * 16                  # whole 16-token tiles behind every sample
+            E = torch.cat(extra, dim=1)                          # [B, 2 S]: slot e = (modality 1 + e // S, position e % S)
+            order = torch.sort((~E).to(torch.uint8), dim=1, stable=True).indices
+            if D > order.shape[1]:
+                order = torch.cat([order, order.new_zeros(B, D - order.shape[1])], dim=1)
+            order = order[:, :D]
+            live = torch.arange(D, device=dev)[None, :] < n_extra[:, None]
+            src = torch.where(live, order % S, torch.zeros_like(order))
+            vmod = torch.where(live, 1 + order // S, torch.full_like(order, 255))
+            zeros = torch.zeros(B, D, dtype=torch.bool, device=dev)
+            ext = [torch.cat([t, zeros], 1), torch.cat([v & ~extra[0], vmod == 1], 1), torch.cat([a & ~extra[1], vmod == 2], 1), torch.cat([q, zeros], 1)]
+            rt = cls.from_avt_masks([m.to(torch.int32) for m in ext])          # (disjoint now)
+            rt.dup_src, rt.S_real = src.long().contiguous(), S
+            return rt
+        Lk = int(stats[1])
         kp = first[:, None] + torch.arange(Lk, device=dev)[None, :]
         inside = kp <= last[:, None]
         kpc = kp.clamp(max=S - 1)

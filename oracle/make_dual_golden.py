@@ -26,7 +26,7 @@ from oracle.make_goldens import _import_reference, rel   # noqa: E402
 def main():
     AvtLinear, _ = _import_reference()
     g = torch.Generator().manual_seed(20260929)
-    B, L, d_in, d_out, r, alpha, w = 2, 24, 32, 48, 4, 16.0, 1.0
+    B, L, d_in, d_out, r, alpha, w = 2, 24, 32, 64, 4, 16.0, 1.0          # (widths: multiples of 32, what the HIP path takes)
     dt = torch.float64
     x = torch.randn(B, L, d_in, generator=g, dtype=dt)
     W = torch.randn(d_out, d_in, generator=g, dtype=dt) * 0.05

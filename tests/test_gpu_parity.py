@@ -1152,3 +1152,83 @@ def test_deterministic_weight_gradients_wide_ranks(r):
     for a, b, d in zip(g1, g2, base):
         assert torch.equal(a, b)
         assert rel(a, d) < 1e-2                      # the returned gradient is cast to bf16
+
+
+def test_tokens_of_two_modalities_against_the_reference_golden():
+    """A token in TWO modality masks (lora.py:468-477 runs every adapter on its masked copy; never in the reference's data): the real
+    layer's fp64 outputs and gradients (tests/golden/avt_dual_modality.npz, oracle/make_dual_golden.py) against the HIP path, which
+    routes the further memberships as virtual tokens (MokaRouting.from_avt_masks: dup_src / extend / fold).  fp32 storage straight
+    against the golden (<= 1e-5); bf16 storage against the dense-mask oracle on the bf16-rounded operands (<= 1e-3 on y / dx)."""
+    import numpy as np
+    from moka_amd.functional import AdapterSpec, moka_linear
+    from moka_amd.routing import MokaRouting
+    from oracle.dense_avt import avt_dense_forward
+    dev = _dev()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "avt_dual_modality.npz"))
+    t = lambda k: torch.from_numpy(g[k])          # noqa: E731
+    masks = [m for m in t("masks")]
+    r, alpha, w = int(g["r"]), float(g["alpha"]), float(g["w"])
+    rt = MokaRouting.from_avt_masks([m.to(dev) for m in masks])
+    assert rt.dup_src is not None
+    spec = AdapterSpec(r, alpha / r, [1.0, 1.0, 1.0], w, 1.0 / math.sqrt(r))
+    rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()          # noqa: E731
+    # fp32 storage: the golden itself
+    f32 = torch.float32
+    x = t("x").to(dev, f32).requires_grad_(True)
+    A = [a.to(dev, f32).requires_grad_(True) for a in t("A")]
+    Bw = t("Bw").to(dev, f32).requires_grad_(True)
+    y = moka_linear(x, t("W").to(dev, f32), None, Bw, A, rt, spec)
+    y.backward(t("gy").to(dev, f32))
+    assert rel(y.detach(), t("ref_y")) <= 1e-5 and rel(x.grad, t("ref_dx")) <= 1e-5 and rel(Bw.grad, t("ref_dB")) <= 1e-5
+    for m in range(3):
+        assert rel(A[m].grad, t("ref_dA")[m]) <= 1e-5, m
+    # bf16 storage: the dense-mask oracle on the operands the kernels see
+    bf = torch.bfloat16
+    rb = lambda v: v.to(bf).double()              # noqa: E731
+    xo = rb(t("x")).requires_grad_(True)
+    Ao = [rb(a).requires_grad_(True) for a in t("A")]
+    Bo = rb(t("Bw")).requires_grad_(True)
+    yo = avt_dense_forward(xo, torch.zeros_like(t("W")), Ao, Bo, masks, alpha, r, w)          # adapter term alone
+    (yo * rb(t("gy"))).sum().backward()
+    x = t("x").to(dev, bf).requires_grad_(True)
+    A = [a.to(dev, bf).requires_grad_(True) for a in t("A")]
+    Bw = t("Bw").to(dev, bf).requires_grad_(True)
+    y = moka_linear(x, None, None, Bw, A, rt, spec)
+    y.backward(t("gy").to(dev, bf))
+    # y / dx of a token of two modalities are the bf16 SUM of two bf16 rows (real + virtual): up to three roundings there, one elsewhere
+    dual = ((masks[0] + masks[1] + masks[2]) > 1).reshape(-1)
+    for got, ref in ((y.detach().float(), yo.detach()), (x.grad.float(), xo.grad)):
+        got2, ref2 = got.reshape(-1, got.shape[-1]).cpu(), ref.reshape(-1, ref.shape[-1])
+        e1, e2 = rel(got2[~dual], ref2[~dual].to(bf).double()), rel(got2[dual], ref2[dual])
+        assert e1 <= TOL_BF16 and e2 <= 4e-3, (e1, e2)
+    assert rel(Bw.grad.float(), Bo.grad) <= 4e-3
+    for m in range(3):
+        assert rel(A[m].grad.float(), Ao[m].grad) <= 4e-3, m                        # (autograd gradients of bf16 parameters are stored as bf16)
+
+
+def test_avt_module_takes_overlapping_masks_like_the_reference_layer():
+    """The same golden through the drop-in module (moka_amd.peft_hyper.Linear.forward(x, [text, video, audio, question]), fp32 storage):
+    overlapping masks used to raise ValueError in the routing; the real layer accepts them (lora.py:460-532)."""
+    import numpy as np
+    from moka_amd.peft_hyper import Linear
+    dev = _dev()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "avt_dual_modality.npz"))
+    t = lambda k: torch.from_numpy(g[k])          # noqa: E731
+    r = int(g["r"])
+    d_out, d_in = g["W"].shape
+    lin = Linear(d_in, d_out, r=(r, r, r), lora_alpha=float(g["alpha"]), lora_nums=3, blc_alpha=1, blc_weight=float(g["w"]), lora_dropout=0.0,
+                 loramethod="train", bias=False).to(dev, torch.float32)
+    with torch.no_grad():
+        lin.weight.copy_(t("W"))
+        for i in range(3):
+            getattr(lin, f"lora_A{i}").weight.copy_(t("A")[i])
+        lin.lora_B0.weight.copy_(t("Bw"))
+    for p_ in lin.parameters():
+        p_.requires_grad_(True)
+    x = t("x").to(dev, torch.float32).requires_grad_(True)
+    y = lin(x, [m.to(dev) for m in t("masks")])
+    y.backward(t("gy").to(dev, torch.float32))
+    rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()          # noqa: E731
+    assert rel(y.detach(), t("ref_y")) <= 1e-5 and rel(x.grad, t("ref_dx")) <= 1e-5 and rel(lin.lora_B0.weight.grad, t("ref_dB")) <= 1e-5
+    for i in range(3):
+        assert rel(getattr(lin, f"lora_A{i}").weight.grad, t("ref_dA")[i]) <= 1e-5

@@ -73,12 +73,14 @@ def test_oracle_backward_matches_autograd_of_itself():
         assert torch.allclose(dA[m], A[m].grad, rtol=1e-10, atol=1e-12)
 
 
-def test_reference_on_overlapping_masks_is_pinned_and_the_routed_forms_refuse_them():
+def test_reference_on_overlapping_masks_is_pinned_and_the_hip_routing_expresses_them_with_virtual_tokens():
     """A token in TWO modality masks (lora.py:468 runs every adapter on its masked copy of x): the real AVT layer gives it one
     rank-space row per modality stream, each stream interacts on its own, the streams are summed -- pinned by
     tests/golden/avt_dual_modality.npz (oracle/make_dual_golden.py: reference fp64 outputs + gradients) through the dense-mask
-    restatement oracle/dense_avt.py.  One modality id per token cannot express that: the routed oracle and the host routing of the
-    HIP path raise ValueError instead of computing something else."""
+    restatement oracle/dense_avt.py.  One modality id per token cannot express that: the routed oracle raises ValueError; the host
+    routing of the HIP path (round 5) gives the token one VIRTUAL token per further membership behind the sample's real ones
+    (MokaRouting.dup_src / extend / fold) -- checked here on the CPU by running the routed oracle on the extended rows and folding,
+    tests/test_gpu_parity.py::test_tokens_of_two_modalities_against_the_reference_golden runs the kernels on them."""
     import os
     import numpy as np
     from moka_amd.routing import MokaRouting
@@ -102,5 +104,16 @@ def test_reference_on_overlapping_masks_is_pinned_and_the_routed_forms_refuse_th
     assert rel(y1, t("ref_y")) > 1e-3
     with pytest.raises(ValueError):
         O.routing_from_avt_masks(masks)
-    with pytest.raises(ValueError):
-        MokaRouting.from_avt_masks(masks)
+    rt = MokaRouting.from_avt_masks(masks)
+    B, L = masks[0].shape[:2]
+    n_extra = int(((masks[0] + masks[1] + masks[2]).clamp(min=1) - 1).sum())
+    assert rt.dup_src is not None and rt.S_real == L and rt.S == L + 16 and rt.T == B * rt.S and n_extra == 4
+    tok = rt.tok_mod[:rt.T].reshape(B, rt.S)
+    assert int((tok[:, L:] != 255).sum()) == n_extra                              # one virtual token per further membership
+    assert (tok[0, 5:8] == 0).all() and tok[1, 12] == 0                             # the token itself keeps its first (text) membership
+    ext = [(tok == m).to(torch.int32).reshape(B, rt.S, 1) for m in range(3)] + [torch.cat([masks[3], torch.zeros(B, 16, 1, dtype=masks[3].dtype)], 1)]
+    xe = rt.extend(t("x"))
+    assert torch.equal(xe[:, :L], t("x")) and torch.equal(xe[0, L:L + 3], t("x")[0, 5:8]) and torch.equal(xe[1, L], t("x")[1, 12])
+    ya, _ = O.avt_forward(xe, torch.zeros_like(t("W")), [a.detach() for a in A], Bw.detach(), ext, float(g["alpha"]), int(g["r"]), float(g["w"]))
+    y2 = t("x") @ t("W").t() + rt.fold(ya)
+    assert rel(y2, t("ref_y")) < 1e-12
