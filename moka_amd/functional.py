@@ -720,7 +720,7 @@ class MokaLinearFn(torch.autograd.Function):
 
 
 def moka_linear(x, W, bias, Bw, A: Sequence[torch.Tensor], rt: MokaRouting, spec: AdapterSpec):
-    if rt.dup_src is not None:
+    if getattr(rt, "dup_src", None) is not None:
         # tokens of several modalities (MokaRouting.from_avt_masks): the adapter term over the real + virtual tokens, the virtual rows folded
         # back onto the tokens they stand for (autograd carries their input gradients the same way); the frozen base sees the real tokens only
         ya = rt.fold(MokaLinearFn.apply(rt.extend(x), None, None, Bw, rt, spec, *A)).reshape(*x.shape[:-1], Bw.shape[0])
@@ -900,7 +900,7 @@ class MokaLinearGroupFn(torch.autograd.Function):
 
 def moka_linear_group(x, projections, rt: MokaRouting, specs: Sequence[AdapterSpec]):
     """projections: list of (W, bias|None, Bw, [A_0..A_{M-1}]) fed by the same x.  Returns the list of outputs."""
-    if x.dtype == torch.float32 or rt.dup_src is not None:          # fp32 storage / virtual tokens: correctness paths, one projection at a time
+    if x.dtype == torch.float32 or getattr(rt, "dup_src", None) is not None:          # fp32 storage / virtual tokens: correctness paths, one projection at a time
         return [moka_linear(x, W, b, Bw, A, rt, sp) for (W, b, Bw, A), sp in zip(projections, specs)]
     G = len(projections)
     M = len(projections[0][3])
