@@ -49,8 +49,12 @@ def test_errors_follow_the_reference():
     z = torch.zeros(1, 6, 1, dtype=torch.int32)
     with pytest.raises(IndexError):                                 # AVT sample without a question token (lora.py:489-490)
         MokaRouting.from_avt_masks([t, z, z, z])
-    with pytest.raises(ValueError):                                 # a token in two modalities
-        MokaRouting.from_avt_masks([t, t, z, t])
+    # a token in two modalities: one virtual token per further membership behind the sample's real ones (as the dense-mask reference
+    # computes it, lora.py:468-477; tests/test_oracle_golden.py checks the arithmetic) -- round 4 refused these masks
+    rt = MokaRouting.from_avt_masks([t, t, z, t])
+    assert rt.dup_src is not None and rt.S_real == 6 and rt.S == 6 + 16 and rt.dup_src[0, :6].tolist() == [0, 1, 2, 3, 4, 5]
+    assert (rt.tok_mod[:6] == 0).all() and (rt.tok_mod[6:12] == 1).all() and (rt.tok_mod[12:22] == 255).all()
+    assert MokaRouting.from_avt_masks([t, z, z, t]).dup_src is None
     with pytest.raises(ValueError):
         MokaRouting.from_vt_masks(torch.ones(1, 4, dtype=torch.bool), torch.ones(1, 4, dtype=torch.bool), torch.zeros(1, 4, dtype=torch.bool))
 
