@@ -35,6 +35,29 @@ def main(tag):
             print("no JSON line in", f)
             continue
         json.dump(json.loads(lines[-1]), open(os.path.join(dst, f"{tag}_{os.path.basename(f)}"), "w"))
+    # ---- the fixed term of the step, tracked as a first-class number: step = fixed_ms + ms_per_sequence * (sequences per GPU), least
+    #      squares over the batch sizes a schedule was run on (one chain: b1 / b2 / b4 / b8; two part-batch chains: b2 / b3 / b4 / b8)
+    def line(name):
+        f = os.path.join(src, name + ".json")
+        if not os.path.exists(f):
+            return None
+        ls = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        return json.loads(ls[-1]) if ls else None
+    fits = {}
+    for label, names in (("one chain (round 4's graph shape)", {1: "bench_b1", 2: "bench_b2_chains1", 4: "bench_b4_chains1", 8: "bench_b8_chains1"}),
+                         ("two part-batch chains (the default where the batch has two sequences)", {2: "bench_b2", 3: "bench_b3", 4: "bench_driver_command", 8: "bench_b8"})):
+        pts = [(bsz, line(n)["ms_per_step"]) for bsz, n in sorted(names.items()) if line(n) is not None]
+        if len(pts) >= 2:
+            n_ = len(pts)
+            sx, sy = sum(p[0] for p in pts), sum(p[1] for p in pts)
+            sxx, sxy = sum(p[0] * p[0] for p in pts), sum(p[0] * p[1] for p in pts)
+            slope = (n_ * sxy - sx * sy) / (n_ * sxx - sx * sx)
+            fits[label] = {"points_batch_ms": pts, "ms_per_sequence": round(slope, 3), "fixed_ms": round((sy - slope * sx) / n_, 3),
+                           "slope_alone_frac_of_8TBps": round(17.305e6 * 2048 / (slope * 1e-3) / 8e12, 4)}
+    if fits:
+        json.dump({"what": "step time = fixed_ms + ms_per_sequence x sequences per GPU (least squares over the batch sizes of one run of tools/round_profile.sh, one box)",
+                   "fits": fits}, open(os.path.join(dst, f"{tag}_fixed_term.json"), "w"), indent=1)
+        print(json.dumps(fits, indent=1))
     for name in ("kernel_trace.md", "timeline.md", "pmc_fetch_size.md", "pmc_write_size.md", "pmc_traffic.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
