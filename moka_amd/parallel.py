@@ -242,7 +242,9 @@ class FlatAdamW:
         1 / sqrt(1 - beta2^t), 1 - lr * wd} into device memory (``moka_adamw_begin_dev``).  The inputs are launch arguments -- copied when
         the launch is enqueued -- so a host that runs steps ahead of the GPU cannot disturb a step that has not read its coefficients
         yet (a pinned staging buffer, the round-3 form, could).  device_counter: the launch counts the steps itself instead of taking
-        t from the host: captured in a hipGraph it advances by one per replay (the caller keeps ``self.t`` in step for bookkeeping)."""
+        t from the host: captured in a hipGraph it advances by one per replay (the caller keeps ``self.t`` in step for bookkeeping).
+        NOTE: lr / betas / weight_decay are launch arguments too, so a CAPTURED begin_step replays with the hyper-parameters it was captured with:
+        a schedule that changes them needs a re-capture (or the live launch: ``MokaFlatOptimizer`` / ``attach`` never capture it)."""
         from . import _lib
         if not self.master.is_cuda:
             raise _lib.MokaError("moka_amd: FlatAdamW runs as a HIP kernel; the buffers live on %s" % self.master.device)
@@ -293,6 +295,8 @@ class FlatAdamW:
                 setattr(self, k, float(sd[k]))
         if "betas" in sd:
             self.betas = (float(sd["betas"][0]), float(sd["betas"][1]))
+        if self._state is not None:
+            self.set_device_step(self.t)             # (a captured begin_step(device_counter=True) resumes the bias correction at step t + 1, not at 1)
 
 
 _LAYER_RE = re.compile(r"^(.*?(?:^|\.)layers)\.(\d+)\.")
@@ -668,8 +672,16 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
             for pn, _p in mod.named_parameters(recurse=False):
                 owner[(mod_name + "." if mod_name else "") + pn] = mod
         if no_decay == "hf":
-            def no_decay(n, p, mod):                 # transformers.Trainer.get_decay_parameter_names: no norm layers, no biases
-                return n.endswith("bias") or "norm" in type(mod).__name__.lower()
+            # transformers.Trainer.get_decay_parameter_names: every parameter of a normalisation layer (isinstance against ALL_LAYERNORM_LAYERS) and
+            # every parameter whose name contains "bias" takes no decay; modules the table does not know (an RMSNorm of one's own) count by class name
+            try:
+                from transformers.pytorch_utils import ALL_LAYERNORM_LAYERS as _NORMS
+                _norms = tuple(_NORMS)
+            except Exception:
+                _norms = (nn.LayerNorm,)
+
+            def no_decay(n, p, mod):
+                return "bias" in n or isinstance(mod, _norms) or "norm" in type(mod).__name__.lower()
         ranges = []
         for n, o, sz in zip(names, offsets, sizes):
             if no_decay(n, by_name[n], owner.get(n)):
