@@ -82,9 +82,12 @@ class Unit:
     """The projections of one decoder layer that are fed by the same input (q/k/v; o; gate/up; down) with the
     ctypes argument lists of the six (grouped) entry points pre-built.  G = 1 is the per-projection path."""
 
-    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False):
+    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False, company=1):
         from moka_amd import _lib
         G = len(members)
+        # moka_opts.company: how many independent chains run side by side (the pass over gy then sizes its token runs for its share of the CUs)
+        self.opts = _lib.MokaOpts(None, 0, int(company))
+        ob = byref(self.opts) if company > 1 else None
         # per unit: the library's advice for this shape (moka_up_fwd_fused_pays: e.g. not for the 70B widths' single projections)
         self.fused = bool(fused and _lib.up_fwd_fused_pays(T, _lib.ksplit(T, members[0]["d_in"], r, G), [m["d_out"] for m in members], r))
         self.label, self.G, self.T = label, G, T
@@ -127,11 +130,11 @@ class Unit:
                                                               BwT, AT, G, r, w, c)),
             # the weight shadows the backward reads (BwT, AT): functions of the weights alone -> once per step, off the chain
             "moka_weight_shadows": ("moka_weight_shadows_group", (Bw, do, A, self.d_in, BwT, AT, G, r, M)),
-            "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0, None)),
+            "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0, ob)),
             # the two outputs of moka_up_bwd as separate calls (--defer-db: where dB is a pass of its own anyway, moka_up_bwd_passes() == 2,
             # it leaves the dependency chain like dA_m)
-            "moka_up_bwd:g": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, None, T, r, do, M, G, 0, None)),
-            "moka_up_bwd:dB": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, None, dB, T, r, do, M, G, 0, None)),
+            "moka_up_bwd:g": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, None, T, r, do, M, G, 0, ob)),
+            "moka_up_bwd:dB": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, None, dB, T, r, do, M, G, 0, ob)),
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
                                                       drop_p, sd, 0, None)),
@@ -266,7 +269,8 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                 units.append(Unit("+".join(m["name"].replace("_proj", "") for m in mem), mem, Tc, r, M, rt, acts[src], dacts[src], scratch2[len(units) & 1],
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
-                                  own_dh_kmj=own[l % n_own][len(units) % len(unit_defs)] if defer else None, fused=fused))
+                                  own_dh_kmj=own[l % n_own][len(units) % len(unit_defs)] if defer else None, fused=fused,
+                                  company=chains if getattr(args, "company_hint", "on") == "on" else 1))
         layer_da, layer_db = [], []
         if defer:
             per = len(unit_defs)
@@ -766,6 +770,9 @@ def main():
                          "of the other; they share the parameters, the gradient accumulators and the optimizer slices.  0 (default) = 2 where the "
                          "batch splits evenly and the step is replayed as graphs, else 1.  Per-kernel durations (`roofline`, `kernels`) are "
                          "taken with the chains back to back on one stream")
+    ap.add_argument("--company-hint", choices=("on", "off"), default="on",
+                    help="with chains: tell the library how many chains run side by side (moka_opts.company: the pass over gy sizes its token runs for its "
+                         "share of the CUs)")
     ap.add_argument("--chain-stagger", type=int, default=0,
                     help="MB of a fill launched in front of the second (third, ...) chain's forward: a phase shift between otherwise identical chains (A/B)")
     ap.add_argument("--defer-da", choices=("auto", "off", "main", "side", "window", "layer", "bucket", "unit"), default="auto",

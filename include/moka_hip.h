@@ -69,12 +69,12 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      602            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+#define MOKA_VERSION      603            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
                                             at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
                                             0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional;
                                             0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_weight_shadows_batch, moka_up_fwd_fused at every rank pad;
-                                            0.6.2: moka_ksplit_group() */
+                                            0.6.2: moka_ksplit_group(); 0.6.3: moka_opts.company */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MAX_SHADOW_BATCH 16         /* projections of one moka_weight_shadows_batch launch */
@@ -110,6 +110,10 @@ typedef struct moka_opts {
     void*  det_ws;      /* != NULL: deterministic weight gradients (see "deterministic weight gradients" below); 16-byte aligned,
                            used by this call's launches on `stream` -- concurrent calls on other streams need their own */
     size_t det_bytes;   /* >= moka_deterministic_ws_bytes(T, C_max, r, G, M) for this call, checked before anything is launched */
+    int    company;     /* 0 / 1: the caller's launches have the device to themselves.  N > 1: the caller runs N independent launch chains side by
+                           side (part-batches on N streams / branches of one hipGraph): moka_up_bwd then sizes the token runs of its weight-gradient
+                           half for 1 / N of the CUs -- longer runs, fewer dB atomics -- instead of covering the chip on its own (7B widths,
+                           r = 32, two chains of 4096 tokens: 40.5 -> 39.5 ms per step; r = 16: no difference).  Results are the same sums. */
 } moka_opts;
 
 int         moka_version(void);

@@ -30,7 +30,7 @@ class MokaRoutingStruct(Structure):
 
 class MokaOpts(ctypes.Structure):
     """moka_opts of include/moka_hip.h: per-call options of the backward entry points (the deterministic-mode workspace)."""
-    _fields_ = [("det_ws", c_void_p), ("det_bytes", ctypes.c_size_t)]
+    _fields_ = [("det_ws", c_void_p), ("det_bytes", ctypes.c_size_t), ("company", c_int)]
 
 
 class MokaError(RuntimeError):

@@ -3887,11 +3887,15 @@ static int current_device() {
 struct DetCall { float* ws; size_t bytes; };
 static thread_local DetCall t_det = {nullptr, 0};
 static thread_local size_t g_det_need = 0;              // set by a launcher that found the workspace too small
+static thread_local int t_company = 1;                  // moka_opts.company of the call in progress (independent launch chains side by side)
 #define g_det_ws (t_det.ws)
 #define g_det_bytes (t_det.bytes)
 struct DetScope {
-    explicit DetScope(const moka_opts* o) { t_det.ws = o ? (float*)o->det_ws : nullptr; t_det.bytes = (o && o->det_ws) ? o->det_bytes : 0; g_det_need = 0; }
-    ~DetScope() { t_det.ws = nullptr; t_det.bytes = 0; g_det_need = 0; }
+    explicit DetScope(const moka_opts* o) {
+        t_det.ws = o ? (float*)o->det_ws : nullptr; t_det.bytes = (o && o->det_ws) ? o->det_bytes : 0; g_det_need = 0;
+        t_company = (o && o->company > 1) ? (o->company > 8 ? 8 : o->company) : 1;
+    }
+    ~DetScope() { t_det.ws = nullptr; t_det.bytes = 0; g_det_need = 0; t_company = 1; }
 };
 
 static int fail(int code, const char* fmt, ...) {
@@ -4387,9 +4391,11 @@ static int launch_gs_auto(GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     for (int z = 0; z < nz; ++z) active += (gb.z[z].C + 511) / 512;
     // token groups per workgroup: long runs keep the dB atomics (and the start-ups) down, as long as every CU still gets a workgroup
     // (T = 8192, kernel sequence of a step: 4096 wide 4 / 8 / 16 groups -> 28.7 / 24.6 / 27.8 us, 11008 wide 64.1 / 58.8 / 51.0 us)
+    // (moka_opts.company = N: the caller runs N chains side by side -- this launch covers its share of the CUs, the runs get longer)
     auto blocks = [&](int n) { return active * ((ngroups + n - 1) / n); };
-    int ng = (4 * blocks(16) >= 5L * num_cu()) ? 16 : (blocks(8) >= (long)num_cu() ? 8 : 4);
-    while (ng > 2 && blocks(ng) < (long)num_cu() / 2) ng >>= 1;
+    const long cus = (long)num_cu() / t_company;
+    int ng = (4 * blocks(16) >= 5L * cus) ? 16 : (blocks(8) >= cus ? 8 : 4);
+    while (ng > 2 && blocks(ng) < cus / 2) ng >>= 1;
     if (g_tune_gy_ng > 0) ng = g_tune_gy_ng;
     launch_gs_t<RP, WITH_DB>(gb, nz, (Cmax + 511) / 512, ng, st);
     return check_launch("moka_gs_kernel");
