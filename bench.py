@@ -1321,6 +1321,8 @@ def main():
                 traffic = round(traffic / args.chains)   # (the PMC passes profile whole-batch launches; traffic is linear in the tokens)
             if args.chains > 1 and traffic is not None:
                 traffic_src += " / %d (launches of %d tokens)" % (args.chains, T // args.chains)
+            elif traffic is not None:
+                traffic_src += " (measured on launches of %d tokens, scaled)" % json.load(open(PMC_TRAFFIC_FILE))["tokens"]
         out = {
             "metric": "tokens/sec/GPU Llama-2-7B MokA r=16 seq2048 bf16; adapter HBM %roofline" if (args.model, args.rank, args.seq) == ("7b", 16, 2048)
                       else "tokens/sec/GPU Llama-2-%s MokA r=%d seq%d bf16; adapter HBM %%roofline" % (args.model.upper(), args.rank, args.seq),

@@ -1,7 +1,7 @@
 #!/bin/bash
 export MOKA_HIP_LIB=$PWD/moka_amd/libmoka_hip_diag.so
 out=gpurun_out/r05r32; mkdir -p $out
-for t in none gy_ng=8 gy_ng=16 gy_ng=32 none; do
+for t in "$@"; do
   if [ "$t" = "none" ]; then tt=""; else tt=$t; fi
   MOKA_TUNE=$tt timeout 300 python bench.py --rank 32 --steps 20 --no-cpu-baseline --no-traffic 2>>$out/err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"$t\", d[\"value\"], d[\"ms_per_step\"], d[\"entry_point_ms_per_pass\"])" | tee -a $out/tune.log
 done
