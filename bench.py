@@ -759,9 +759,13 @@ def main():
                          "packet of its own: bracketing all 128 launches of a step costs 0.7 ms of it; 5 is coprime to the 4 unit shapes "
                          "of a layer, so the sample covers them evenly)")
     ap.add_argument("--comm-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (153 instead of 306 MB per step at 7B r=16; accumulation stays fp32)")
+    ap.add_argument("--buckets", type=int, default=0,
+                    help="gradient buckets (groups of whole decoder layers, each all-reduced / updated as soon as its layers' backward has been enqueued); "
+                         "with collectives every bucket is a hipGraph of its own: fewer buckets = fewer points at which the chains meet.  0 (default) = "
+                         "8 equal buckets without collectives, the geometric layout 1 / 3 / 9 / 19 layers (parallel.geometric_buckets) with them")
     ap.add_argument("--tail-layers", type=int, default=-1,
                     help="layers of the gradient bucket that ships last (it holds layer 0: its all-reduce has nothing left to hide behind); the other "
-                         "layers split evenly over the remaining 7 buckets.  -1 (default) = 1 when collectives run, 0 (8 equal buckets) otherwise")
+                         "layers split evenly over the remaining buckets (with --buckets N).  -1 (default) / 0: no tail bucket (the default layout with collectives is geometric)")
     ap.add_argument("--no-traffic", action="store_true", help="leave roofline.traffic null instead of reading the PMC summary under profiles/")
     ap.add_argument("--chains", type=int, default=0,
                     help="process the micro-batch as this many part-batches (batch / chains sequences each) whose launch chains are branches of "
@@ -899,10 +903,17 @@ def main():
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
     if args.chains > 1 and args.graph == "off":
         raise SystemExit("--chains > 1 exists as branches of captured graphs (--graph all / bwd)")
-    # (collectives on: the bucket that ships last -- layer 0's -- is one layer, so that the all-reduce nothing is left to hide is small)
-    tail = args.tail_layers if args.tail_layers >= 0 else (1 if comm else 0)
-    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=8, comm_dtype=torch.bfloat16 if args.comm_bf16 else None,
-                                                                       force_comm=args.force_comm, tail_layers=tail or None),
+    # collectives on: geometric buckets -- 1, 3, 9, 19 layers from layer 0 up.  The backward walks the layers last -> first: the big buckets
+    # ship early with plenty of backward left to hide their all-reduce, the bucket nothing is left to hide is ONE layer, and there are four
+    # points (not eight) at which the per-bucket graphs make the chains meet (one GPU, one-rank RCCL: 32.0-32.5 -> 31.3 ms)
+    from moka_amd.parallel import geometric_buckets
+    tail = args.tail_layers if args.tail_layers >= 0 else 0
+    sizes = None
+    if args.buckets == 0 and comm and tail == 0:
+        sizes = geometric_buckets(args.layers)
+    nb = args.buckets if args.buckets > 0 else 8
+    wl = build_workload(args, dev, lib, lambda n, ends: FlatGradBucket(n, ends, dev, n_buckets=nb, comm_dtype=torch.bfloat16 if args.comm_bf16 else None,
+                                                                       force_comm=args.force_comm, tail_layers=tail or None, bucket_sizes=sizes),
                         chains=args.chains)
     T = wl["T"]
     torch.cuda.synchronize()

@@ -33,10 +33,14 @@ class FlatGradBucket:
 
     def __init__(self, numel: int, layer_end: Sequence[int], device, n_buckets: int = 8,
                  process_group=None, dtype=torch.float32, comm_dtype: Optional[torch.dtype] = None, force_comm: bool = False,
-                 tail_layers: Optional[int] = None):
+                 tail_layers: Optional[int] = None, bucket_sizes: Optional[Sequence[int]] = None):
         """tail_layers: the backward walks the layers last -> first, so the bucket that holds layer 0 is the one whose all-reduce nothing
         is left to hide; ``tail_layers = t`` makes that bucket layers [0, t) and splits the other layers evenly over the remaining
         ``n_buckets - 1`` buckets (None: ``n_buckets`` equal groups) -- the exposed tail of the step is one small collective.
+        bucket_sizes: the layout spelled out -- layers per bucket from layer 0 UPWARD (the first entry is the bucket that ships last), summing
+        to the number of layers; overrides n_buckets / tail_layers.  ``geometric_buckets(n)`` = 1, 3, 9, ... : every bucket's all-reduce has
+        about a third of its own layers' backward left to hide behind, and there are few buckets (where every bucket is a hipGraph of its own,
+        the launch chains meet at every bucket boundary).
         comm_dtype: payload type of the all-reduce (None = the buffer's own fp32).  torch.bfloat16 halves the bytes on
         xGMI (7B r=16: 153 instead of 306 MB per step -- the figure SURVEY.md 8(e) sized): a bucket is rounded to bf16 into a
         staging buffer, summed there and widened back; accumulation across micro-batches stays fp32.
@@ -57,7 +61,16 @@ class FlatGradBucket:
         self.comm = self.world > 1 or bool(force_comm)      # do the collectives run?
         self.layers_per_bucket = max(1, -(-self.n_layers // max(1, n_buckets)))
         # buckets = contiguous groups of layers [first, end); a bucket ships when its FIRST layer reports (layers arrive last -> first)
-        if tail_layers is not None and 0 < int(tail_layers) < self.n_layers and n_buckets > 1:
+        if bucket_sizes is not None:
+            sizes_ = [int(v) for v in bucket_sizes]
+            if any(v < 1 for v in sizes_) or sum(sizes_) != self.n_layers:
+                raise ValueError(f"bucket_sizes {sizes_} must be positive and sum to the {self.n_layers} layers")
+            firsts, acc_ = [], 0
+            for v in sizes_:
+                firsts.append(acc_)
+                acc_ += v
+            self.layers_per_bucket = max(sizes_)
+        elif tail_layers is not None and 0 < int(tail_layers) < self.n_layers and n_buckets > 1:
             t = int(tail_layers)
             per = max(1, -(-(self.n_layers - t) // (n_buckets - 1)))
             firsts = [0] + list(range(t, self.n_layers, per))
@@ -170,6 +183,21 @@ class FlatGradBucket:
         self._pending.clear()
         if average and self.world > 1:
             self.flat.div_(self.world)
+
+
+def geometric_buckets(n_layers: int, tail: int = 1, ratio: float = 3.0) -> List[int]:
+    """Layers per gradient bucket from layer 0 upward: tail, ~ratio x tail, ... (the last entry takes what is left): 32 layers -> [1, 3, 9, 19].
+    The backward walks the layers last -> first, so the LARGE buckets ship early and overlap with plenty of backward, and the buckets that
+    ship late -- little or nothing left to hide them -- are small."""
+    sizes, left, cur = [], int(n_layers), max(1, int(tail))
+    while left > 0:
+        take = min(left, cur)
+        if left - take < cur:                        # (what is left would be smaller than this bucket: merge it)
+            take = left if sizes else take
+        sizes.append(take)
+        left -= take
+        cur = max(cur + 1, int(round(cur * ratio)))
+    return sizes
 
 
 class FlatAdamW:
@@ -557,7 +585,7 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
            comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True,
            optimizer_in_backward: bool = False, force_comm: bool = False, no_decay="hf",
-           overlap_base: Optional[bool] = None, tail_layers: Optional[int] = None) -> AdapterDataParallel:
+           overlap_base: Optional[bool] = None, tail_layers: Optional[int] = None, bucket_sizes=None) -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
     base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
@@ -587,6 +615,8 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
       backward of the earlier layers; ``step()`` then only updates what no bucket covered.  No gradient clipping in this mode (the
       global norm does not exist yet when the first bucket is updated), and every synchronised backward must be followed by ``step()``.
 
+    * ``tail_layers`` / ``bucket_sizes``: the layout of the gradient buckets (``FlatGradBucket``): a small bucket for the layers whose
+      backward runs last, or the whole layout (``"geometric"``: 1, 3, 9, ... layers from the first one up);
     * ``force_comm``: run the bucket all-reduces even in a process group of one rank (``FlatGradBucket``): the communication path
       -- RCCL's own stream, the bucket hooks, the optimizer slices behind the all-reduce -- as N > 1 ranks run it, on one GPU;
     * ``no_decay``: which parameters take no weight decay: ``"hf"`` (default) = what HF ``Trainer``'s default optimizer excludes and
@@ -651,8 +681,10 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
         sizes.append(named[k][1].numel())
         off += (named[k][1].numel() + 7) // 8 * 8                               # 16-byte aligned bf16 / 32-byte fp32 views
     ends.append(off)
+    if bucket_sizes == "geometric":                  # 1, 3, 9, ... groups of layers from the first one up (geometric_buckets)
+        bucket_sizes = geometric_buckets(len(ends))
     bucket = FlatGradBucket(off, ends, dev, n_buckets=n_buckets, process_group=process_group, comm_dtype=comm_dtype, force_comm=force_comm,
-                            tail_layers=tail_layers)
+                            tail_layers=tail_layers, bucket_sizes=bucket_sizes)
     master = torch.zeros(off, dtype=torch.float32, device=dev)
     work = torch.zeros(off, dtype=torch.bfloat16, device=dev)
     by_name = dict(named)

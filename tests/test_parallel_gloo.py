@@ -444,3 +444,16 @@ def test_bucket_update_behind_a_bf16_payload_world2():
         assert p.exitcode == 0
     for _, e32, e16 in res:
         assert e32 <= 1e-6 and e16 <= 1e-2, res             # bf16 payload: 2^-9 per addend
+
+
+def test_geometric_bucket_layout():
+    """bucket_sizes spells the layout out (layers per bucket from layer 0 up); geometric_buckets: 1, 3, 9, ... -- the buckets that ship late are small."""
+    from moka_amd.parallel import FlatGradBucket, geometric_buckets
+    assert geometric_buckets(32) == [1, 3, 9, 19] and geometric_buckets(40) == [1, 3, 9, 27] and geometric_buckets(80) == [1, 3, 9, 27, 40]
+    assert geometric_buckets(1) == [1] and geometric_buckets(4) == [1, 3] and all(sum(geometric_buckets(n)) == n for n in range(1, 100))
+    ends = [10 * (i + 1) for i in range(32)]
+    b = FlatGradBucket(320, ends, "cpu", bucket_sizes=geometric_buckets(32))
+    assert b.bucket_firsts() == [0, 1, 4, 13] and [len(b.bucket_layers(f)) for f in b.bucket_firsts()] == [1, 3, 9, 19]
+    assert b.bucket_bounds(13) == (130, 320) and b.bucket_bounds(0) == (0, 10) and b.last_bucket_bytes() == 40
+    with pytest.raises(ValueError):
+        FlatGradBucket(320, ends, "cpu", bucket_sizes=[1, 3, 9])
