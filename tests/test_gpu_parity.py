@@ -1232,3 +1232,45 @@ def test_avt_module_takes_overlapping_masks_like_the_reference_layer():
     assert rel(y.detach(), t("ref_y")) <= 1e-5 and rel(x.grad, t("ref_dx")) <= 1e-5 and rel(lin.lora_B0.weight.grad, t("ref_dB")) <= 1e-5
     for i in range(3):
         assert rel(getattr(lin, f"lora_A{i}").weight.grad, t("ref_dA")[i]) <= 1e-5
+
+
+@pytest.mark.parametrize("r", [16, 32])
+def test_company_hint_changes_the_launch_shape_not_the_sums(r):
+    """moka_opts.company = N (the caller runs N launch chains side by side): moka_up_bwd sizes the token runs of its weight-gradient half
+    for 1 / N of the CUs -- fewer, longer runs, fewer dB atomics.  The split-K slices g are the same bits, dB the same sums (fp32 atomics in
+    another order)."""
+    import ctypes
+    from moka_amd import _lib
+    from moka_amd import functional as F
+    from moka_amd.routing import MokaRouting
+    dev = _dev()
+    lib = _lib.load()
+    B, S, d_out = 2, 2048, 4096
+    gen = torch.Generator().manual_seed(11 + r)
+    tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)] + [q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev)]
+    rt = MokaRouting.from_avt_masks(masks)
+    T = B * S
+    bf = torch.bfloat16
+    x = torch.randn(T, 256, generator=gen).to(dev, bf)
+    A = [(torch.randn(r, 256, generator=gen) * 0.1).to(dev, bf) for _ in range(3)]
+    Bw = (torch.randn(d_out, r, generator=gen) * 0.05).to(dev, bf)
+    gy = torch.randn(T, d_out, generator=gen).to(dev, bf)
+    part = F.down_fwd(x, A, rt, r, 1.0)
+    st = F.cross_fwd(part, rt, r, [1.0, 1.0, 1.0], 1.0, 1.0 / math.sqrt(r), Bw=Bw, A=A)
+    ks = _lib.ksplit_bwd(T, d_out, r)
+    so = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
+    outs = []
+    for company in (1, 2, 4):
+        g_part = torch.zeros(ks, T, _lib.rank_pad(r), device=dev)
+        dB = torch.zeros(d_out, r, device=dev)
+        opts = _lib.MokaOpts(None, 0, company)
+        rc = lib.moka_up_bwd(gy.data_ptr(), st.hp_kmj.data_ptr(), st.BwT.data_ptr(), rt.tok_mod.data_ptr(), so, g_part.data_ptr(), dB.data_ptr(),
+                             T, r, d_out, 3, 0, ctypes.byref(opts), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.moka_last_error()
+        torch.cuda.synchronize()
+        outs.append((g_part, dB))
+    for g_part, dB in outs[1:]:
+        assert torch.equal(g_part, outs[0][0])
+        assert float((dB - outs[0][1]).abs().max()) <= 2e-5 * float(outs[0][1].abs().max())
+    assert float(outs[0][1].abs().max()) > 0
