@@ -1377,7 +1377,11 @@ def main():
                          "algorithmic_bytes_per_launch": round(dom_bytes / cnt[dom]),
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches_timed": cnt[dom],
                          "where": ("live passes right behind the timed region (the timed region replays a hipGraph: nothing can be bracketed inside it)"
-                                   if roof_behind else "HIP events inside the timed region (every %d-th launch)" % args.bracket_every)},
+                                   if roof_behind else "HIP events inside the timed region (every %d-th launch)" % args.bracket_every),
+                         "note": (None if args.chains == 1 else
+                                  "launches of %d tokens timed ALONE, the %d chains back to back on one stream; in the step they run beside the other chain's "
+                                  "launches (not observable inside a graph; rocprofv3 serialises the dispatches) -- adapter_hbm_roofline_frac is the step's figure"
+                                  % (T // args.chains, args.chains))},
             "entry_point_ms_per_pass": {n: round(tot_x[n], 3) for n in ENTRY},
             "forward_only": fwd_only,
             "kernels": table,
