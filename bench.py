@@ -832,7 +832,8 @@ def main():
         # auto: two part-batch chains where the step is replayed as hipGraphs, the batch has two sequences and the launches are short enough to
         # leave gaps (7B widths, rank pad <= 32: 32.2 -> 30.5 ms at r = 16, 41.7 -> 40.9 at r = 32; the 70B widths lose, 160.3 -> 166.1 ms, and
         # so does rank 64 at the 13B widths, 78.6 -> 79.5: their launches fill the chip on their own)
-        args.chains = 2 if (args.graph != "off" and args.batch >= 2 and args.model == "7b" and args.rank <= 32) else 1
+        # (13B widths: r = 16 54.9 -> 48.9 ms, r = 32 63.8 -> 61.2 ms)
+        args.chains = 2 if (args.graph != "off" and args.batch >= 2 and args.model in ("7b", "13b") and args.rank <= 32) else 1
     if args.graph_topology == "auto":
         args.graph_topology = "hub" if args.chains > 1 else "chain"      # (one chain: 32.15-32.27 ms in round 4's shape, 32.39 as hub + 1 chain)
     if args.defer_da == "auto":
