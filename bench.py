@@ -902,8 +902,6 @@ def main():
     SHADOWS_BATCH = args.shadows_batch == "on"
     CHAIN_FIRST = args.capture_order == "chain-first"
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
-    if args.chains > 1 and args.graph == "off":
-        raise SystemExit("--chains > 1 exists as branches of captured graphs (--graph all / bwd)")
     # collectives on: geometric buckets -- 1, 3, 9, 19 layers from layer 0 up.  The backward walks the layers last -> first: the big buckets
     # ship early with plenty of backward left to hide their all-reduce, the bucket nothing is left to hide is ONE layer, and there are four
     # points (not eight) at which the per-bucket graphs make the chains meet (one GPU, one-rank RCCL: 32.0-32.5 -> 31.3 ms)
@@ -1054,6 +1052,8 @@ def main():
                 return [(l, l + 1) for l in range(hi_ - 1, lo_ - 1, -1)]
 
             graph_keep = []
+            if os.environ.get("MOKA_BENCH_FAIL_CAPTURE") == "1":
+                raise RuntimeError("MOKA_BENCH_FAIL_CAPTURE=1 (test hook: exercise the live fallback)")
             if args.graph == "all":
                 # (collectives cannot ride inside the graph: capturing the one-rank RCCL all-reduce with torch 2.10 / RCCL 2.26.6 segfaults at
                 #  capture time -- measured round 4 -- so N > 1 and --force-comm use one graph per gradient bucket with the hooks between them)
@@ -1099,10 +1099,10 @@ def main():
                     bwd_graphs.append((g, lo, hi))
             torch.cuda.synchronize()
         except Exception as exc:                         # capture is an optimisation, never a requirement
-            if args.chains > 1:
-                raise SystemExit(f"bench: hipGraph capture failed ({exc!r}) and --chains {args.chains} exists only as branches of the one graph")
-            print(f"bench: hipGraph capture failed ({exc!r}); launching live", file=sys.stderr)
+            # (with chains: the part-batches then run one after the other on the one stream -- every launch of the step still happens)
+            print(f"bench: hipGraph capture failed ({exc!r}); launching live" + (", the %d chains back to back" % args.chains if args.chains > 1 else ""), file=sys.stderr)
             fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
+            args.graph = "off (capture failed)"          # (what the line reports is what ran)
             torch.cuda.synchronize()
 
     # N > 1: how long the main stream stands still in bucket.finish() (the part of the all-reduce the backward did not hide)
@@ -1125,17 +1125,22 @@ def main():
             if fwd_graph is not None:
                 fwd_graph.replay()
             else:
-                run_forward(lib, wl, sp, rec, shadows=shadows_main)
+                for ch in wl["chains"]:
+                    run_forward(lib, ch, sp, rec, shadows=shadows_main)
             if bwd_graphs is not None:
                 for g, lo, hi in bwd_graphs:
                     g.replay()
                     for l in range(hi - 1, lo - 1, -1):
                         bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
             else:
-                run_backward(lib, wl, sp, L, bucket.layer_done, rec,   # all-reduce of finished layer groups overlaps the rest
-                             defer=(args.defer_da, main_stream, live_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None,
-                             bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and not comm) else None,
-                             shadows_after_opt=shadows_opt and opt_in_bwd and not comm)
+                # (live launches: the chains one after the other; the bucket hooks / optimizer slices ride with the LAST chain's layers -- every
+                #  earlier chain's gradients are in front of them in stream order)
+                for ci, ch in enumerate(wl["chains"]):
+                    last = ci == len(wl["chains"]) - 1
+                    run_backward(lib, ch, sp, L, bucket.layer_done if last else None, rec,   # all-reduce of finished layer groups overlaps the rest
+                                 defer=(args.defer_da, main_stream, live_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None,
+                                 bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and not comm and last) else None,
+                                 shadows_after_opt=shadows_opt and opt_in_bwd and not comm and last)
         if comm_ev is not None and i >= args.warmup:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
@@ -1146,7 +1151,7 @@ def main():
             bucket.finish(average=opt is None)       # join the all-reduces; the optimizer kernel averages (grad_scale)
         if opt is not None and not opt_in_bwd:
             opt.step(grad_scale=1.0 / world, zero_grad=True)
-        if shadows_opt and opt is not None and not (opt_in_bwd and not comm and (fwd_bwd_graph is not None or args.chains == 1)) and not shadows_in_cb:
+        if shadows_opt and opt is not None and not (opt_in_bwd and not comm) and not shadows_in_cb:
             run_shadows(lib, wl, sp, range(L))       # (every weight has changed: the shadows of the whole stack, behind the step)
 
     for i in range(args.warmup):
@@ -1361,7 +1366,7 @@ def main():
                             "grad_payload": "%s payload of the fp32 flat bucket, %d buckets, all-reduce on a side stream overlapped with the backward" % ("bf16" if args.comm_bf16 else "fp32", len(bucket.bucket_firsts())),
                             "bucket_layers": [len(bucket.bucket_layers(f)) for f in bucket.bucket_firsts()], "last_bucket_bytes": bucket.last_bucket_bytes(),
                             "adapter_params": wl["n_params"]},
-            "graph": args.graph, "graph_replay_host_ms": replay_host_ms, "graph_topology": ("hub" if args.hub else "chain") if args.graph != "off" else None,
+            "graph": args.graph, "graph_replay_host_ms": replay_host_ms, "graph_topology": ("hub" if args.hub else "chain") if not args.graph.startswith("off") else None,
             "graph_check": graph_check,
             "fused_forward": ("all units" if all(u.fused for u in units_all) else ("units " + ", ".join(sorted({u.label for u in units_all if u.fused})) if any(u.fused for u in units_all) else False)) if args.fused else False,
             "chains": args.chains,

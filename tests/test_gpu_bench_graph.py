@@ -50,3 +50,25 @@ def test_captured_schedule_equals_live_launches(extra):
 def test_default_line_says_how_it_ran():
     out = _bench()
     assert out["graph"] == "all" and out["graph_topology"] == "hub" and out["chains"] == 2 and out["defer_dA"] in ("layer", "side", "unit")
+
+
+def test_capture_failure_falls_back_to_live_launches_of_every_chain():
+    """hipGraph capture is an optimisation: when it fails the step is launched live -- with two chains, both part-batches back to back on the
+    one stream (it used to run only the first chain's launches; then it exited).  MOKA_BENCH_FAIL_CAPTURE=1 is the test hook."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    outs = {}
+    for name, extra_env, extra in (("graph", {}, ()), ("fallback", {"MOKA_BENCH_FAIL_CAPTURE": "1"}, ()), ("off", {}, ("--graph", "off", "--chains", "2"))):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layers", "4", "--seq", "512", "--steps", "3", "--warmup", "1",
+                              "--no-cpu-baseline", "--no-traffic", *extra], capture_output=True, text=True, timeout=900, env={**env, **extra_env}, cwd=ROOT)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        outs[name] = json.loads(lines[0])
+        if name == "fallback":
+            assert "launching live" in res.stderr and "2 chains back to back" in res.stderr
+    assert outs["graph"]["chains"] == outs["fallback"]["chains"] == outs["off"]["chains"] == 2
+    # the same launches, the same bytes: the per-pass entry-point table (taken from live passes in every mode) covers both chains
+    for k in ("moka_up_fwd", "moka_down_bwd"):
+        a, b = outs["graph"]["entry_point_ms_per_pass"][k], outs["fallback"]["entry_point_ms_per_pass"][k]
+        assert a > 0 and b > 0 and 0.5 < a / b < 2.0
+    assert outs["fallback"]["value"] > 0 and outs["off"]["value"] > 0 and outs["graph"]["value"] >= 0.8 * outs["fallback"]["value"]
