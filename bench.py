@@ -9,7 +9,9 @@ sequences of 2048 tokens per GPU (SURVEY.md 8(d) layout: 16 text | 256 image | 1
 128 audio | 64 question | text), then the data-parallel step on the adapter gradients
 (bucketed RCCL all-reduce of the flat fp32 gradient buffer on a side stream, launched as soon as
 a group of layers has finished its backward and overlapped with the backward of the remaining
-layers) and a fused AdamW update of the adapter parameters.  The frozen base GEMMs
+layers) and a fused AdamW update of the adapter parameters.  By default the micro-batch runs as TWO part-batch chains (half the sequences
+each: nothing in the model mixes tokens of different samples) captured as branches of one hub-shaped hipGraph that share the parameters,
+the gradient accumulators and the optimizer slices (--chains).  The frozen base GEMMs
 are NOT part of the hot path (they run on stock PyTorch-ROCm); their outputs / input
 gradients are the in/out operands of the kernels and are resident in HBM before the clock
 starts.
