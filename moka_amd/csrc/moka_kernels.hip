@@ -4419,10 +4419,11 @@ static int bwd_kw(int T, int C, int r);
 template <int RP, bool WITH_DB>
 static int launch_gy_rp(const GyBatch& gb_in, int nz, int Cmax, hipStream_t st) {
     GyBatch gb = gb_in;                                  // (launch_gy_t fills in the grid map)
-    // LDS-DMA ring; at r <= 16 except for the widest batches (gate + up, 2 x 11008: 97.5 against 92.8 us for the first form in the step's
-    // kernel sequence; o / down 26.3 against 27.9, q + k + v 54 against 58); "gy_form" 1 / 2 forces the first / second form
+    // LDS-DMA ring; at r <= 16 except for the widest batches on long token sets (gate + up, 2 x 11008, 8192 tokens: 97.5 against 92.8 us for
+    // the first form in the step's kernel sequence; o / down 26.3 against 27.9, q + k + v 54 against 58; on 4096-token launches -- the part-batch
+    // chains of round 5 -- the ring wins there too: up_bwd 8.48 -> 8.18 ms per pass, step 30.3 -> 29.95 ms); "gy_form" 1 / 2 forces the first / second form
     if constexpr (RP <= 32) {
-        if (g_tune_gy_form == 2 || (g_tune_gy_form == 0 && (RP == 32 || !(nz > 1 && Cmax > 8192)))) return launch_gs_auto<RP, WITH_DB>(gb, nz, Cmax, st);
+        if (g_tune_gy_form == 2 || (g_tune_gy_form == 0 && (RP == 32 || !(nz > 1 && Cmax > 8192 && gb.z[0].T > 4096)))) return launch_gs_auto<RP, WITH_DB>(gb, nz, Cmax, st);
     }
     if constexpr (RP == 64 && !WITH_DB) {
         if (g_tune_gy_form != 1) {
