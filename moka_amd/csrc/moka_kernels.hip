@@ -138,7 +138,7 @@ static __device__ __forceinline__ void wave_sum_vec(float (&v)[N]) {
 
 // ---- dropout: counter-based keep mask, one base hash per 16-byte chunk (8 bf16 of one token row) ----
 // chunk idx = token * (C/8) + column/8;  base = fmix32(idx ^ seed_lo) + seed_hi;  dword w of the chunk
-// gets x_w = base * K_w, x_w ^= x_w >> 15, and its two elements keep iff the 15-bit fields
+// gets x_w = (base >> 8) *24 K_w (a full-rate 24-bit product), x_w ^= x_w >> 15, and its two elements keep iff the 15-bit fields
 // x_w[14:0] / x_w[30:16] are >= thr = round(p * 32768).  The compare runs packed (v_pk_sub_i16 +
 // v_pk_ashrrev_i16 -> 0xffff per kept element), ~35 VALU instructions per chunk -- the stream budget
 // is ~130 per 16-byte load.  The same function is evaluated by the down-projection (x), the dA kernel
@@ -154,11 +154,13 @@ static __device__ __forceinline__ unsigned fmix32(unsigned h) {
 }
 static __device__ __forceinline__ KeepMask drop_keep8(const DropArgs& d, unsigned idx) {
     const unsigned base = fmix32(idx ^ d.seed_lo) + d.seed_hi;
-    constexpr unsigned K[4] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu};
+    // (v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter: the four per-dword products take the top 24 bits of the base hash)
+    constexpr unsigned K[4] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu};
+    const unsigned b24 = base >> 8;
     KeepMask km;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        unsigned x = base * K[w];
+        unsigned x = __umul24(b24, K[w]);
         x ^= x >> 15;
         x &= 0x7fff7fffu;
         union { unsigned u; s16x2 v; } r, t, m;
