@@ -660,6 +660,7 @@ __global__ void __launch_bounds__(256) moka_shadows_batch_kernel(const ShadowBat
 // Rows that are themselves key rows are finished by part b (their dq, if any, joins their dK slot).
 template <int RP>
 __global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab) {
+    __builtin_amdgcn_s_setprio(3);             // (latency-bound, few waves: issue ahead of the streaming kernel of the other chain on this SIMD)
     constexpr int NTH = 256, NWV = 4, RB = 16, KP = RP + 1, NT = RP / 16, KS4 = RP / 4, R4 = RP / 4, KC = 64;
     constexpr int RI = RB * R4;                // float4 elements of the block's rows (64 / 128 / 256)
     constexpr int SG = NTH / RI;               // thread groups that share the slices of one element (4 / 2 / 1)
@@ -933,6 +934,7 @@ __global__ void __launch_bounds__(256) moka_cross_bwd_kernel(const CrossBatch ab
 // Deterministic (fixed summation order), no atomics, no scratch that has to be zero on entry.
 template <int RP>
 __global__ void __launch_bounds__(256) moka_cross_bwd_keys_kernel(const CrossBatch ab, int nblk) {
+    __builtin_amdgcn_s_setprio(3);
     const CrossArgs& a = ab.z[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* list = (int*)smem;                           // [nblk] indices of the blocks that wrote a partial
