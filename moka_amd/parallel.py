@@ -333,11 +333,27 @@ _LAYER_RE = re.compile(r"^(.*?(?:^|\.)layers)\.(\d+)\.")
 def _in_backward(dp=None) -> bool:
     """True while an autograd backward pass is running on this thread (activation checkpointing re-runs layer forwards there).
     ``torch._C._current_graph_task_id`` is a private hook: where it is missing, the handle's own flag decides (set by the first
-    backward callback of a pass, cleared by finish() / step())."""
+    backward callback of a pass, cleared by an engine callback when that pass ends: ``_mark_pass``)."""
     f = getattr(torch._C, "_current_graph_task_id", None)
     if f is not None:
         return f() != -1
-    return bool(dp is not None and dp._bwd_active)
+    return bool(dp is not None and dp._pass_running)
+
+
+def _mark_pass(dp) -> None:
+    """Called from inside a backward pass (a deferred-launch node, a layer hook): ``dp._pass_running`` is True until THIS pass ends -- the
+    engine runs the queued callback when the graph task completes.  (``dp._bwd_active`` stays set until finish() / step(): it says that a
+    pass has reported work, not that one is running.)"""
+    dp._bwd_active = True
+    if not dp._pass_running:
+        dp._pass_running = True
+
+        def _ended():
+            dp._pass_running = False
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_ended)
+        except RuntimeError:                         # (not inside a backward pass: a direct call from a test or a manual launch)
+            dp._pass_running = False
 
 
 def _decoder_prefix(names: Sequence[str]) -> Optional[str]:
@@ -386,6 +402,8 @@ class AdapterDataParallel:
         self._opt_begun = False
         self._opt_done: List = []                    # [lo, hi) ranges of the flat buffers already updated in this step
         self._bwd_active = False                     # a backward pass has reported work since the last finish() / step()
+        self._warned_no_clip = False
+        self._pass_running = False                   # ... and is still running (``_mark_pass``: cleared by an engine callback at its end)
 
     # ---------------------------------------------------------------- backward side
     def _opt_slice(self, lo: int, hi: int) -> None:
@@ -400,7 +418,7 @@ class AdapterDataParallel:
         """fn: the launch as a closure; da / db = (key, items): the same work described as problems of moka_down_bwd_da_batch (key =
         (routing, r, dropout_p), items = [(dh_kmj, x2, [dA_acc_m], seed)]) or moka_up_bwd_db_batch (key = (routing, r), items =
         [(gy2, hp_kmj, dB_acc)]), so that a decoder layer's weight-gradient launches leave as ONE per kind."""
-        self._bwd_active = True
+        _mark_pass(self)
         desc = ("da", da) if da is not None else (("db", db) if db is not None else None)
         self._deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)], desc))
     _defer.accepts_da = True
@@ -455,7 +473,7 @@ class AdapterDataParallel:
             self._side_busy = False
 
     def _layer_done(self, l: int) -> None:
-        self._bwd_active = True
+        _mark_pass(self)
         self._flush_deferred()                       # the layer's dA_m launches leave for the side stream now
         if not self.sync or l in self._done:
             return
@@ -524,11 +542,14 @@ class AdapterDataParallel:
                 pos = max(pos, hi)
             self._opt_done.clear()
             self._opt_begun = False
-            if max_grad_norm is not None and max_grad_norm > 0:
-                # (raised AFTER the step has been completed consistently: the buckets of this step were updated inside the backward,
-                #  before a global norm existed; MokaFlatOptimizer refuses the combination up front)
-                raise RuntimeError("attach(optimizer_in_backward=True) updates a bucket before the global gradient norm exists: no clipping in "
-                                   "this mode (the step just taken was NOT clipped)")
+            if max_grad_norm is not None and max_grad_norm > 0 and not self._warned_no_clip:
+                # (the buckets of this step were updated inside the backward, before a global norm existed: nothing to refuse any more at this
+                #  point, and a step that mutates the parameters and then throws leaves the caller with neither; MokaFlatOptimizer refuses
+                #  the combination up front, a direct caller is told once)
+                import warnings
+                warnings.warn("attach(optimizer_in_backward=True) updates a bucket before the global gradient norm exists: step(max_grad_norm=%g) "
+                              "does NOT clip in this mode" % max_grad_norm, RuntimeWarning, stacklevel=2)
+                self._warned_no_clip = True
             return None
         self.finish(average=False)
         scale = 1.0 / self.bucket.world

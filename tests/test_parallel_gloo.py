@@ -457,3 +457,32 @@ def test_geometric_bucket_layout():
     assert b.bucket_bounds(13) == (130, 320) and b.bucket_bounds(0) == (0, 10) and b.last_bucket_bytes() == 40
     with pytest.raises(ValueError):
         FlatGradBucket(320, ends, "cpu", bucket_sizes=[1, 3, 9])
+
+
+def test_pass_running_flag_is_cleared_when_the_backward_pass_ends():
+    """Builds without torch._C._current_graph_task_id: `_in_backward` falls back to the handle's `_pass_running`, which an engine
+    callback clears at the end of the pass that set it (`_bwd_active` stays until finish() / step())."""
+    import types
+    import torch
+    from moka_amd import parallel as P
+
+    dp = types.SimpleNamespace(_bwd_active=False, _pass_running=False)
+    seen = []
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            P._mark_pass(dp)
+            seen.append((dp._bwd_active, dp._pass_running))
+            return g * 2
+
+    x = torch.ones(3, requires_grad=True)
+    Node.apply(Node.apply(x)).sum().backward()
+    assert seen == [(True, True), (True, True)]
+    assert dp._bwd_active and not dp._pass_running            # the pass has ended; the work it reported is still to be finished
+    P._mark_pass(dp)                                          # outside a backward pass: nothing to wait for
+    assert not dp._pass_running
