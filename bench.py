@@ -1374,6 +1374,10 @@ def main():
             "chains": args.chains,
             "defer_dA": args.defer_da,
             "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority, "optimizer_in_backward": bool(opt_in_bwd),
+            # (what this line's schedule is and is not: ADVICE r04)
+            "schedule": "bench.py's launch schedule over the C ABI (part-batch chains / deferred dA_m on a hub stream / one hipGraph, persistent weight "
+                        "shadows rewritten behind the optimizer slices); moka_amd.parallel.attach + MokaLinearFn run ONE chain through autograd and "
+                        "relaunch the shadows every forward: --e2e measures that path",
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             # what the bus really carries: this implementation's own bytes (x / dx of a group once, x a second time for the deferred dA)

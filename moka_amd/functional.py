@@ -42,10 +42,25 @@ class _launch_on:
     def __enter__(self):
         self.prev = getattr(_LAUNCH, "stream", None)
         _LAUNCH.stream = self.stream
+        if DEBUG_LAUNCH_ON:
+            self._freed = _blocks_freed(self.stream.device)
 
     def __exit__(self, *exc):
         _LAUNCH.stream = self.prev
+        if DEBUG_LAUNCH_ON and exc[0] is None and _blocks_freed(self.stream.device) != self._freed:
+            # what makes the scheme safe is that NOTHING allocated for these launches dies before the current stream has joined `stream`:
+            # a block freed in here returns to the current stream's pool and may be handed out again while the side kernel still uses it
+            raise _lib.MokaError("moka_amd: a device allocation was freed inside a _launch_on(side) region (a temporary in a wrapper?): the "
+                                 "side-stream launches are not ordered against its reuse on the current stream")
         return False
+
+
+# debug hook (MOKA_DEBUG_LAUNCH_ON=1, or set by a test): every _launch_on region checks that the caching allocator freed no block inside it
+DEBUG_LAUNCH_ON = __import__("os").environ.get("MOKA_DEBUG_LAUNCH_ON") == "1"
+
+
+def _blocks_freed(device) -> int:
+    return int(torch.cuda.memory_stats(device).get("active.all.freed", 0))
 
 
 def _require_device(t: torch.Tensor, name: str):
@@ -440,6 +455,7 @@ def _token_scale(rt: MokaRouting, s_out: Sequence[float], device) -> torch.Tenso
 # backward call as `moka_opts`).  One workspace per (device, stream): calls that run concurrently on two streams never share one.
 _DET_ON = {}            # device -> True
 _DET_WS = {}            # (device, stream handle) -> uint8 workspace tensor
+_DET_RETIRED = []       # outgrown workspaces kept until set_deterministic(False)
 
 
 def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G: int = 3, M: int = 3, device=None) -> None:
@@ -455,6 +471,7 @@ def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G:
         _DET_ON.pop(dev, None)
         for k in [k for k in _DET_WS if k[0] == dev]:
             del _DET_WS[k]
+        _DET_RETIRED[:] = [w_ for w_ in _DET_RETIRED if w_.device != dev]
         return
     _DET_ON[dev] = True
     if T and C_max:
@@ -475,6 +492,8 @@ def _det_opts(device, T: int, C_max: int, r: int, G: int, M: int):
     key = (dev, _launch_stream(dev).cuda_stream)
     ws = _DET_WS.get(key)
     if ws is None or ws.numel() < n:
+        if ws is not None and getattr(_LAUNCH, "stream", None) is not None:
+            _DET_RETIRED.append(ws)                  # (outgrown inside a _launch_on region: not handed back to the current stream's pool in there)
         ws = torch.empty(n, dtype=torch.uint8, device=dev)
         _DET_WS[key] = ws
     return ctypes.byref(_lib.MokaOpts(ws.data_ptr(), ws.numel()))

@@ -240,6 +240,7 @@ def test_overlap_with_the_base_gemm_gives_the_same_bits():
     try:
         for ovl in (False, True):
             F.set_overlap_base(ovl)
+            F.DEBUG_LAUNCH_ON = ovl                          # every _launch_on(side) region: no device block freed inside it
             specs = [AdapterSpec(spec0.r, spec0.s_in, spec0.s_out, spec0.w, spec0.inv_sqrt_dk, 0.1, seed=100 + g) for g in range(3)]
             x = cds[0].x.to(dev, bf).requires_grad_(True)
             params = [(cd.W.to(dev, bf), None, cd.Bw.to(dev, bf).requires_grad_(True), [a.to(dev, bf).requires_grad_(True) for a in cd.A]) for cd in cds]
@@ -251,6 +252,7 @@ def test_overlap_with_the_base_gemm_gives_the_same_bits():
                         [p_[2].grad.clone() for p_ in params] + [a.grad.clone() for p_ in params for a in p_[3]])
     finally:
         F.set_overlap_base(False)
+        F.DEBUG_LAUNCH_ON = False
         F.set_deterministic(False, device=dev)
     for a_, b_ in zip(*outs):
         assert torch.equal(a_, b_)
