@@ -50,6 +50,7 @@ def test_captured_schedule_equals_live_launches(extra):
 def test_default_line_says_how_it_ran():
     out = _bench()
     assert out["graph"] == "all" and out["graph_topology"] == "hub" and out["chains"] == 2 and out["defer_dA"] in ("layer", "side", "unit")
+    assert "attach" in out["schedule"] and "--e2e" in out["schedule"]      # whose schedule the headline is (and which flag measures the autograd path)
 
 
 def test_capture_failure_falls_back_to_live_launches_of_every_chain():
