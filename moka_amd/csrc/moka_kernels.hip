@@ -4414,6 +4414,10 @@ static int launch_gs_auto(GyBatch& gb, int nz, int Cmax, hipStream_t st) {
     const long cus = (long)num_cu() / t_company;
     int ng = (4 * blocks(16) >= 5L * cus) ? 16 : (blocks(8) >= cus ? 8 : 4);
     while (ng > 2 && blocks(ng) < cus / 2) ng >>= 1;
+    // rank pad 32 beside another chain (company > 1): 16 groups for a single 4096-wide projection too -- half the dB atomics (a workgroup's 512 columns x 32 ranks leave
+    // once per run), 64 long workgroups while the other chain's launch has the rest of the chip: r = 32, two chains of 4096 tokens, 38.38 -> 37.92 ms per step (three
+    // alternating pairs; the pass alone gets slower, 13.55 -> 14.99 ms); rank pad 16: no difference (29.61 / 29.64 ms), left alone; 32 groups lose at both ranks
+    if (RP == 32 && t_company > 1 && ng < 16 && 2 * blocks(16) >= cus) ng = 16;
     if (g_tune_gy_ng > 0) ng = g_tune_gy_ng;
     launch_gs_t<RP, WITH_DB>(gb, nz, (Cmax + 511) / 512, ng, st);
     return check_launch("moka_gs_kernel");
