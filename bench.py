@@ -87,7 +87,8 @@ class Unit:
     def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False, company=1):
         from moka_amd import _lib
         G = len(members)
-        # moka_opts.company: how many independent chains run side by side (the pass over gy then sizes its token runs for its share of the CUs)
+        # moka_opts.company: how many independent chains run side by side (the pass over gy then sizes its token runs for its share of the CUs;
+        # the dx pass of a wide input takes fewer, longer workgroups)
         self.opts = _lib.MokaOpts(None, 0, int(company))
         ob = byref(self.opts) if company > 1 else None
         # per unit: the library's advice for this shape (moka_up_fwd_fused_pays: e.g. not for the 70B widths' single projections)
@@ -139,11 +140,11 @@ class Unit:
             "moka_up_bwd:dB": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, None, dB, T, r, do, M, G, 0, ob)),
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                      drop_p, sd, 0, None)),
+                                                      drop_p, sd, 0, ob)),
             # the two halves of moka_down_bwd as separate calls (either output may be NULL): dx stays on the dependency chain,
             # dA_m is needed by the optimizer only
             "moka_down_bwd:dx": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, None, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0, None)),
+                                                         drop_p, sd, 0, ob)),
             "moka_down_bwd:dA": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, None, T, self.d_in, r, M, G,
                                                          drop_p, sd, 0, None)),
         }

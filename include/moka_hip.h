@@ -113,7 +113,9 @@ typedef struct moka_opts {
     int    company;     /* 0 / 1: the caller's launches have the device to themselves.  N > 1: the caller runs N independent launch chains side by
                            side (part-batches on N streams / branches of one hipGraph): moka_up_bwd then sizes the token runs of its weight-gradient
                            half for 1 / N of the CUs -- longer runs, fewer dB atomics -- instead of covering the chip on its own (7B widths,
-                           r = 32, two chains of 4096 tokens: 40.5 -> 39.5 ms per step; r = 16: no difference).  Results are the same sums. */
+                           r = 32, two chains of 4096 tokens: 40.5 -> 39.5 ms per step; r = 16: no difference), and moka_down_bwd gives the dx pass
+                           of a wide input (d_in > 8192) three workgroups per CU instead of eight (r = 16, the 11008-wide input: 0.1-0.3 ms per
+                           step).  Results are the same sums. */
 } moka_opts;
 
 int         moka_version(void);

@@ -4069,7 +4069,10 @@ static void launch_expand_t(const ExpandBatch& ab, int nz, hipStream_t st) {
     for (int z = 0; z < (G == 1 ? nz : 1); ++z) Cmax = ab.z[z].C > Cmax ? ab.z[z].C : Cmax;
     const int nc = (Cmax + CW - 1) / CW;
     const int ntiles = (ab.z[0].T + 15) / 16;
-    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : ((Cmax > 8192 || (W_CK && nz > 1)) ? 8 : 2);
+    // (wide launches: 8 workgroups per CU when the launch has the chip to itself; beside another chain (moka_opts.company > 1) THREE -- fewer, longer workgroups while the
+    //  other chain's launch fills the rest: the dx pass of the 11008-wide input, two chains of 4096 tokens: 29.57 -> 29.36 / 29.47, 30.45 -> 30.25, 30.62 -> 30.31 ms per step on
+    //  two boxes, 13B widths 47.85 -> 47.40, 47.28 -> 46.98; one chain: 31.86 -> 31.96 (stays at 8); the narrow launches stay at 2: 3 loses 0.1-0.2 ms)
+    const int bpc = g_tune_expand_bpc > 0 ? g_tune_expand_bpc : ((Cmax > 8192 || (W_CK && nz > 1)) ? (t_company > 1 ? 3 : 8) : 2);
     // the x dimension of the grid enumerates the column blocks of all batched problems (xend): grouped-query k / v beside q are
     // 16 + 2 + 2 column blocks, not 3 x 16
     ExpandBatch sb = ab;

@@ -1234,6 +1234,46 @@ def test_avt_module_takes_overlapping_masks_like_the_reference_layer():
         assert rel(getattr(lin, f"lora_A{i}").weight.grad, t("ref_dA")[i]) <= 1e-5
 
 
+def test_company_hint_on_the_dx_pass_of_a_wide_input_same_bits():
+    """moka_opts.company > 1 gives the dx pass of a wide input (d_in > 8192) fewer, longer workgroups (moka_down_bwd): dx is a deterministic
+    read-modify-write, so the result must not change by a bit -- with and without dropout."""
+    import ctypes
+    from moka_amd import _lib
+    from moka_amd import functional as F
+    from moka_amd.routing import MokaRouting
+    dev = _dev()
+    lib = _lib.load()
+    B, S, d_in, r = 2, 1024, 11008, 16
+    gen = torch.Generator().manual_seed(77)
+    tok, q = C.build_layout(C.synthetic_sequence_layout(S), S)
+    masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev) for m in range(3)] + [q.to(torch.int32).reshape(1, S, 1).repeat(B, 1, 1).to(dev)]
+    rt = MokaRouting.from_avt_masks(masks)
+    T = B * S
+    bf = torch.bfloat16
+    x = torch.randn(T, d_in, generator=gen).to(dev, bf)
+    A = [(torch.randn(r, d_in, generator=gen) * 0.05).to(dev, bf) for _ in range(3)]
+    Bw = (torch.randn(256, r, generator=gen) * 0.05).to(dev, bf)
+    gy = torch.randn(T, 256, generator=gen).to(dev, bf)
+    part = F.down_fwd(x, A, rt, r, 1.0)
+    st = F.cross_fwd(part, rt, r, [1.0, 1.0, 1.0], 1.0, 1.0 / math.sqrt(r), Bw=Bw, A=A)
+    g_part = F.up_bwd(gy, None, st.BwT, rt, r, [1.0, 1.0, 1.0], None)
+    bst = F.cross_bwd(g_part, st.h, rt, r, 1.0, 1.0, 1.0 / math.sqrt(r))
+    dx0 = torch.randn(T, d_in, generator=gen).to(dev, bf)
+    for p_drop, seed in ((0.0, 0), (0.05, 1234)):
+        outs = []
+        for company in (1, 2, 4):
+            dx = dx0.clone()
+            opts = _lib.MokaOpts(None, 0, company)
+            rc = lib.moka_down_bwd(bst.dh_tok.data_ptr(), None, None, st.AT.data_ptr(), rt.tok_mod.data_ptr(), None, dx.data_ptr(),
+                                   T, d_in, r, rt.M, float(p_drop), int(seed), 0, ctypes.byref(opts), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.moka_last_error()
+            torch.cuda.synchronize()
+            outs.append(dx)
+        assert not torch.equal(outs[0], dx0)
+        for dx in outs[1:]:
+            assert torch.equal(dx, outs[0])
+
+
 @pytest.mark.parametrize("r", [16, 32])
 def test_company_hint_changes_the_launch_shape_not_the_sums(r):
     """moka_opts.company = N (the caller runs N launch chains side by side): moka_up_bwd sizes the token runs of its weight-gradient half
