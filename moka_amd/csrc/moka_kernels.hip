@@ -4514,8 +4514,10 @@ static int launch_xs(const XaArgs& a, hipStream_t st) {
     const int ncb = (a.C + 512 * HC - 1) / (512 * HC), ntile = a.T >> 4;
     // tiles per workgroup: long runs amortise the resident weights (G x 6 KB per wave), short ones give more workgroups
     int tpb = (G == 3) ? 16 : 8;
-    // (three projections: one workgroup of 16 tiles per CU beat two of 8 -- 34.4 vs 40.0 us -- their 18 KB of weights per wave are the start-up)
-    while (tpb > 2 && (long)ncb * ((ntile + tpb - 1) / tpb) < (G == 3 ? 1L : 2L) * num_cu()) tpb >>= 1;
+    // (three projections: one workgroup of 16 tiles per CU beat two of 8 -- 34.4 vs 40.0 us -- their 18 KB of weights per wave are the start-up;
+    //  one or two projections on 4096-token launches likewise: ONE workgroup of 8 tiles per CU instead of two of 4 -- moka_down_fwd 5.84 -> 5.67 ms per pass at the
+    //  7B widths, step 29.43 -> 29.12, 29.29 -> 29.24 ms; 8192-token launches keep their 512 workgroups of 8 tiles either way)
+    while (tpb > 2 && (long)ncb * ((ntile + tpb - 1) / tpb) < (long)num_cu()) tpb >>= 1;
     const size_t lds = (size_t)NS * 16 * 1040 + (size_t)2 * 8 * G * 256 * 4 + (size_t)tpb * 16;
     ensure_lds((const void*)moka_xs_kernel<G, NS, HC>, lds);
     hipLaunchKernelGGL((moka_xs_kernel<G, NS, HC>), dim3(ncb, (ntile + tpb - 1) / tpb), dim3(512), lds, st, a, tpb);
