@@ -80,83 +80,10 @@ def synthetic_layout(S):
     return tok, q
 
 
-class Unit:
-    """The projections of one decoder layer that are fed by the same input (q/k/v; o; gate/up; down) with the
-    ctypes argument lists of the six (grouped) entry points pre-built.  G = 1 is the per-projection path."""
+from moka_amd import schedule as SCH  # noqa: E402  (the launch schedule lives in the package: bench.py builds synthetic buffers, constructs
+#                                                      a GraphedAdapterStep over them and times its step())
 
-    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False, company=1):
-        from moka_amd import _lib
-        G = len(members)
-        # moka_opts.company: how many independent chains run side by side (the pass over gy then sizes its token runs for its share of the CUs;
-        # the dx pass of a wide input takes fewer, longer workgroups)
-        self.opts = _lib.MokaOpts(None, 0, int(company))
-        ob = byref(self.opts) if company > 1 else None
-        # per unit: the library's advice for this shape (moka_up_fwd_fused_pays: e.g. not for the 70B widths' single projections)
-        self.fused = bool(fused and _lib.up_fwd_fused_pays(T, _lib.ksplit(T, members[0]["d_in"], r, G), [m["d_out"] for m in members], r))
-        self.label, self.G, self.T = label, G, T
-        self.d_in = members[0]["d_in"]
-        self.d_outs = [m["d_out"] for m in members]
-        ks_in = _lib.ksplit(T, self.d_in, r, G)
-        ks_out = _lib.ksplit_bwd(T, max(self.d_outs), r)
-        P = lambda ts: (c_void_p * len(ts))(*[t.data_ptr() for t in ts])          # noqa: E731
-        I = lambda vs: (ctypes.c_int * len(vs))(*vs)                              # noqa: E731
-        A = P([a for m in members for a in m["A"]])
-        dA = P([a for m in members for a in m["dA"]])
-        Bw, dB = P([m["Bw"] for m in members]), P([m["dB"] for m in members])
-        y = P([m["y"] for m in members])
-        h, hp_kmj = P([m["h"] for m in members]), P([m["hp_kmj"] for m in members])
-        BwT, AT = P([m["BwT"] for m in members]), P([m["AT"] for m in members])
-        part = P([scratch[g]["part"] for g in range(G)])
-        hp_tok = P([scratch[g]["hp_tok"] for g in range(G)])
-        dh_tok = P([scratch[g]["dh_tok"] for g in range(G)])
-        # (--defer-da: the dA launches run a layer later, beside the next layer's chain: their operand packs cannot sit in the shared scratch)
-        dh_kmj = P([(own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]) for g in range(G)])
-        ws = P([rt.cross_ws(r, g) for g in range(G)])
-        so = (c_float * M)(*s_out)
-        sd = (ctypes.c_ulonglong * G)(*seeds)
-        do = I(self.d_outs)
-        tm = rt.tok_mod.data_ptr()
-        self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sd, do, x, dx)
-        # (--defer-da layer: the dA_m halves of a whole decoder layer as one moka_down_bwd_da_batch launch)
-        self.da_items = [((own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]), x, self.d_in, members[g]["dA"], seeds[g]) for g in range(G)]
-        self.sh_items = [(m["Bw"], m["d_out"], m["A"], self.d_in, m["BwT"], m["AT"]) for m in members]
-        self.db_items = [(members[g]["y"], members[g]["hp_kmj"], members[g]["d_out"], members[g]["dB"]) for g in range(G)]
-        self.calls = {
-            "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sd, 0)),
-            "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
-                                                        BwT, AT, G, r, w, c)),
-            "moka_up_fwd": ("moka_up_fwd_group", (hp_tok, Bw, tm, y, T, r, do, G, 0)),
-            # --fuse-fwd (default): the up-projection computes the interaction itself from the slices (moka_up_fwd_fused); the rank-space
-            # launch only writes what the BACKWARD reads (h, hp_kmj, BwT, AT: hp_tok = NULL) and leaves the dependency chain
-            "moka_up_fwd:fused": ("moka_up_fwd_fused_group", (part, ks_in, byref(rt.struct), so, Bw, y, do, h, hp_kmj, G, r, w, c, 0)),
-            "moka_cross_fwd:state": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, None, hp_kmj,
-                                                              BwT, AT, G, r, w, c)),
-            # the weight shadows the backward reads (BwT, AT): functions of the weights alone -> once per step, off the chain
-            "moka_weight_shadows": ("moka_weight_shadows_group", (Bw, do, A, self.d_in, BwT, AT, G, r, M)),
-            "moka_up_bwd": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, dB, T, r, do, M, G, 0, ob)),
-            # the two outputs of moka_up_bwd as separate calls (--defer-db: where dB is a pass of its own anyway, moka_up_bwd_passes() == 2,
-            # it leaves the dependency chain like dA_m)
-            "moka_up_bwd:g": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, part, None, T, r, do, M, G, 0, ob)),
-            "moka_up_bwd:dB": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, None, dB, T, r, do, M, G, 0, ob)),
-            "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
-            "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                      drop_p, sd, 0, ob)),
-            # the two halves of moka_down_bwd as separate calls (either output may be NULL): dx stays on the dependency chain,
-            # dA_m is needed by the optimizer only
-            "moka_down_bwd:dx": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, None, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0, ob)),
-            "moka_down_bwd:dA": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, None, T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0, None)),
-        }
-        # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
-        # per-projection definition: a group that reads x once is still credited G reads -- the roofline
-        # fraction is defined on the reference's per-projection traffic):
-        #   down_fwd: read x  E*T*d_in      up_fwd: read+write y  2*E*T*d_out
-        #   up_bwd  : read gy E*T*d_out     down_bwd: read x, r+w dx  3*E*T*d_in
-        sdo = sum(self.d_outs)
-        self.algo = {"moka_down_fwd": E * T * self.d_in * G, "moka_up_fwd": 2 * E * T * sdo, "moka_up_bwd": E * T * sdo,
-                     "moka_down_bwd": 3 * E * T * self.d_in * G, "moka_cross_fwd": 3 * 4 * T * r * G, "moka_cross_bwd": 3 * 4 * T * r * G,
-                     "moka_weight_shadows": 2 * E * r * (sdo + M * self.d_in * G)}
+Unit = SCH.AdapterUnit
 
 
 def build_workload(args, dev, lib, bucket_factory, chains=1):
@@ -274,247 +201,16 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
                                   own_dh_kmj=own[l % n_own][len(units) % len(unit_defs)] if defer else None, fused=fused,
                                   company=chains if getattr(args, "company_hint", "on") == "on" else 1))
-        layer_da, layer_db = [], []
-        if defer:
-            per = len(unit_defs)
-            for l in range(L):
-                items = [it for u in reversed(units[l * per:(l + 1) * per]) for it in u.da_items]
-                n = len(items)
-                argl = ((c_void_p * n)(*[it[0].data_ptr() for it in items]), (c_void_p * n)(*[it[1].data_ptr() for it in items]),
-                        (ctypes.c_int * n)(*[it[2] for it in items]), rt.tok_mod.data_ptr(),
-                        (c_void_p * (n * M))(*[a.data_ptr() for it in items for a in it[3]]), n, Tc, r, M, args.dropout,
-                        (ctypes.c_ulonglong * n)(*[it[4] for it in items]), 0, None)
-                layer_da.append(argl)
-                dbi = [it for u in reversed(units[l * per:(l + 1) * per]) for it in u.db_items]
-                layer_db.append(((c_void_p * n)(*[it[0].data_ptr() for it in dbi]), (c_void_p * n)(*[it[1].data_ptr() for it in dbi]),
-                                 (ctypes.c_int * n)(*[it[2] for it in dbi]), rt.tok_mod.data_ptr(), (c_void_p * n)(*[it[3].data_ptr() for it in dbi]),
-                                 n, Tc, r, M, 0, None))
-        chain_list.append(dict(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db, rank=r, reuse_wait=(n_own < L)))
+        layer_da, layer_db = SCH.make_layer_batches(units, len(unit_defs), L, rt, Tc, r, M, args.dropout) if defer else ([], [])
+        chain_list.append(SCH.AdapterChain(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db, rank=r, reuse_wait=(n_own < L)))
         keep.append((sets, masks, scratch2, own))
-    return dict(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], rank=r, chains=chain_list, master=master, work=work, reuse_wait=chain_list[0]["reuse_wait"],
-                gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
+    return SCH.AdapterWorkload(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], rank=r, chains=chain_list, master=master, work=work, reuse_wait=chain_list[0]["reuse_wait"],
+                             gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
 
 
-ENTRY = ["moka_down_fwd", "moka_cross_fwd", "moka_up_fwd", "moka_up_bwd", "moka_cross_bwd", "moka_down_bwd", "moka_weight_shadows"]
-
-
+ENTRY = SCH.ENTRY
 LIVE = ("moka_up_fwd",)     # the dominant single-kernel entry point, bracketed inside the timed region
-
-
-class Recorder:
-    """HIP-event brackets around launches on the launch stream.  `only` limits which entry points are
-    bracketed (bracketing every launch of a step makes the host the bottleneck and distorts the headline)."""
-
-    def __init__(self, only=None, every=1):
-        self.only, self.items, self.pool, self.every, self.seen = only, [], [], max(1, int(every)), 0
-
-    def skip(self):
-        """Bracket every `every`-th eligible launch (an event record is a packet of its own on the stream: ~2 us each)."""
-        self.seen += 1
-        return (self.seen % self.every) != 0
-
-    def event(self):
-        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
-
-    def reserve(self, n):
-        self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(n))
-
-
-def _call(lib, name, u, sp, rec, stream=None):
-    """Launch one entry point of unit `u`; bracket it with HIP events (on `stream`, default: torch's current stream, which is the
-    launch stream of the bracketed passes) when the recorder asks for it.  "entry:variant" is recorded as "entry"."""
-    sym, args = u.calls[name]
-    base = name.split(":")[0]
-    if rec is None or (rec.only is not None and base not in rec.only) or rec.skip():
-        rc = getattr(lib, sym)(*args, sp)
-    else:
-        e0, e1 = rec.event(), rec.event()
-        e0.record(stream) if stream is not None else e0.record()
-        rc = getattr(lib, sym)(*args, sp)
-        e1.record(stream) if stream is not None else e1.record()
-        rec.items.append((base, u, e0, e1))
-    if rc:
-        raise RuntimeError(lib.moka_last_error().decode())
-
-
-def run_forward(lib, wl, sp, rec=None, shadows=False):
-    """Per unit: down-projection, interaction, up-projection.  Fused units (--fuse-fwd): down-projection -> up-projection with the
-    interaction inside (it also writes h and the rank-major hp pack for the backward).  The weight shadows the backward reads (BwT, AT)
-    are functions of the weights alone: they are rewritten where the weights change (run_shadows behind the optimizer step), not in
-    the forward -- unless `shadows` asks for them in front of every unit (--shadows main)."""
-    for u in wl["units"]:
-        if not u.fused:
-            _call(lib, "moka_down_fwd", u, sp, rec)
-            _call(lib, "moka_cross_fwd", u, sp, rec)       # (writes its own weight shadows: taking them out gained nothing at rank 64, 82.3 vs 84.1 ms)
-            _call(lib, "moka_up_fwd", u, sp, rec)
-            continue
-        if shadows:
-            if u.fused:                      # (the other units' moka_cross_fwd writes their shadows in the forward)
-                _call(lib, "moka_weight_shadows", u, sp, rec)
-        _call(lib, "moka_down_fwd", u, sp, rec)
-        _call(lib, "moka_up_fwd:fused", u, sp, rec)
-
-
-SHADOWS_BATCH = True          # --shadows-batch off: one moka_weight_shadows_group launch per unit (A/B)
-
-
-def run_shadows(lib, wl, sp, layers, rec=None):
-    """BwT / AT of the given layers' FUSED units (the other units' moka_cross_fwd writes theirs in the forward; all chains share the
-    parameters: the first chain's units carry the buffers): one moka_weight_shadows_batch launch per 16 projections (a recorder gets
-    the per-unit launches, so that the entry point keeps its line in the table)."""
-    units, per = wl["units"], wl["units_per_layer"]
-    if rec is not None or not SHADOWS_BATCH:
-        for l in layers:
-            for u in units[l * per:(l + 1) * per]:
-                if u.fused:
-                    _call(lib, "moka_weight_shadows", u, sp, rec)
-        return
-    from moka_amd import _lib as _L
-    key = ("shadows", tuple(layers))
-    if key not in wl:
-        items = [it for l in layers for u in units[l * per:(l + 1) * per] if u.fused for it in u.sh_items]
-        calls = []
-        for i in range(0, len(items), _L.MOKA_MAX_SHADOW_BATCH):
-            part = items[i:i + _L.MOKA_MAX_SHADOW_BATCH]
-            n, M = len(part), len(part[0][2])
-            calls.append(((c_void_p * n)(*[it[0].data_ptr() for it in part]), (ctypes.c_int * n)(*[it[1] for it in part]),
-                          (c_void_p * (n * M))(*[a.data_ptr() for it in part for a in it[2]]), (ctypes.c_int * n)(*[it[3] for it in part]),
-                          (c_void_p * n)(*[it[4].data_ptr() for it in part]), (c_void_p * n)(*[it[5].data_ptr() for it in part]), n, wl["rank"], M))
-        wl[key] = calls
-    for argl in wl[key]:
-        _L.check(lib.moka_weight_shadows_batch(*argl, sp), "moka_weight_shadows_batch")
-
-
-def run_backward(lib, wl, sp, n_layers, on_layer_done=None, rec=None, lo=0, defer=None, bucket_opt=None, shadows_after_opt=False, state=None, join=True,
-                 flush=False):
-    """Reverse layer order (layers n_layers-1 .. lo); `on_layer_done(l)` fires after layer l's launches are enqueued.
-    defer = (mode, main_stream, side_stream): the dA_m halves of a layer's moka_down_bwd calls leave the dependency chain (only the
-    optimizer needs them) and are enqueued after the layer's chain -- "main": on the same stream; "side": on a second stream,
-    beside the NEXT layer's chain (whose rank-space kernels leave most of the chip idle), joined before the gradients are used.
-    state / join: the walk in pieces (--chains captures the chains layer by layer, interleaved): `state` carries the buffer-reuse events
-    from call to call, join=False leaves the side stream unjoined."""
-    units, per = wl["units"], wl["units_per_layer"]
-    if defer is None:
-        for l in range(n_layers - 1, lo - 1, -1):
-            for u in reversed(units[l * per:(l + 1) * per]):
-                _call(lib, "moka_up_bwd", u, sp, rec)
-                _call(lib, "moka_cross_bwd", u, sp, rec)
-                _call(lib, "moka_down_bwd", u, sp, rec)
-            if on_layer_done is not None:
-                on_layer_done(l)
-        return
-    mode, main, side = defer[:3]
-    split_db = len(defer) > 3 and defer[3]                       # dB off the chain too (where it is a pass of its own)
-    up = "moka_up_bwd:g" if split_db else "moka_up_bwd"
-    sps = c_void_p(side.cuda_stream)
-    done = state if state is not None else {}                    # layer -> event "its deferred dA launches have finished" (side mode)
-    flush_at = None
-    per_unit = False
-    if mode == "layer":
-        mode, batched = "side", True                             # the side schedule with ONE dA launch per layer
-    elif mode == "unit":
-        # a unit's dA_m leaves for the side stream as soon as its rank-space backward (which writes the packs it reads) has been enqueued,
-        # captured behind the unit's dx launch (chain-first).  Hub-shaped graphs only: there a fork per unit does not cut the chain
-        mode, batched, per_unit = "side", False, True
-    elif mode == "bucket":
-        # one fork per gradient BUCKET of layers (every cross-stream edge of a hipGraph costs its replay host time): the batched dA launches
-        # of the bucket's layers go out together when its first layer's chain has been enqueued; every layer owns its pack buffers
-        mode, batched, flush_at = "side", True, defer[4]
-    else:
-        batched = False
-    held = []                                                    # layers whose deferred launches wait for the bucket's flush
-    # CHAIN_FIRST (captures only): a layer's side-stream launches are enqueued AFTER the first launch of the next layer's chain.  The DAG is
-    # the same; what changes is the order of a fork node's out-edges, and the hipGraph executor (ROCm 7.2) derives its execution streams
-    # from a depth-first walk that follows the FIRST out-edge: side-first lets the walk leave the chain at every fork
-    reuse = wl.get("reuse_wait", True) and flush_at is None      # (pack buffers of layer l + 2 reused by layer l: the chain waits for that dA)
-    late = CHAIN_FIRST and on_layer_done is None and mode == "side"
-    post = done.pop("post", None) if late else None              # (layer, held layers, event on main) of the fork not yet emitted
-
-    def emit(l, held_, ev_main, pending_u):
-        side.wait_event(ev_main)
-        for u in reversed(units[l * per:(l + 1) * per]):
-            if split_db and not batched and not per_unit:
-                _call(lib, "moka_up_bwd:dB", u, sps, None)
-            if batched or per_unit or (mode == "window" and u is not pending_u):
-                continue                                        # (already out, beside the next unit's rank-space backward)
-            _call(lib, "moka_down_bwd:dA", u, sps, None)
-        if batched:
-            from moka_amd import _lib as _L
-            for ll in held_ + [l]:
-                if split_db:
-                    _L.check(lib.moka_up_bwd_db_batch(*wl["layer_db"][ll], sps), "moka_up_bwd_db_batch")
-                _L.check(lib.moka_down_bwd_da_batch(*wl["layer_da"][ll], sps), "moka_down_bwd_da_batch")
-        if bucket_opt is not None and mode in ("side", "window"):
-            # single GPU: the optimizer step of a gradient bucket as soon as its last dA_m / dB launches are on the side stream -- the
-            # update of the finished layers overlaps the backward of the earlier ones (FlatAdamW.step_range, coefficients in device memory)
-            opt_, bucket_, scale_ = bucket_opt
-            if bucket_.is_bucket_first(l):
-                blo, bhi = bucket_.bucket_bounds(l)
-                with torch.cuda.stream(side):
-                    opt_.step_range(blo, bhi, grad_scale=scale_, zero_grad=True)
-                    if shadows_after_opt:
-                        # the bucket's weights have just changed: their shadows for the NEXT step's backward, still off the chain
-                        run_shadows(lib, wl, sps, bucket_.bucket_layers(l))
-        ev = torch.cuda.Event()
-        ev.record(side)
-        done[l] = ev
-
-    for l in range(n_layers - 1, lo - 1, -1):
-        if not late and reuse and mode in ("side", "window") and (l + 2) in done:
-            main.wait_event(done.pop(l + 2))                     # layer l reuses the pack buffers of layer l + 2
-        pending = None
-        for u in reversed(units[l * per:(l + 1) * per]):
-            _call(lib, up, u, sp, rec)
-            if post is not None:
-                emit(*post)                                      # the layer before's fork, behind this layer's first launch (CHAIN_FIRST)
-                post = None
-            if late and pending is None and reuse and (l + 2) in done:
-                main.wait_event(done.pop(l + 2))                 # (the first writer of the reused pack buffers is this unit's rank-space backward)
-            if mode == "window" and pending is not None:
-                # the dA of the unit before goes out HERE, so that it starts with this unit's rank-space backward -- the two launches of
-                # the chain that leave the memory system idle (a unit's dA moves about as many bytes as that window could)
-                side.wait_stream(main)
-                _call(lib, "moka_down_bwd:dA", pending, sps, None)
-            _call(lib, "moka_cross_bwd", u, sp, rec)
-            if per_unit:
-                ev_u = torch.cuda.Event()
-                ev_u.record(main)
-            _call(lib, "moka_down_bwd:dx", u, sp, None)
-            if per_unit:
-                side.wait_event(ev_u)
-                if split_db:
-                    _call(lib, "moka_up_bwd:dB", u, sps, None)
-                _call(lib, "moka_down_bwd:dA", u, sps, None)
-            pending = u
-        if mode == "main":
-            for u in reversed(units[l * per:(l + 1) * per]):
-                if split_db:
-                    _call(lib, "moka_up_bwd:dB", u, sp, None)
-                _call(lib, "moka_down_bwd:dA", u, sp, None)
-        elif flush_at is not None and not flush_at(l) and l > lo:
-            held.append(l)                                       # (leaves with its bucket's first layer)
-        else:
-            ev_main = torch.cuda.Event()
-            ev_main.record(main)
-            if late:
-                post = (l, held, ev_main, pending)
-            else:
-                emit(l, held, ev_main, pending)
-            held = []
-        if on_layer_done is not None:
-            if mode in ("side", "window") and l in done:
-                main.wait_event(done[l])                         # (a bucket must not ship before its dA has landed)
-            on_layer_done(l)
-    if post is not None:
-        if join or flush or lo == 0:
-            emit(*post)                                          # nothing follows on the chain
-        else:
-            done["post"] = post                                  # (the next piece of the walk emits it)
-    if mode in ("side", "window") and join:
-        main.wait_stream(side)
-
-
-CHAIN_FIRST = True            # --capture-order side-first: A/B
+Recorder, run_forward, run_backward, run_shadows = SCH.Recorder, SCH.run_forward, SCH.run_backward, SCH.run_shadows      # (tools/ written against bench.*)
 
 
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
@@ -824,6 +520,9 @@ def main():
                          "same activation state; y / dx must agree bit for bit, the flat gradient to its atomics' spread -> `graph_check`")
     ap.add_argument("--probe-forward", action="store_true",
                     help="also time the forward alone as a hipGraph of its own against the same launches live (HIP events, no profiler) -> `forward_only`")
+    ap.add_argument("--ablate", default="dominant",
+                    help="in-schedule marginals: dominant (default) = the dominant kernel family only -> roofline.in_schedule; all / a comma list of "
+                         "moka_amd.schedule.FAMILIES -> also the `ablation` table; off")
     ap.add_argument("--no-group", action="store_true",
                     help="launch every projection on its own (the grouped entry points let q/k/v and gate/up share x / dx)")
     args = ap.parse_args()
@@ -901,9 +600,6 @@ def main():
     if args.chains > 1 and args.defer_da == "window":
         raise SystemExit("--chains > 1 runs with --defer-da off / main / side / layer / bucket")
     # dB leaves the dependency chain with dA_m where the library computes it in a pass of its own anyway (r > 32)
-    global SHADOWS_BATCH, CHAIN_FIRST
-    SHADOWS_BATCH = args.shadows_batch == "on"
-    CHAIN_FIRST = args.capture_order == "chain-first"
     args.split_db = args.defer_da != "off" and (args.defer_db == "on" or (args.defer_db == "auto" and lib.moka_up_bwd_passes(args.rank, 0) == 2))
     # collectives on: geometric buckets -- 1, 3, 9, 19 layers from layer 0 up.  The backward walks the layers last -> first: the big buckets
     # ship early with plenty of backward left to hide their all-reduce, the bucket nothing is left to hide is ONE layer, and there are four
@@ -929,233 +625,27 @@ def main():
         from moka_amd.parallel import FlatAdamW
         opt = FlatAdamW(wl["master"], bucket.flat, wl["work"], lr=1e-4)
     L = args.layers
-    # the optimizer step per gradient bucket INSIDE the backward (off: one launch behind it): needs the side stream of the deferred dA_m
-    # (single GPU) or the communication stream behind the bucket's all-reduce (N > 1, fp32 payload)
-    # (--chains N: every chain defers its dA_m to a side stream of its own; the slice of a bucket goes out on one more stream once the
-    #  bucket's layers have landed in EVERY chain)
-    opt_in_bwd = (opt is not None and args.opt_in_backward == "on" and
-                  ((not comm and (args.defer_da in ("side", "window", "layer", "bucket", "unit") or args.chains > 1) and args.graph in ("auto", "all", "off"))
-                   or comm))
-    # fused forward: the weight shadows are rewritten where the weights change ("opt": behind the optimizer -- the bucket's slice on the
-    # side / communication stream with --opt-in-backward, the one launch behind the backward otherwise) or in front of every unit ("main")
-    shadows_main = bool(args.fused and args.shadows == "main")
-    shadows_opt = bool(args.fused and args.shadows == "opt")
-    shadows_in_cb = False
-    if opt_in_bwd:
-        opt.set_device_step(0)                       # (allocates the device-side coefficient state; no step counted)
-        if comm:
-            ends = wl["layer_end"]
 
-            def _reduced(blo, bhi):
-                opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
-                if shadows_opt:                      # (on the communication stream, behind the bucket's update)
-                    run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), [l for l in range(L) if blo < ends[l] <= bhi])
-            bucket.on_reduced = _reduced
-            shadows_in_cb = shadows_opt
-    if shadows_opt:
-        run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), range(L))     # the initial weights' shadows
-        torch.cuda.synchronize()
+    # The schedule is the package's (moka_amd/schedule.py): part-batch chains as branches of one hub-shaped hipGraph, dA_m / dB / optimizer
+    # slices / weight shadows on the hub, per-bucket graphs where collectives run between them.  bench.py builds the synthetic buffers,
+    # constructs the executor and times its step().
+    def make_cfg(skip=()):
+        return SCH.ScheduleConfig(chains=args.chains, graph=args.graph, topology=args.graph_topology, defer_da=args.defer_da, split_db=bool(args.split_db),
+                                chain_priority=args.chain_priority, fused=bool(args.fused), shadows=args.shadows, shadows_batch=args.shadows_batch == "on",
+                                chain_first=args.capture_order == "chain-first", chain_stagger=args.chain_stagger,
+                                opt_in_backward=args.opt_in_backward == "on", skip=frozenset(skip))
+    sched = SCH.GraphedAdapterStep(wl, make_cfg(), L, optimizer=opt, world=world, comm=comm, device=dev)
+    opt_in_bwd, shadows_main, shadows_opt = sched.opt_in_bwd, sched.shadows_main, sched.shadows_opt
 
     records = Recorder(only=LIVE, every=args.bracket_every)
     records.reserve(2 * len(wl["units"]) * args.steps + 16)
 
-    # hipGraphs (the library only enqueues on the stream it is given -- no allocation, no synchronisation -- so its launches
-    # capture unchanged).  "bwd": the forward as one graph and the backward launches of every gradient bucket (4 layers: 80 kernels)
-    # as one graph each; the bucket hooks (RCCL all-reduce of a finished bucket) run between the graphs exactly as between live
-    # layers.  "all": the whole micro-batch as one graph (single GPU).  Nothing can be bracketed inside a graph: `roofline` then
-    # comes from the extra live passes behind the timed region.
-    fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
-    if args.graph != "off":
-        try:
-            # the chain's (capture) stream at high priority, the deferred dA / dB stream at normal: when both have workgroups waiting, the
-            # dependency chain goes first (7B r = 16, same box twice: 33.43-33.48 -> 33.16-33.18 ms; r = 64: no difference)
-            side = torch.cuda.Stream(device=dev, priority=-1 if args.chain_priority == "high" else 0)
-            with torch.cuda.stream(side):
-                spw = c_void_p(side.cuda_stream)
-                for ch in wl["chains"]:
-                    run_forward(lib, ch, spw)
-                    run_backward(lib, ch, spw, L)   # warm-up on the capture stream (LDS attributes, lazy module load)
-            torch.cuda.synchronize()
-            pri = -1 if args.chain_priority == "high" else 0
-            anchor = torch.zeros(64, device=dev)
-            stagger_buf = torch.empty(max(1, args.chain_stagger * (1 << 20) * max(1, args.chains - 1)), dtype=torch.uint8, device=dev)
-
-            def capture_hub(graph, forward, pieces, with_opt):
-                """One graph in the hub shape: the N part-batch chains on N forked streams, everything off the chains (every chain's deferred
-                dA_m / dB launches, the optimizer slices, the weight shadows) on the capture's origin stream.
-                * hipStreamEndCapture (ROCm 7.2) segfaults on ANY dependency between two streams that are both forks
-                  (tools/probes/capture_topology.py): every edge has to touch the origin, so the origin is the hub;
-                * the executor does not run a graph on the capture's streams: it cuts the DAG into lists by a depth-first walk from the roots
-                  that follows every node's FIRST out-edge, gives every list a stream of its own and maps those onto a handful of in-order
-                  hardware queues (a list that waits for another list blocks whatever shares its queue).  Round 4's side-first forks made
-                  every layer's dA_m a list of its own and cut the chain at every fork.  This graph is SHAPED for that walk: the hub's
-                  launches are the root's first path (an anchor node captured in front of the forks' first launches), nothing on a chain ever
-                  waits for the hub (every layer owns its pack buffers: no reuse edges), so the walk yields exactly 1 + N lists;
-                * the walk of the backward is captured piece by piece (a layer; --defer-da bucket: a gradient bucket), chain by chain, so that
-                  the hub's stream order is "piece p of every chain, then the bucket's optimizer slice"."""
-                hub = torch.cuda.Stream(device=dev)
-                branch = [torch.cuda.Stream(device=dev, priority=pri) for _ in wl["chains"]]
-                with torch.cuda.graph(graph, stream=hub):
-                    cur = torch.cuda.current_stream()
-                    if with_opt:
-                        # the step's AdamW coefficients, written on the device by a one-thread launch that counts the steps itself:
-                        # every replay advances by one, nothing is read from host memory (FlatAdamW.begin_step)
-                        opt.begin_step(device_counter=True)
-                        opt.t -= 1                       # (the capture is not a step)
-                    else:
-                        anchor.zero_()                   # (the root)
-                    for st in branch:
-                        st.wait_stream(cur)              # fork
-                    anchor.zero_()                       # the root's FIRST successor is on the hub: the walk runs down the hub before it sees a chain
-                    if forward:
-                        for ci_, (ch, st) in enumerate(zip(wl["chains"], branch)):
-                            if ci_ and args.chain_stagger > 0:
-                                # (identical chains that start together march in lockstep -- both in a latency-bound launch at the same
-                                #  time; a fill of `--chain-stagger` MB in front of the later chains shifts their phase)
-                                with torch.cuda.stream(st):
-                                    stagger_buf[:ci_ * args.chain_stagger * (1 << 20)].zero_()
-                            run_forward(lib, ch, c_void_p(st.cuda_stream), shadows=shadows_main)
-                    states = [dict() for _ in branch]
-                    pend_opt = None
-
-                    def hub_opt(lb, evs):
-                        # the chains add into the same gradient accumulators: the bucket's AdamW slice (and its layers' weight shadows for
-                        # the next step) goes out on the hub, behind the dA_m launches of the bucket's first layer of EVERY chain
-                        for ev in evs:
-                            cur.wait_event(ev)           # (the in-chain gradients of the layer: dB rides with the pass over gy)
-                        blo, bhi = bucket.bucket_bounds(lb)
-                        opt.step_range(blo, bhi, grad_scale=1.0 / world, zero_grad=True)
-                        if shadows_opt:
-                            run_shadows(lib, wl, c_void_p(cur.cuda_stream), bucket.bucket_layers(lb))
-                    for pi_, (l, l_hi) in enumerate(pieces):
-                        for ch, st, stt in zip(wl["chains"], branch, states):
-                            run_backward(lib, ch, c_void_p(st.cuda_stream), l_hi, lo=l, state=stt, join=False, flush=pi_ == len(pieces) - 1,
-                                         defer=(args.defer_da, st, cur, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None)
-                        if pend_opt is not None:
-                            hub_opt(*pend_opt)           # (chain-first: behind the first launches of the chains' next piece)
-                            pend_opt = None
-                        if with_opt and bucket.is_bucket_first(l):
-                            evs = []
-                            for st in branch:
-                                ev = torch.cuda.Event()
-                                ev.record(st)
-                                evs.append(ev)
-                            if CHAIN_FIRST and pi_ < len(pieces) - 1:
-                                pend_opt = (l, evs)
-                            else:
-                                hub_opt(l, evs)
-                    for st in branch:
-                        cur.wait_stream(st)              # join
-                return hub, branch                       # (kept alive with the graph)
-
-            def pieces_of(lo_, hi_):
-                # (pieces of the walk: a layer; with --defer-da bucket a whole gradient bucket, whose dA_m launches leave together)
-                if args.defer_da == "bucket":
-                    return [(f, bucket.bucket_layers(f).stop) for f in reversed(bucket.bucket_firsts()) if lo_ <= f < hi_]
-                return [(l, l + 1) for l in range(hi_ - 1, lo_ - 1, -1)]
-
-            graph_keep = []
-            if os.environ.get("MOKA_BENCH_FAIL_CAPTURE") == "1":
-                raise RuntimeError("MOKA_BENCH_FAIL_CAPTURE=1 (test hook: exercise the live fallback)")
-            if args.graph == "all":
-                # (collectives cannot ride inside the graph: capturing the one-rank RCCL all-reduce with torch 2.10 / RCCL 2.26.6 segfaults at
-                #  capture time -- measured round 4 -- so N > 1 and --force-comm use one graph per gradient bucket with the hooks between them)
-                assert not comm, "--graph all: single GPU without collectives only"
-                fwd_bwd_graph = torch.cuda.CUDAGraph()
-                if not args.hub:
-                    da_side = torch.cuda.Stream(device=dev)
-                    with torch.cuda.graph(fwd_bwd_graph, stream=side):
-                        cur = torch.cuda.current_stream()
-                        spg = c_void_p(cur.cuda_stream)
-                        if opt_in_bwd:
-                            opt.begin_step(device_counter=True)
-                            opt.t -= 1                   # (the capture is not a step)
-                        run_forward(lib, wl, spg, shadows=shadows_main)
-                        run_backward(lib, wl, spg, L, defer=(args.defer_da, cur, da_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None,
-                                     bucket_opt=(opt, bucket, 1.0 / world) if opt_in_bwd else None, shadows_after_opt=shadows_opt and opt_in_bwd)
-                else:
-                    graph_keep.append(capture_hub(fwd_bwd_graph, True, pieces_of(0, L), opt_in_bwd))
-            elif not args.hub:
-                da_side = torch.cuda.Stream(device=dev)
-                fwd_graph = torch.cuda.CUDAGraph()       # the forward has no hooks: one graph
-                with torch.cuda.graph(fwd_graph, stream=side):
-                    run_forward(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), shadows=shadows_main)
-                bwd_graphs = []
-                for lo in reversed(bucket.bucket_firsts()):      # buckets are contiguous groups of layers, walked last -> first
-                    hi = bucket.bucket_layers(lo).stop
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        cs = torch.cuda.current_stream()
-                        run_backward(lib, wl, c_void_p(cs.cuda_stream), hi, lo=lo,
-                                     defer=(args.defer_da, cs, da_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None)
-                    bwd_graphs.append((g, lo, hi))
-            else:
-                # N > 1 with part-batch chains: the forward as one hub-shaped graph, one hub-shaped graph per gradient bucket of the backward (the
-                # chains meet at every graph's end: that is where the bucket's all-reduce is handed to RCCL)
-                fwd_graph = torch.cuda.CUDAGraph()
-                graph_keep.append(capture_hub(fwd_graph, True, [], False))
-                bwd_graphs = []
-                for lo in reversed(bucket.bucket_firsts()):
-                    hi = bucket.bucket_layers(lo).stop
-                    g = torch.cuda.CUDAGraph()
-                    graph_keep.append(capture_hub(g, False, pieces_of(lo, hi), False))
-                    bwd_graphs.append((g, lo, hi))
-            torch.cuda.synchronize()
-        except Exception as exc:                         # capture is an optimisation, never a requirement
-            # (with chains: the part-batches then run one after the other on the one stream -- every launch of the step still happens)
-            print(f"bench: hipGraph capture failed ({exc!r}); launching live" + (", the %d chains back to back" % args.chains if args.chains > 1 else ""), file=sys.stderr)
-            fwd_bwd_graph, bwd_graphs, fwd_graph = None, None, None
-            args.graph = "off (capture failed)"          # (what the line reports is what ran)
-            torch.cuda.synchronize()
-
-    # N > 1: how long the main stream stands still in bucket.finish() (the part of the all-reduce the backward did not hide)
-    comm_ev = [] if comm else None
-
-    live_side = torch.cuda.Stream(device=dev) if args.defer_da != "off" else None
+    sched.capture()                                  # (falls back to live launches, and says so, if the capture fails)
+    args.graph = sched.graph_mode                    # (what the line reports is what ran)
+    fwd_bwd_graph, bwd_graphs = sched.fwd_bwd_graph, sched.bwd_graphs
 
     def step(i, rec=None):
-        sp = c_void_p(main_stream.cuda_stream)
-        if opt is None:
-            bucket.zero_()                           # (the optimizer kernel leaves the gradient buffer zeroed)
-        if opt_in_bwd:
-            if fwd_bwd_graph is None:
-                opt.begin_step()                     # this step's coefficients: a one-thread launch on the main stream (launch arguments)
-            else:
-                opt.t += 1                           # (the captured launch counts on the device; the host keeps the books)
-        if fwd_bwd_graph is not None:
-            fwd_bwd_graph.replay()
-        else:
-            if fwd_graph is not None:
-                fwd_graph.replay()
-            else:
-                for ch in wl["chains"]:
-                    run_forward(lib, ch, sp, rec, shadows=shadows_main)
-            if bwd_graphs is not None:
-                for g, lo, hi in bwd_graphs:
-                    g.replay()
-                    for l in range(hi - 1, lo - 1, -1):
-                        bucket.layer_done(l)         # all-reduce of the finished bucket overlaps the next graphs
-            else:
-                # (live launches: the chains one after the other; the bucket hooks / optimizer slices ride with the LAST chain's layers -- every
-                #  earlier chain's gradients are in front of them in stream order)
-                for ci, ch in enumerate(wl["chains"]):
-                    last = ci == len(wl["chains"]) - 1
-                    run_backward(lib, ch, sp, L, bucket.layer_done if last else None, rec,   # all-reduce of finished layer groups overlaps the rest
-                                 defer=(args.defer_da, main_stream, live_side, args.split_db, bucket.is_bucket_first) if args.defer_da != "off" else None,
-                                 bucket_opt=(opt, bucket, 1.0 / world) if (opt_in_bwd and not comm and last) else None,
-                                 shadows_after_opt=shadows_opt and opt_in_bwd and not comm and last)
-        if comm_ev is not None and i >= args.warmup:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main_stream)
-            bucket.finish(average=opt is None)
-            e1.record(main_stream)
-            comm_ev.append((e0, e1))
-        else:
-            bucket.finish(average=opt is None)       # join the all-reduces; the optimizer kernel averages (grad_scale)
-        if opt is not None and not opt_in_bwd:
-            opt.step(grad_scale=1.0 / world, zero_grad=True)
-        if shadows_opt and opt is not None and not (opt_in_bwd and not comm) and not shadows_in_cb:
-            run_shadows(lib, wl, sp, range(L))       # (every weight has changed: the shadows of the whole stack, behind the step)
+        sched.step(i, rec, time_comm=i >= args.warmup)
 
     for i in range(args.warmup):
         step(i)
@@ -1181,18 +671,7 @@ def main():
     # host side of a replay: how long hipGraphLaunch keeps the launching thread for ONE step (idle GPU in front of it, so nothing blocks on
     # a full queue) against the step on the GPU -- a multi-branch graph is replayed node by node, and a step whose replay takes the host
     # longer than the GPU needs is host-bound
-    replay_host_ms = None
-    if fwd_bwd_graph is not None and rank == 0:
-        hs = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            fwd_bwd_graph.replay()
-            hs.append((time.perf_counter() - th) * 1e3)
-            torch.cuda.synchronize()
-            if opt_in_bwd:
-                opt.t += 1
-        replay_host_ms = round(min(hs), 3)
+    replay_host_ms = sched.replay_host_ms() if rank == 0 else None
 
     # --verify-graph: the captured schedule (chains on forked streams, deferred dA_m on the hub, whatever the executor makes of it) against the
     # same launches live, one chain after the other on ONE stream, from the same activation state: y and dx bit for bit (deterministic
@@ -1210,20 +689,13 @@ def main():
             bucket.zero_()
         restore()
         torch.cuda.synchronize()
-        if fwd_bwd_graph is not None:
-            fwd_bwd_graph.replay()
-        else:
-            fwd_graph.replay()
-            for g, lo, hi in bwd_graphs:
-                g.replay()
+        sched.replay_only()
         torch.cuda.synchronize()
         g_graph = bucket.flat.clone()
         got = [t.clone() for t in mut]
         restore()
         sp_v = c_void_p(torch.cuda.current_stream().cuda_stream)
-        for ch in wl["chains"]:
-            run_forward(lib, ch, sp_v, None, shadows=shadows_main)
-            run_backward(lib, ch, sp_v, L, None, None)
+        sched.live_pass(sp_v)
         torch.cuda.synchronize()
         den = float(bucket.flat.abs().max())
         graph_check = {"activations_bit_identical": all(torch.equal(a_, b_) for a_, b_ in zip(got, mut)), "tensors_compared": len(mut),
@@ -1232,6 +704,58 @@ def main():
                        "what": "graph replay vs the same launches live, chain after chain on one stream, from the same activation state"}
         restore()
         del got, g_graph
+
+    # In-schedule marginals: the SAME captured schedule with one kernel family's launches left out (ScheduleConfig.skip:
+    # the executor simply does not enqueue them -- no rebuilt library, no edited source), timed like the headline; marginal = base - without.
+    # The default line carries the dominant family's (`roofline.in_schedule`); --ablate all / a list: the whole table (`ablation`).
+    ablation = None
+    if rank == 0 and world == 1 and not comm and sched.fwd_bwd_graph is not None and args.ablate != "off" and not args.verify_graph:
+        fams = ["up_fwd"] if args.ablate == "dominant" else ([f for f in SCH.FAMILIES if f != "none"] if args.ablate == "all" else [f.strip() for f in args.ablate.split(",")])
+        if opt is None:
+            fams = [f for f in fams if f != "optimizer"]
+        n_ab = max(5, min(args.steps, 20))
+
+        def timed_schedule(skip, accept_ms=None, tries=3):
+            # (every capture creates new streams, and which in-order hardware queues the executor maps a graph's lists onto depends on how many
+            #  exist: every few captures the two chains of a graph share a queue and the step takes ~46 instead of ~30 ms.  A schedule is therefore
+            #  captured up to `tries` times and the FASTEST capture counts -- the mapping is the runtime's, not the schedule's)
+            best = None
+            for _ in range(tries):
+                sc = SCH.GraphedAdapterStep(wl, make_cfg(skip), L, optimizer=opt, world=world, comm=comm, device=dev)
+                if not sc.capture():
+                    return None
+                for i_ in range(3):
+                    sc.step(i_)
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for i_ in range(n_ab):
+                    sc.step(i_)
+                torch.cuda.synchronize()
+                ms_ = (time.perf_counter() - t_) * 1e3 / n_ab
+                best = ms_ if best is None else min(best, ms_)
+                del sc
+                if accept_ms is not None and best <= accept_ms:
+                    break
+            return best
+        fam_bytes = {"down_fwd": lambda u: u.algo["moka_down_fwd"], "up_fwd": lambda u: u.algo["moka_up_fwd"], "up_bwd": lambda u: u.algo["moka_up_bwd"],
+                     "cross_bwd": lambda u: u.algo["moka_cross_bwd"], "dx": lambda u: 2 * E * u.T * u.d_in * u.G, "dA": lambda u: E * u.T * u.d_in * u.G,
+                     "shadows": lambda u: u.algo["moka_weight_shadows"] / max(1, args.chains), "optimizer": lambda u: 0, "none": lambda u: 0}
+        rows = {}
+        for fam in fams:
+            base_ms = timed_schedule((), accept_ms=1.02 * ms_per_step)   # (re-measured beside every ablated schedule: the pair shares the box's clock state)
+            wo_ms = timed_schedule((fam,), accept_ms=0.0)
+            if base_ms is None or wo_ms is None:
+                continue
+            nbytes = sum(fam_bytes[fam](u) for ch in wl["chains"] for u in ch["units"]) if fam != "optimizer" else 34 * wl["n_params"]
+            marg = base_ms - wo_ms
+            rows[fam] = {"base_ms": round(base_ms, 3), "without_ms": round(wo_ms, 3), "marginal_ms": round(marg, 3), "algorithmic_bytes": int(nbytes),
+                         "achieved_GBps": round(nbytes / (marg * 1e-3) / 1e9, 1) if marg > 0 else None,
+                         "frac": round(nbytes / (marg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if marg > 0 else None}
+        ablation = {"how": "step time of the captured schedule minus the step time of the same schedule captured WITHOUT the family's launches "
+                           "(moka_amd.schedule.ScheduleConfig.skip), %d timed steps each after 3 warm-up steps, base re-measured beside every row, fastest of "
+                           "up to 3 captures per schedule (the runtime's queue mapping of a capture varies); "
+                           "algorithmic bytes per step (SURVEY 8(d)) / marginal time" % n_ab,
+                    "families": rows}
 
     out = None
     if rank == 0:
@@ -1259,16 +783,12 @@ def main():
             # graph replay: nothing can be bracketed inside the timed region -> the dominant entry point is bracketed (every n-th
             # launch, as in the live mode) in extra live passes right behind it, same buffers, same kernel sequence
             for _ in range(min(args.steps, 3)):
-                for ch in wl["chains"]:
-                    run_forward(lib, ch, sp_, records, shadows=shadows_main)
-                    run_backward(lib, ch, sp_, L, None, None)
+                sched.live_pass(sp_, records, None)
             torch.cuda.synchronize()
         tot, cnt, byt, per_shape = collect(records.items)         # the dominant entry point (LIVE)
         # every entry point, in one extra untimed pass (full bracketing would perturb the timed region)
         extra = Recorder()
-        for ch in wl["chains"]:
-            run_forward(lib, ch, sp_, extra, shadows=shadows_main)
-            run_backward(lib, ch, sp_, L, None, extra)
+        sched.live_pass(sp_, extra, extra)
         if shadows_opt:
             run_shadows(lib, wl, sp_, range(L), extra)
         torch.cuda.synchronize()
@@ -1350,7 +870,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # `value` is the whole-job aggregate over the N GPUs (driver contract); the metric's per-GPU figure beside it
             "tokens_per_s_per_gpu": round(tokens_per_s / world, 1), "aggregate_tokens_per_s": round(tokens_per_s, 1),
-            "comm_exposed_ms": (round(sum(a.elapsed_time(b) for a, b in comm_ev) / max(1, len(comm_ev)), 4) if comm_ev else 0.0),
+            "comm_exposed_ms": (round(sum(a.elapsed_time(b) for a, b in sched.comm_ev) / max(1, len(sched.comm_ev)), 4) if sched.comm_ev else 0.0),
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Llama-2-%s dims, MokA r=%d %s, adapter fwd+bwd of 7x%d projections, "
                                    "seq=%d (%s), lora_dropout %g, batch %d seq/GPU, %s, "
@@ -1376,9 +896,9 @@ def main():
             "defer_dA": args.defer_da,
             "defer_dB": bool(args.split_db), "chain_priority": args.chain_priority, "optimizer_in_backward": bool(opt_in_bwd),
             # (what this line's schedule is and is not: ADVICE r04)
-            "schedule": "bench.py's launch schedule over the C ABI (part-batch chains / deferred dA_m on a hub stream / one hipGraph, persistent weight "
-                        "shadows rewritten behind the optimizer slices); moka_amd.parallel.attach + MokaLinearFn run ONE chain through autograd and "
-                        "relaunch the shadows every forward: --e2e measures that path",
+            "schedule": "moka_amd.schedule.GraphedAdapterStep over the C ABI (part-batch chains / deferred dA_m on a hub stream / one hipGraph, persistent "
+                        "weight shadows rewritten behind the optimizer slices) on caller-owned buffers; the autograd path (moka_amd.parallel.attach + "
+                        "MokaLinearFn under a decoder stack, GraphedTrainStep) is what --e2e measures",
             "adapter_hbm_roofline_frac": round(algo_gbs / world / HBM_PEAK_GBS, 4),
             "adapter_algorithmic_GBps_per_gpu": round(algo_gbs / world, 1),
             # what the bus really carries: this implementation's own bytes (x / dx of a group once, x a second time for the deferred dA)
@@ -1394,11 +914,16 @@ def main():
                          "note": (None if args.chains == 1 else
                                   "launches of %d tokens timed ALONE, the %d chains back to back on one stream; in the step they run beside the other chain's "
                                   "launches (not observable inside a graph; rocprofv3 serialises the dispatches) -- adapter_hbm_roofline_frac is the step's figure"
-                                  % (T // args.chains, args.chains))},
+                                  % (T // args.chains, args.chains)),
+                         # the dominant family INSIDE the timed schedule (both chains, hub launches and all): marginal of leaving its launches out
+                         "in_schedule": (dict(kernel=kern_name, family="up_fwd", **ablation["families"]["up_fwd"], how=ablation["how"])
+                                         if (ablation and "up_fwd" in ablation["families"]) else None)},
             "entry_point_ms_per_pass": {n: round(tot_x[n], 3) for n in ENTRY},
             "forward_only": fwd_only,
             "kernels": table,
         }
+        if ablation is not None and args.ablate != "dominant":
+            out["ablation"] = ablation
         if world == 1 and args.e2e:
             del wl, opt, records
             torch.cuda.empty_cache()
