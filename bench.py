@@ -96,13 +96,25 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
     B, S, r, M = args.batch, args.seq, args.rank, (2 if vt else 3)
     dims, L = MODELS[args.model], args.layers
     d, ff = dims["d"], dims["ff"]
-    assert 1 <= chains <= B, "--chains: at most one chain per sequence"
-    sizes = [B // chains + (1 if ci < B % chains else 0) for ci in range(chains)]      # (uneven splits: the larger part-batches first)
     T = B * S
     tok, q = synthetic_layout(S)
     if vt:
         # BASELINE.json configs[1]: visual-text -- the audio span becomes text, bool [B,S] masks (VisualText/train/train.py:206-231)
         tok = torch.where(tok == 2, torch.zeros_like(tok), tok)
+    by_class = getattr(args, "chain_split", "sample") == "class" and chains == 2
+    if by_class:
+        # chains INSIDE the samples: text tokens that are neither query nor key rows interact with nothing
+        # (lora.py:497-499 masks the update to video / audio rows; keys are the question span), so the token blocks that hold query / key
+        # rows -- here: every sequence's leading blocks up to the end of the question span -- form chain 0 (with the rank-space launches'
+        # real work), the text-only rest of every sequence chain 1 (a routing without keys).  Same tokens, same sums; also for B = 1.
+        span = int(max(int(torch.nonzero(q).max()) if bool(q.any()) else -1, int(torch.nonzero(tok > 0).max()) if bool((tok > 0).any()) else -1)) + 1
+        S0 = min(S, (span + 127) // 128 * 128)
+        assert 0 < S0 < S and bool((tok[S0:] == 0).all()) and not bool(q[S0:].any()), "--chain-split class: no text-only tail in this layout"
+        parts = [(B, S0, tok[:S0], q[:S0]), (B, S - S0, None, None)]
+    else:
+        assert 1 <= chains <= B, "--chains: at most one chain per sequence"
+        # (uneven splits: the larger part-batches first)
+        parts = [(B // chains + (1 if ci < B % chains else 0), S, tok, q) for ci in range(chains)]
     RP = _lib.rank_pad(r)
     bf, f32 = torch.bfloat16, torch.float32
     width = lambda k: dims[k]          # noqa: E731
@@ -149,20 +161,26 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
             unit_defs.append((src, [pi]))
 
     s = 16.0 / r
+    # the device word the dropout kernels fold into their seeds (moka_opts.seed_dev): the executor rewrites it in front of every step, so the
+    # replays of a captured graph -- seeds frozen with the launch arguments -- draw fresh keep masks like the training steps they stand for
+    seed_epoch = torch.zeros(1, dtype=torch.int64, device=dev) if (args.dropout > 0 and getattr(args, "seed_dev", "on") == "on") else None
     nset = max(1, min(L, args.distinct))
     chain_list, keep = [], []
     shadow_bufs = {}              # (layer, projection) -> (BwT, AT): functions of the weights alone, so every chain reads the same pair
     for ci in range(chains):
-        Bc = sizes[ci]
-        Tc = Bc * S
+        Bc, Sc, tok_c, q_c = parts[ci]
+        Tc = Bc * Sc
         Tp = _lib.tok_pad(Tc)
         max_ks = max(_lib.ksplit(Tc, ff, r, 1), _lib.ksplit(Tc, d, r, 2), _lib.ksplit_bwd(Tc, ff, r))
-        if vt:
-            masks = [(tok == 0).reshape(1, S).repeat(Bc, 1).to(dev), (tok == 1).reshape(1, S).repeat(Bc, 1).to(dev), q.reshape(1, S).repeat(Bc, 1).to(dev)]
+        if tok_c is None:
+            masks = None
+            rt = MokaRouting.plain(Bc, Sc, dev, M)                   # text tokens only, no key rows: the adapter of modality 0, no interaction
+        elif vt:
+            masks = [(tok_c == 0).reshape(1, Sc).repeat(Bc, 1).to(dev), (tok_c == 1).reshape(1, Sc).repeat(Bc, 1).to(dev), q_c.reshape(1, Sc).repeat(Bc, 1).to(dev)]
             rt = MokaRouting.from_vt_masks(*masks)
         else:
-            masks = [(tok == m).to(torch.int32).reshape(1, S, 1).repeat(Bc, 1, 1).to(dev) for m in range(3)]
-            masks.append(q.to(torch.int32).reshape(1, S, 1).repeat(Bc, 1, 1).to(dev))
+            masks = [(tok_c == m).to(torch.int32).reshape(1, Sc, 1).repeat(Bc, 1, 1).to(dev) for m in range(3)]
+            masks.append(q_c.to(torch.int32).reshape(1, Sc, 1).repeat(Bc, 1, 1).to(dev))
             rt = MokaRouting.from_avt_masks(masks)
         # activation buffers: `args.distinct` layer sets cycled (all chains together: each set >> 256 MiB Infinity Cache).  Projections
         # fed by the same tensor (q/k/v <- hid, gate/up <- hid2) share ONE input and ONE input-gradient buffer, as in the
@@ -200,12 +218,12 @@ def build_workload(args, dev, lib, bucket_factory, chains=1):
                                   1.0 if vt else s, [s] * M if vt else [1.0] * M, 0.05 if vt else 1.0, 1.0 / math.sqrt(r), args.dropout,
                                   [1000003 * l + pi + 7919 * 104729 * ci for pi in pis],      # every chain its own dropout masks
                                   own_dh_kmj=own[l % n_own][len(units) % len(unit_defs)] if defer else None, fused=fused,
-                                  company=chains if getattr(args, "company_hint", "on") == "on" else 1))
+                                  company=chains if getattr(args, "company_hint", "on") == "on" else 1, seed_dev=seed_epoch))
         layer_da, layer_db = SCH.make_layer_batches(units, len(unit_defs), L, rt, Tc, r, M, args.dropout) if defer else ([], [])
         chain_list.append(SCH.AdapterChain(units=units, units_per_layer=len(unit_defs), rt=rt, T=Tc, layer_da=layer_da, layer_db=layer_db, rank=r, reuse_wait=(n_own < L)))
         keep.append((sets, masks, scratch2, own))
     return SCH.AdapterWorkload(units=chain_list[0]["units"], units_per_layer=len(unit_defs), rt=chain_list[0]["rt"], layer_da=chain_list[0]["layer_da"], layer_db=chain_list[0]["layer_db"], rank=r, chains=chain_list, master=master, work=work, reuse_wait=chain_list[0]["reuse_wait"],
-                             gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep)
+                             gbuf=gbuf, bucket=bucket, T=T, n_params=n_params, layer_end=layer_end, keep=keep, seed_epoch=seed_epoch)
 
 
 ENTRY = SCH.ENTRY
@@ -376,7 +394,7 @@ def end_to_end(args, dev):
         m.weight.requires_grad = False
         return m
 
-    def timed(make, train_adapter):
+    def build(make, train_adapter):
         old = torch.get_default_dtype()
         torch.set_default_dtype(bf)
         try:
@@ -387,45 +405,111 @@ def end_to_end(args, dev):
         st.train()
         for n, p_ in st.named_parameters():
             p_.requires_grad = train_adapter and "lora_" in n
-        params = [p_ for p_ in st.parameters() if p_.requires_grad]
-        opt = torch.optim.AdamW(params, lr=1e-4, fused=True) if params else None
-        x = h.clone().requires_grad_(True)            # dx reaches the embeddings / projector in the real model
+        return st
 
-        def step():
-            out, _ = st(x, masks)
-            out.backward(gout)
-            if opt is not None:
-                opt.step()
-                opt.zero_grad(set_to_none=False)
-            x.grad = None
-
-        for _ in range(2):
+    def clock(step, n=3, warm=2):
+        for _ in range(warm):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 3
         for _ in range(n):
             step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3 / n
-        del st, opt, params
+        return (time.perf_counter() - t0) * 1e3 / n
+
+    batch = {"h": h, "gout": gout, "m_t": masks[0], "m_v": masks[1], "m_a": masks[2], "m_q": masks[3]}
+
+    def stack_loss(st):
+        # (dx reaches the embeddings / projector in the real model: the stack's input carries a gradient; the "loss" is <out, gout>, whose
+        #  backward feeds gout into the last layer like out.backward(gout) does)
+        def f(part):
+            x = part["h"].detach().requires_grad_(True)
+            out, _ = st(x, [part["m_t"], part["m_v"], part["m_a"], part["m_q"]])
+            return (out.float() * part["gout"].float()).sum() / out.shape[0]
+        return f
+
+    def live(make, mode, **attach_kw):
+        """mode: "base" (frozen stack only) | "autograd" (adapters as plain autograd nodes + torch's fused AdamW: no attach) |
+        "attach" (moka_amd.parallel.attach: gradient sinks, persistent weight shadows, the fused flat AdamW; defer_dA as given)."""
+        st = build(make, mode != "base")
+        f = stack_loss(st)
+        if mode == "attach":
+            from moka_amd.parallel import attach
+            dp = attach(st, n_buckets=8, lr=1e-4, **attach_kw)
+
+            def step():
+                f(batch).backward()
+                dp.step()
+        else:
+            params = [p_ for p_ in st.parameters() if p_.requires_grad]
+            opt = torch.optim.AdamW(params, lr=1e-4, fused=True) if params else None
+
+            def step():
+                f(batch).backward()
+                if opt is not None:
+                    opt.step()
+                    opt.zero_grad(set_to_none=False)
+        ms = clock(step)
+        del st, step, f
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         return ms
 
-    from moka_amd import functional as MF
-    ms_base = timed(plain, False)
-    ms_moka = timed(adapted, True)
-    # the adapter's x-only / gy-only halves on a side stream beside the frozen base GEMM of the same projection (functional.OVERLAP_BASE,
-    # attach(overlap_base=True)): same kernels, same bits
-    MF.set_overlap_base(True)
-    try:
-        ms_ovl = timed(adapted, True)
-    finally:
-        MF.set_overlap_base(False)
-    return {"what": "decoder stack fwd+bwd (+ fused AdamW on the adapter), %d layers, %d x %d tokens, bf16; NOT the metric" % (L, B, S),
-            "ms_per_step": round(ms_moka, 2), "tokens_per_s": round(B * S / (ms_moka * 1e-3), 1),
-            "frozen_base_only_ms_per_step": round(ms_base, 2), "adapter_share_of_step": round(1.0 - ms_base / ms_moka, 4),
-            "overlap_base": {"ms_per_step": round(ms_ovl, 2), "adapter_share_of_step": round(1.0 - ms_base / ms_ovl, 4)}}
+    def graphed(make, with_adapter, chains, **attach_kw):
+        """The whole step as ONE hub-shaped hipGraph captured through autograd (moka_amd.schedule.GraphedTrainStep)."""
+        from moka_amd.parallel import attach
+        from moka_amd.routing import MokaRouting
+        st = build(make, with_adapter)
+        dp = attach(st, n_buckets=8, lr=1e-4, **attach_kw) if with_adapter else None
+        gs = SCH.GraphedTrainStep(dp, stack_loss(st), batch, chains=chains,
+                                  routing_fn=(lambda p_: MokaRouting.from_avt_masks([p_["m_t"], p_["m_v"], p_["m_a"], p_["m_q"]])) if with_adapter else None)
+        ms = clock(lambda: gs(None), n=5)
+        del gs, dp, st
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        return ms
+
+    def say(msg):
+        print("bench --e2e: " + msg, file=sys.stderr, flush=True)
+
+    res = {"what": "decoder stack fwd+bwd (+ AdamW on the adapter), %d layers, %d x %d tokens, bf16; NOT the metric.  adapter_ms = the stack's step "
+                   "minus the frozen stack's step in the SAME launch mode" % (L, B, S)}
+    base_live = live(plain, "base")
+    say("frozen base, live: %.2f ms" % base_live)
+    auto_live = live(adapted, "autograd")
+    say("autograd nodes + torch AdamW, live: %.2f ms" % auto_live)
+    att_live = live(adapted, "attach", defer_dA=False)
+    say("attach(defer_dA=False), live: %.2f ms" % att_live)
+    att_defer = live(adapted, "attach", defer_dA=True)
+    say("attach(defer_dA=True), live: %.2f ms" % att_defer)
+    res["live"] = {"frozen_base_only_ms": round(base_live, 2),
+                   "autograd_nodes_torch_adamw_ms": round(auto_live, 2), "autograd_nodes_adapter_ms": round(auto_live - base_live, 2),
+                   "attach_ms": round(att_live, 2), "attach_adapter_ms": round(att_live - base_live, 2),
+                   "attach_defer_dA_ms": round(att_defer, 2), "attach_defer_dA_adapter_ms": round(att_defer - base_live, 2),
+                   "note": "defer_dA puts the dA_m launches on a side stream beside the NEXT layer's launches: beside the frozen base's hipBLASLt GEMMs the "
+                           "streaming kernel costs the GEMMs more than it hides (the same finding as round 5's overlap_base, removed this round)"}
+    best = att_live
+    for ch in ([1, 2] if args.e2e_chains2 else [1]):
+        if ch > B:
+            continue
+        try:
+            b_ms = graphed(plain, False, ch)
+            say("frozen base, graphed, %d chain(s): %.2f ms" % (ch, b_ms))
+            a_ms = graphed(adapted, True, ch, defer_dA=False)
+            say("attach(defer_dA=False), graphed, %d chain(s): %.2f ms" % (ch, a_ms))
+            d_ms = graphed(adapted, True, ch, defer_dA=True)
+            say("attach(defer_dA=True), graphed, %d chain(s): %.2f ms" % (ch, d_ms))
+            res["graphed_chains%d" % ch] = {"frozen_base_only_ms": round(b_ms, 2), "attach_ms": round(a_ms, 2), "adapter_ms": round(a_ms - b_ms, 2),
+                                            "attach_defer_dA_ms": round(d_ms, 2), "adapter_share_of_step": round(1.0 - b_ms / a_ms, 4)}
+            best = min(best, a_ms, d_ms)
+        except Exception as exc:                     # (a capture the runtime refuses is reported, not fatal: the live figures stand)
+            res["graphed_chains%d" % ch] = {"error": repr(exc)[:300]}
+            torch.cuda.synchronize()
+    res.update({"ms_per_step": round(best, 2), "tokens_per_s": round(B * S / (best * 1e-3), 1), "frozen_base_only_ms_per_step": round(base_live, 2),
+                "adapter_ms": round(att_live - base_live, 2), "adapter_share_of_step": round(1.0 - base_live / att_live, 4)})
+    return res
 
 
 def main():
@@ -448,6 +532,9 @@ def main():
     ap.add_argument("--e2e", action="store_true",
                     help="also time the whole decoder stack (frozen base + adapters) through moka_amd/decoder.py and report it as "
                          "`end_to_end` (context only; the metric stays the adapter path)")
+    ap.add_argument("--e2e-chains2", action="store_true",
+                    help="with --e2e: also capture the whole stack as TWO part-batch chains (tests/test_gpu_trainer.py runs that shape on a small stack; "
+                         "at the 7B widths the capture did not finish within minutes on ROCm 7.2 -- run it under `timeout`)")
     ap.add_argument("--graph", choices=("auto", "off", "bwd", "all"), default="auto",
                     help="hipGraph replay (the library only enqueues on the stream it is given, so its launches capture unchanged): "
                          "all = the whole micro-batch as one graph (single GPU; nothing can be bracketed inside a graph, so `roofline` comes "
@@ -473,6 +560,13 @@ def main():
                          "of the other; they share the parameters, the gradient accumulators and the optimizer slices.  0 (default) = 2 where the "
                          "batch splits evenly and the step is replayed as graphs, else 1.  Per-kernel durations (`roofline`, `kernels`) are "
                          "taken with the chains back to back on one stream")
+    ap.add_argument("--chain-split", choices=("sample", "class"), default="sample",
+                    help="how --chains 2 cuts the micro-batch: sample (default) = half the sequences each; class = by token class INSIDE every sequence: "
+                         "chain 0 the leading token blocks up to the end of the question span (all query / key rows: the interaction lives there), chain 1 "
+                         "the text-only rest (no key rows, no interaction) -- also splits a batch of ONE sequence")
+    ap.add_argument("--seed-dev", choices=("on", "off"), default="on",
+                    help="on: every step's dropout masks follow a device word rewritten in front of the step (moka_opts.seed_dev), so graph replays are "
+                         "distinct training steps; off: the seeds are launch arguments only (a replay repeats the capture's masks; A/B)")
     ap.add_argument("--company-hint", choices=("on", "off"), default="on",
                     help="with chains: tell the library how many chains run side by side (moka_opts.company: the pass over gy sizes its token runs for its "
                          "share of the CUs)")
@@ -677,9 +771,52 @@ def main():
     # same launches live, one chain after the other on ONE stream, from the same activation state: y and dx bit for bit (deterministic
     # kernels), the flat gradient to the spread of its fp32 atomics
     graph_check = None
-    if args.verify_graph and rank == 0:
-        if opt is not None or (fwd_bwd_graph is None and bwd_graphs is None):
-            raise SystemExit("--verify-graph compares gradients: run it with --no-optimizer and a graph mode")
+    if args.verify_graph and rank == 0 and opt is not None:
+        # the DEFAULT schedule -- chains sharing gradient accumulators, AdamW slices and shadow rewrites on the hub behind
+        # per-branch events, chain-first deferred optimizer slices -- against the same steps launched live from identical state: K steps
+        # each way from the same master / moments / activations; a missing hub -> chain edge (a shadow rewrite or the gradient zeroing
+        # racing a slower chain) shows up as different weights
+        if not sched.graphed:
+            raise SystemExit("--verify-graph: the step is not replayed from a graph")
+        K = 3
+        mut = [t for k in wl["keep"] for (acts, dacts, ys) in k[0] for t in list(dacts.values()) + list(ys)]
+        snap = [t.clone() for t in mut]
+        st0 = (wl["master"].clone(), wl["work"].clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t)
+        live_exec = SCH.GraphedAdapterStep(wl, SCH.ScheduleConfig(**{**make_cfg().__dict__, "graph": "off"}), L, optimizer=opt, world=world, comm=comm, device=dev)
+
+        def restore():
+            for t, s_ in zip(mut, snap):
+                t.copy_(s_)
+            wl["master"].copy_(st0[0]); wl["work"].copy_(st0[1]); opt.exp_avg.copy_(st0[2]); opt.exp_avg_sq.copy_(st0[3])
+            opt.t = st0[4]
+            opt.set_device_step(st0[4])
+            bucket.zero_()
+            run_shadows(lib, wl, c_void_p(torch.cuda.current_stream().cuda_stream), range(L))
+            torch.cuda.synchronize()
+        sh_units = [u for u in wl["units"] if u.fused][:8]
+        results = []
+        for ex in (sched, live_exec):
+            restore()
+            ex._epoch = 0                            # (the same sequence of dropout epochs either way)
+            for i_ in range(K):
+                ex.step(i_)
+            torch.cuda.synchronize()
+            results.append((wl["master"].clone(), wl["work"].clone(), [m["BwT"].clone() for u in sh_units for m in u.keep[0]], bucket.flat.clone(),
+                            [t.clone() for t in mut[:8]]))
+        (mg, wg, sg, fg, ag), (ml, wl_, sl, fl, al) = results
+        graph_check = {"what": "%d optimizer steps of the captured default schedule vs the same steps launched live (chains back to back, dA_m / AdamW slices "
+                               "on a side stream), from identical master / moments / activations" % K,
+                       "steps": K, "master_rel_diff": float((mg - ml).norm() / ml.norm()), "master_max_abs_diff": float((mg - ml).abs().max()),
+                       "work_max_abs_diff": float((wg.float() - wl_.float()).abs().max()),
+                       "shadows_equal_work": all(bool(torch.equal(a_, b_)) for a_, b_ in zip(sg, sl)) if float((wg.float() - wl_.float()).abs().max()) == 0.0 else None,
+                       "shadow_max_abs_diff": max([float((a_.float() - b_.float()).abs().max()) for a_, b_ in zip(sg, sl)] or [0.0]),
+                       "grad_left_zero": float(fg.abs().max()) == 0.0 and float(fl.abs().max()) == 0.0,
+                       "activations_max_rel_diff": max(float((a_.float() - b_.float()).norm() / b_.float().norm().clamp_min(1e-20)) for a_, b_ in zip(ag, al))}
+        restore()
+        del results, live_exec
+    elif args.verify_graph and rank == 0:
+        if fwd_bwd_graph is None and bwd_graphs is None:
+            raise SystemExit("--verify-graph: the step is not replayed from a graph")
         mut = [t for k in wl["keep"] for (acts, dacts, ys) in k[0] for t in list(dacts.values()) + list(ys)]
         snap = [t.clone() for t in mut]
 

@@ -69,12 +69,13 @@ extern "C" {
 typedef void* moka_stream_t;            /* hipStream_t */
 #endif
 
-#define MOKA_VERSION      603            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
+#define MOKA_VERSION      700            /* 0.5.0: per-call moka_opts (deterministic workspace) on the backward entry points, moka_deterministic()
                                             removed, moka_tune() only in the diagnostics build; 0.5.1: moka_up_bwd_passes(), moka_ksplit()
                                             at rank pad 64 depends on T; 0.5.2: moka_adamw_flat_dev(), moka_adamw_coef();
                                             0.6.0: moka_up_fwd_fused (the interaction inside the up-projection), hp_tok of moka_cross_fwd optional;
                                             0.6.1: moka_down_bwd_da_batch, moka_up_bwd_db_batch, moka_weight_shadows_batch, moka_up_fwd_fused at every rank pad;
-                                            0.6.2: moka_ksplit_group(); 0.6.3: moka_opts.company */
+                                            0.6.2: moka_ksplit_group(); 0.6.3: moka_opts.company;
+                                            0.7.0 (ABI break): moka_opts leads with struct_size and gains seed_dev, moka_down_fwd[_group] take a moka_opts */
 #define MOKA_MAX_MOD      3
 #define MOKA_MAX_GROUP    3              /* projections sharing one input (q/k/v, gate/up) */
 #define MOKA_MAX_SHADOW_BATCH 16         /* projections of one moka_weight_shadows_batch launch */
@@ -104,9 +105,13 @@ typedef struct moka_routing {
                                  chunks of 64 with a running softmax; only moka_cross_ws_bytes() grows with it */
 } moka_routing;
 
-/* Per-call options of the backward entry points (NULL = defaults).  Plain data owned by the caller; nothing is retained
- * after the call returns, so two trainers -- or two streams -- in one process never interact through the library. */
+/* Per-call options (NULL = defaults).  Plain data owned by the caller; nothing is retained after the call returns, so two trainers --
+ * or two streams -- in one process never interact through the library.
+ * ABI: struct_size = sizeof(moka_opts) AS THE CALLER WAS COMPILED.  The library reads no field beyond it (a shorter struct from an older
+ * header is valid: the missing fields are their defaults) and rejects a struct too short to hold `company` (0.7.0 is an ABI break against
+ * 0.6.x, whose struct had no size member: check moka_version() >= 700). */
 typedef struct moka_opts {
+    size_t struct_size; /* sizeof(moka_opts) */
     void*  det_ws;      /* != NULL: deterministic weight gradients (see "deterministic weight gradients" below); 16-byte aligned,
                            used by this call's launches on `stream` -- concurrent calls on other streams need their own */
     size_t det_bytes;   /* >= moka_deterministic_ws_bytes(T, C_max, r, G, M) for this call, checked before anything is launched */
@@ -116,6 +121,12 @@ typedef struct moka_opts {
                            r = 32, two chains of 4096 tokens: 40.5 -> 39.5 ms per step; r = 16: no difference), and moka_down_bwd gives the dx pass
                            of a wide input (d_in > 8192) three workgroups per CU instead of eight (r = 16, the 11008-wide input: 0.1-0.3 ms per
                            step).  Results are the same sums. */
+    const unsigned long long* seed_dev;
+                        /* NULL, or a DEVICE pointer (8-byte aligned) to one 64-bit word e the dropout kernels read when they start: the mask of
+                           the call is then the mask of the seed  ((seed_hi + e_hi) << 32) | (seed_lo ^ e_lo)  (32-bit halves; moka_dropout_mask with
+                           that combined seed replays it).  A launch captured in a hipGraph replays with its launch arguments frozen; whoever
+                           replays the graph rewrites *seed_dev before every replay (any stream-ordered write: a memset, a fill kernel) and every
+                           step draws fresh masks -- moka_down_fwd and moka_down_bwd / moka_down_bwd_da_batch of one step must see the same word. */
 } moka_opts;
 
 int         moka_version(void);
@@ -164,7 +175,7 @@ int moka_up_bwd_passes(int r, int dtype);
 int moka_down_fwd(const void* x, const void* const* A /*host array of M device ptrs*/,
                   const uint8_t* tok_mod, float* part,
                   int T, int d_in, int r, int M, float s_in, float dropout_p, unsigned long long seed,
-                  int dtype, moka_stream_t stream);
+                  int dtype, const moka_opts* opts /*NULL: defaults (seed_dev is the field read here)*/, moka_stream_t stream);
 
 /* Rank-r cross-modal interaction: sums the ks partials into h, computes
  * hp = h + w * softmax(h K^T * inv_sqrt_dk) K for query rows, and writes the operand packs of
@@ -272,7 +283,7 @@ int moka_up_bwd_db_batch(const void* const* gy /*[n]*/, const void* const* hp_km
  * one launch per projection (same results). */
 int moka_down_fwd_group(const void* x, const void* const* A /*[G*M]*/, const uint8_t* tok_mod, float* const* part /*[G]*/,
                         int T, int d_in, int r, int M, int G, float s_in, float dropout_p,
-                        const unsigned long long* seeds /*[G] or NULL when dropout_p == 0*/, int dtype, moka_stream_t stream);
+                        const unsigned long long* seeds /*[G] or NULL when dropout_p == 0*/, int dtype, const moka_opts* opts, moka_stream_t stream);
 int moka_cross_fwd_group(const float* const* part, int ks, const moka_routing* rt, const float* s_out,
                          const void* const* Bw, const int* d_out, const void* const* A /*[G*M]*/, int d_in,
                          float* const* h, float* const* hp /*NULL or [G] (entries may be NULL)*/,

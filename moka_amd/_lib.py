@@ -29,8 +29,14 @@ class MokaRoutingStruct(Structure):
 
 
 class MokaOpts(ctypes.Structure):
-    """moka_opts of include/moka_hip.h: per-call options of the backward entry points (the deterministic-mode workspace)."""
-    _fields_ = [("det_ws", c_void_p), ("det_bytes", ctypes.c_size_t), ("company", c_int)]
+    """moka_opts of include/moka_hip.h: per-call options (deterministic-mode workspace, how many launch chains run side by side, the
+    device-resident part of the dropout seed).  ``struct_size`` is filled in: the library reads no field beyond it."""
+    _fields_ = [("struct_size", ctypes.c_size_t), ("det_ws", c_void_p), ("det_bytes", ctypes.c_size_t), ("company", c_int), ("seed_dev", c_void_p)]
+
+    def __init__(self, det_ws=None, det_bytes=0, company=0, seed_dev=None):
+        super().__init__()
+        self.struct_size = ctypes.sizeof(MokaOpts)
+        self.det_ws, self.det_bytes, self.company, self.seed_dev = det_ws, int(det_bytes), int(company), seed_dev
 
 
 class MokaError(RuntimeError):
@@ -52,9 +58,9 @@ SYMBOLS = {
     "moka_ksplit_group": (c_int, [c_int, c_int, c_int, c_int]),
     "moka_ksplit_bwd": (c_int, [c_int, c_int, c_int]),
     "moka_up_bwd_passes": (c_int, [c_int, c_int]),
-    # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, stream
+    # x, A[], tok_mod, part, T, d_in, r, M, s_in, dropout_p, seed, dtype, opts, stream
     "moka_down_fwd": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p,
-                              c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_ulonglong, c_int, c_void_p]),
+                              c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_ulonglong, c_int, POINTER(MokaOpts), c_void_p]),
     # part, ks, rt, s_out[], Bw, d_out, A[], d_in, h, hp, hp_tok, hp_kmj, BwT, AT, r, w, c, stream
     "moka_cross_fwd": (c_int, [c_void_p, c_int, POINTER(MokaRoutingStruct), POINTER(c_float), c_void_p, c_int,
                                POINTER(c_void_p), c_int,
@@ -86,9 +92,9 @@ SYMBOLS = {
     "moka_down_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p,
                               c_int, c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_int, POINTER(MokaOpts), c_void_p]),
     # ---- grouped entry points (host arrays of G pointers)
-    # x, A[G*M], tok_mod, part[G], T, d_in, r, M, G, s_in, dropout_p, seeds[G], dtype, stream
+    # x, A[G*M], tok_mod, part[G], T, d_in, r, M, G, s_in, dropout_p, seeds[G], dtype, opts, stream
     "moka_down_fwd_group": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, POINTER(c_void_p),
-                                    c_int, c_int, c_int, c_int, c_int, c_float, c_float, POINTER(ctypes.c_ulonglong), c_int, c_void_p]),
+                                    c_int, c_int, c_int, c_int, c_int, c_float, c_float, POINTER(ctypes.c_ulonglong), c_int, POINTER(MokaOpts), c_void_p]),
     # part[G], ks, rt, s_out[], Bw[G], d_out[G], A[G*M], d_in, h[G], hp[G], hp_tok[G], hp_kmj[G], BwT[G], AT[G], G, r, w, c, stream
     "moka_cross_fwd_group": (c_int, [POINTER(c_void_p), c_int, POINTER(MokaRoutingStruct), POINTER(c_float),
                                      POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_int,

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -144,7 +145,9 @@ static __device__ __forceinline__ void wave_sum_vec(float (&v)[N]) {
 // is ~130 per 16-byte load.  The same function is evaluated by the down-projection (x), the dA kernel
 // (x) and the dx kernel (output), so nothing is stored and a re-run of the forward (activation
 // checkpointing) reproduces the mask bit for bit.
-struct DropArgs { unsigned thr, seed_lo, seed_hi, thrm1_pk; float inv_keep; };
+// epoch: NULL, or a device pointer to two dwords the kernels fold into the seed when they START (moka_opts.seed_dev): a launch captured in a
+// hipGraph replays with its launch arguments frozen, so a per-step dropout mask has to come from device memory the replay's owner rewrites.
+struct DropArgs { const unsigned* epoch; unsigned thr, seed_lo, seed_hi, thrm1_pk; float inv_keep; };
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 struct KeepMask { unsigned w[4]; };          // 0xffff in each kept 16-bit half
 
@@ -152,8 +155,14 @@ static __device__ __forceinline__ unsigned fmix32(unsigned h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
-static __device__ __forceinline__ KeepMask drop_keep8(const DropArgs& d, unsigned idx) {
-    const unsigned base = fmix32(idx ^ d.seed_lo) + d.seed_hi;
+// The two epoch dwords of a call (0, 0 without one), read ONCE at kernel entry (a uniform load: the values live in scalar registers).
+static __device__ __forceinline__ uint2 drop_epoch(const DropArgs& d) {
+    uint2 e = make_uint2(0u, 0u);
+    if (d.epoch) { e.x = d.epoch[0]; e.y = d.epoch[1]; }
+    return e;
+}
+static __device__ __forceinline__ KeepMask drop_keep8(const DropArgs& d, const uint2 ep, unsigned idx) {
+    const unsigned base = fmix32(idx ^ (d.seed_lo ^ ep.x)) + (d.seed_hi + ep.y);
     // (v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter: the four per-dword products take the top 24 bits of the base hash)
     constexpr unsigned K[4] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu};
     const unsigned b24 = base >> 8;
@@ -1031,6 +1040,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
         if (zi) xb -= ab.xend[zi - 1];
     }
     const ExpandArgs& a = ab.z[G == 1 ? zi : 0];
+    const uint2 ep = drop_epoch(a.drop);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int GY = (int)gridDim.y, BY = (int)blockIdx.y;
     const int i = lane & 15, g = lane >> 4;
@@ -1256,7 +1266,7 @@ __global__ void __launch_bounds__(256) moka_expand_kernel(const ExpandBatch ab) 
                 for (int e = 0; e < 8; ++e) v[e] = d[gi][q][e >> 2][e & 3];
                 float dsc = 1.f;
                 if (ag.drop.thr) {
-                    const KeepMask keep = drop_keep8(ag.drop, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
+                    const KeepMask keep = drop_keep8(ag.drop, ep, (unsigned)min(t, a.T - 1) * (unsigned)(a.C >> 3) + (unsigned)((c_wave + 32 * q) >> 3) + (unsigned)g);
                     dsc = ag.drop.inv_keep;
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
@@ -1348,6 +1358,7 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
     bf16x8* wl = (bf16x8*)smem;                                              // [G][NQ][2][KH][64]
     __shared__ unsigned s_wpm[8];
     const ExpandArgs& a = ab.z[0];
+    const uint2 ep = drop_epoch(a.drop);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ntiles = (a.T + 15) >> 4;
@@ -1458,7 +1469,7 @@ __global__ void __launch_bounds__(512, 2) moka_dxg_kernel(const ExpandBatch ab, 
                     for (int e = 0; e < 8; ++e) v[e] = mine ? d[e >> 2][e & 3] : 0.f;
                     float dsc = 1.f;
                     if (ag.drop.thr) {
-                        const KeepMask keep = drop_keep8(ag.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+                        const KeepMask keep = drop_keep8(ag.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
                         dsc = ag.drop.inv_keep;
 #pragma unroll
                         for (int w2 = 0; w2 < 4; ++w2) {
@@ -1614,6 +1625,7 @@ __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, 
     bf16x8* wl = (bf16x8*)smem;                                              // [NQ][2][KH][64]
     __shared__ unsigned s_wpm[8];
     const ExpandArgs& a = ab.z[0];
+    const uint2 ep = drop_epoch(a.drop);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ntiles = (a.T + 15) >> 4;
@@ -1703,7 +1715,7 @@ __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
                 if (a.drop.thr) {
-                    const KeepMask keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+                    const KeepMask keep = drop_keep8(a.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
                         const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
@@ -1742,6 +1754,7 @@ __global__ void __launch_bounds__(512, RP == 16 ? 4 : 3) moka_dxgt_kernel(const 
     bf16x8* wl = (bf16x8*)smem;                                              // [G][NQ][2][KH][64]
     __shared__ unsigned s_wpm[8];
     const ExpandArgs& a = ab.z[0];
+    const uint2 ep = drop_epoch(a.drop);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ntiles = (a.T + 15) >> 4;
@@ -1838,7 +1851,7 @@ __global__ void __launch_bounds__(512, RP == 16 ? 4 : 3) moka_dxgt_kernel(const 
                     for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
                     float dsc = 1.f;
                     if (ag.drop.thr) {
-                        const KeepMask keep = drop_keep8(ag.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+                        const KeepMask keep = drop_keep8(ag.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
                         dsc = ag.drop.inv_keep;
 #pragma unroll
                         for (int w2 = 0; w2 < 4; ++w2) {
@@ -2252,6 +2265,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
     const int gi = (G == 1) ? 0 : __builtin_amdgcn_readfirstlane(wave_all / NW);   // projection of this wave set
     const int wave = (G == 1) ? wave_all : wave_all - gi * NW;                        // token-run index inside the block
     const WgradArgs& a = ab.z[G == 1 ? blockIdx.z : gi];
+    const uint2 ep = drop_epoch(a.drop);
     const int i = lane & 15, g = lane >> 4;
     const int c_begin = blockIdx.x * CCB;
     if (c_begin >= a.C) return;                     // batched problems of different width (block uniform)
@@ -2331,7 +2345,7 @@ __global__ void __launch_bounds__(NW * G * 64) moka_wgrad_kernel(const WgradBatc
                 uint4 v = ld[sb][u];
                 if (a.drop.thr) {
                     const unsigned trow = (unsigned)min((grp << 5) + 8 * u + lrow, a.T - 1);
-                    const KeepMask keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)((c_begin + sb * 64) >> 3) + (unsigned)lcol);
+                    const KeepMask keep = drop_keep8(a.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((c_begin + sb * 64) >> 3) + (unsigned)lcol);
                     bf16x8 t8 = drop_apply(*(bf16x8*)&v, keep);
                     v = *(uint4*)&t8;
                 }
@@ -2482,6 +2496,7 @@ __global__ void __launch_bounds__(512) moka_wgrad_wide_kernel(const WgradBatch a
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int set = wave_all >> 2, nt = wave_all & 3;
     const WgradArgs& a = ab.z[blockIdx.z];
+    const uint2 ep = drop_epoch(a.drop);
     const int i = lane & 15, g = lane >> 4;
     const int c_begin = blockIdx.x * 64;
     if (c_begin >= a.C) return;                     // batched problems of different width (block uniform)
@@ -2557,7 +2572,7 @@ __global__ void __launch_bounds__(512) moka_wgrad_wide_kernel(const WgradBatch a
             uint4 v = ld[u];
             if (a.drop.thr) {
                 const unsigned trow = (unsigned)min((min(g0 + u, grp_last) << 5) + lrow, a.T - 1);
-                const KeepMask keep = drop_keep8(a.drop, trow * (unsigned)(a.C >> 3) + (unsigned)(c_begin >> 3) + (unsigned)lcol);
+                const KeepMask keep = drop_keep8(a.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)(c_begin >> 3) + (unsigned)lcol);
                 bf16x8 t8 = drop_apply(*(bf16x8*)&v, keep);
                 v = *(uint4*)&t8;
             }
@@ -3124,6 +3139,7 @@ struct XaArgs {
 // goes to a wave-private LDS slot; every PH groups the eight waves' slots are summed into one split-K slice.
 template <int RP, int G, int NG>
 __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
+    const uint2 ep = drop_epoch(a.drop[0]);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16, NW = 8, PH = 2;
     constexpr int RSLOT = 32 * RP;
@@ -3192,7 +3208,7 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
                         xg[kk] = F[st][kk];
                         if (a.drop[gi].thr) {
                             const unsigned trow = (unsigned)min((grp << 5) + 16 * st + i, a.T - 1);
-                            xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 32 * kk) >> 3) + (unsigned)g));
+                            xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], ep, trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 32 * kk) >> 3) + (unsigned)g));
                         }
                     }
 #pragma unroll
@@ -3282,6 +3298,7 @@ __global__ void __launch_bounds__(512) moka_xa_kernel(const XaArgs a) {
 // column range of every token block), half the block reductions.  The weight fragments of both halves are resident (G = 1: 12 fragments).
 template <int G, int NS, int HC = 1>
 __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_per_block) {
+    const uint2 ep = drop_epoch(a.drop[0]);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RP = 16, RPITCH = 1040, STAGE = 16 * RPITCH;   // bytes; pitch 260 dwords: the 64 lanes of a ds_read_b128 spread evenly over the banks
     constexpr int SLOT = 16 * RP;                                // floats per (wave, projection) partial tile
@@ -3389,7 +3406,7 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
                     xg[kk] = xf[kk];
                     if (a.drop[gi].thr) {
                         const unsigned trow = (unsigned)((t0 + k) * 16 + i);
-                        xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 512 * hf + 32 * kk) >> 3) + (unsigned)g));
+                        xg[kk] = drop_apply(xg[kk], drop_keep8(a.drop[gi], ep, trow * (unsigned)(a.C >> 3) + (unsigned)((c0 + 512 * hf + 32 * kk) >> 3) + (unsigned)g));
                     }
                 }
 #pragma unroll
@@ -3431,6 +3448,7 @@ __global__ void __launch_bounds__(512) moka_xs_kernel(const XaArgs a, int tiles_
 // ------------------------------------------------------------------------------------------
 template <int RP, int G, int KW>
 __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_kernel(const XaArgs a, int sub_per_block) {
+    const uint2 ep = drop_epoch(a.drop[0]);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK;     // a sub-tile streams in NU units of HK K steps (two units in flight)
     constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality, projection, rank tile)
@@ -3510,7 +3528,7 @@ __global__ void __launch_bounds__(512, (G * (RP / 16) >= 3) ? 2 : 4) moka_xw_ker
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) {
                     bf16x8 xg = xq;
-                    if (a.drop[gi].thr) xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
+                    if (a.drop[gi].thr) xg = drop_apply(xg, drop_keep8(a.drop[gi], ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
 #pragma unroll
                     for (int m = 0; m < MOKA_MAX_MOD; ++m) {
                         if (!(pm & (1u << m))) continue;     // wave uniform
@@ -3567,6 +3585,7 @@ template <int RP, bool ONEW, int G>
 __global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaBatch ab, int cps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const XaArgs& a = ab.z[blockIdx.z];
+    const uint2 ep = drop_epoch(a.drop[0]);
     constexpr int KW = 256, NT = RP / 16, NKS = KW / 32, HK = 4, NU = NKS / HK, NSLOT = (ONEW || G > 1) ? 1 : 2;
     constexpr int FR = NKS * 64;                             // 16-byte fragments of one (modality slot, rank tile)
     static_assert(NU == 2, "a chunk streams in two units");
@@ -3667,7 +3686,7 @@ __global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaBa
 #pragma unroll
                     for (int gi = 0; gi < G; ++gi) {
                         bf16x8 xg = xq;
-                        if (a.drop[gi].thr) xg = drop_apply(xg, drop_keep8(a.drop[gi], trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
+                        if (a.drop[gi].thr) xg = drop_apply(xg, drop_keep8(a.drop[gi], ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb0 + 32 * ks) >> 3) + (unsigned)g));
 #pragma unroll
                         for (int sl = 0; sl < NSLOT; ++sl) {
                             const int m = sl ? m1 : m0;
@@ -3707,7 +3726,7 @@ __global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaBa
 __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int T, int C, unsigned char* out) {
     const size_t nchunk = (size_t)T * (C >> 3);
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nchunk; idx += (size_t)gridDim.x * 256) {
-        const KeepMask keep = drop_keep8(d, (unsigned)idx);
+        const KeepMask keep = drop_keep8(d, drop_epoch(d), (unsigned)idx);
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[idx * 8 + e] = drop_kept(keep, e) ? 1 : 0;
     }
@@ -3722,7 +3741,7 @@ __global__ void __launch_bounds__(256) moka_dropout_mask_kernel(DropArgs d, int 
 // ------------------------------------------------------------------------------------------
 static __device__ __forceinline__ float drop_f32(const DropArgs& d, int t, int c, int C, float v) {
     if (!d.thr) return v;
-    const KeepMask km = drop_keep8(d, (unsigned)t * (unsigned)(C >> 3) + (unsigned)(c >> 3));
+    const KeepMask km = drop_keep8(d, drop_epoch(d), (unsigned)t * (unsigned)(C >> 3) + (unsigned)(c >> 3));
     return drop_kept(km, c & 7) ? v : 0.f;
 }
 
@@ -3908,12 +3927,27 @@ static thread_local size_t g_det_need = 0;              // set by a launcher tha
 static thread_local int t_company = 1;                  // moka_opts.company of the call in progress (independent launch chains side by side)
 #define g_det_ws (t_det.ws)
 #define g_det_bytes (t_det.bytes)
-struct DetScope {
-    explicit DetScope(const moka_opts* o) {
-        t_det.ws = o ? (float*)o->det_ws : nullptr; t_det.bytes = (o && o->det_ws) ? o->det_bytes : 0; g_det_need = 0;
-        t_company = (o && o->company > 1) ? (o->company > 8 ? 8 : o->company) : 1;
+static thread_local const unsigned* t_seed_dev = nullptr;   // moka_opts.seed_dev of the call in progress (make_drop hands it to the kernels)
+// moka_opts as THIS library reads it: a caller built against an older header passes a shorter struct (its struct_size says how long), the
+// fields behind it read as zero -- never past the caller's struct
+static moka_opts opts_view(const moka_opts* o) {
+    moka_opts v;
+    memset(&v, 0, sizeof(v));
+    if (o) {
+        size_t n = o->struct_size;
+        if (n > sizeof(v)) n = sizeof(v);                // (a newer caller: the fields this build knows)
+        if (n >= sizeof(size_t)) memcpy(&v, o, n);
     }
-    ~DetScope() { t_det.ws = nullptr; t_det.bytes = 0; g_det_need = 0; t_company = 1; }
+    return v;
+}
+struct DetScope {
+    explicit DetScope(const moka_opts* o_in) {
+        const moka_opts o = opts_view(o_in);
+        t_det.ws = (float*)o.det_ws; t_det.bytes = o.det_ws ? o.det_bytes : 0; g_det_need = 0;
+        t_company = o.company > 1 ? (o.company > 8 ? 8 : o.company) : 1;
+        t_seed_dev = (const unsigned*)o.seed_dev;
+    }
+    ~DetScope() { t_det.ws = nullptr; t_det.bytes = 0; g_det_need = 0; t_company = 1; t_seed_dev = nullptr; }
 };
 
 static int fail(int code, const char* fmt, ...) {
@@ -3994,6 +4028,7 @@ static int make_drop(const char* fn, float p, unsigned long long seed, DropArgs*
     d->thrm1_pk = (thr - 1) | ((thr - 1) << 16);
     d->seed_lo = (unsigned)(seed & 0xffffffffull);
     d->seed_hi = (unsigned)(seed >> 32);
+    d->epoch = t_seed_dev;                               // (NULL without moka_opts.seed_dev: the seed is the launch argument alone)
     d->inv_keep = 32768.f / (float)(32768u - thr);
     return MOKA_OK;
 }
@@ -4644,13 +4679,18 @@ static bool f32_det(F32Args& a, int planes, int nruns, SumRunsArgs* sr) {
 
 extern "C" size_t moka_deterministic_ws_bytes(int T, int C_max, int r, int G, int M);
 // the workspace of a deterministic call is validated BEFORE the first launch: a failure must not leave half-updated accumulators
-static int check_det_opts(const char* fn, const moka_opts* o, bool wants_wgrad, int T, int Cmax, int r, int G, int M) {
-    if (!o || !o->det_ws || !wants_wgrad) return MOKA_OK;
-    if ((uintptr_t)o->det_ws & 15) return fail(MOKA_EINVAL, "%s: moka_opts.det_ws must be 16-byte aligned", fn);
+static int check_det_opts(const char* fn, const moka_opts* o_in, bool wants_wgrad, int T, int Cmax, int r, int G, int M) {
+    if (o_in && o_in->struct_size < offsetof(moka_opts, company) + sizeof(int))
+        return fail(MOKA_EINVAL, "%s: moka_opts.struct_size = %zu (set it to sizeof(moka_opts): the library reads no field beyond it)", fn, o_in->struct_size);
+    if (o_in && o_in->struct_size >= offsetof(moka_opts, seed_dev) + sizeof(void*) && ((uintptr_t)o_in->seed_dev & 7))
+        return fail(MOKA_EINVAL, "%s: moka_opts.seed_dev must be 8-byte aligned", fn);
+    const moka_opts o = opts_view(o_in);
+    if (!o.det_ws || !wants_wgrad) return MOKA_OK;
+    if ((uintptr_t)o.det_ws & 15) return fail(MOKA_EINVAL, "%s: moka_opts.det_ws must be 16-byte aligned", fn);
     const size_t need = moka_deterministic_ws_bytes(T, Cmax, r, G, M);
-    if (need == 0 || o->det_bytes < need)
+    if (need == 0 || o.det_bytes < need)
         return fail(MOKA_EINVAL, "%s: the deterministic-mode workspace (moka_opts.det_ws) is too small: %zu bytes needed (moka_deterministic_ws_bytes), %zu given",
-                    fn, need, o->det_bytes);
+                    fn, need, o.det_bytes);
     return MOKA_OK;
 }
 
@@ -4743,9 +4783,11 @@ static bool can_group(int r, int G) { return G > 1 && rank_pad(r) == 16; }
 
 int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_mod, float* const* part,
                         int T, int d_in, int r, int M, int G, float s_in, float dropout_p, const unsigned long long* seeds,
-                        int dtype, moka_stream_t stream) {
+                        int dtype, const moka_opts* opts, moka_stream_t stream) {
     int rc = check_common("moka_down_fwd", T, d_in, r, M, dtype);
     if (rc) return rc;
+    if ((rc = check_det_opts("moka_down_fwd", opts, false, T, d_in, r, G, M))) return rc;
+    DetScope det_scope(opts);                            // (seed_dev: the device-resident part of the dropout seed)
     if (G < 1 || G > MOKA_MAX_GROUP) return fail(MOKA_EINVAL, "moka_down_fwd: G=%d not in 1..%d", G, MOKA_MAX_GROUP);
     if (!x || !A || !tok_mod || !part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
     if (dropout_p != 0.f && !seeds) return fail(MOKA_EINVAL, "moka_down_fwd: dropout without seeds");
@@ -4808,10 +4850,10 @@ int moka_down_fwd_group(const void* x, const void* const* A, const uint8_t* tok_
 
 int moka_down_fwd(const void* x, const void* const* A, const uint8_t* tok_mod, float* part,
                   int T, int d_in, int r, int M, float s_in, float dropout_p, unsigned long long seed,
-                  int dtype, moka_stream_t stream) {
+                  int dtype, const moka_opts* opts, moka_stream_t stream) {
     if (!part) return fail(MOKA_EINVAL, "moka_down_fwd: null pointer");
     float* parts[1] = {part};
-    return moka_down_fwd_group(x, A, tok_mod, parts, T, d_in, r, M, 1, s_in, dropout_p, &seed, dtype, stream);
+    return moka_down_fwd_group(x, A, tok_mod, parts, T, d_in, r, M, 1, s_in, dropout_p, &seed, dtype, opts, stream);
 }
 
 #define GROUP_CHECK(fn) do { if (G < 1 || G > MOKA_MAX_GROUP) return fail(MOKA_EINVAL, fn ": G=%d not in 1..%d", G, MOKA_MAX_GROUP); } while (0)
@@ -5177,7 +5219,8 @@ int moka_up_bwd_db_batch(const void* const* gy, const void* const* hp_kmj, const
     if (n < 1 || n > MOKA_MAX_BATCH) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: n=%d not in 1..%d", n, MOKA_MAX_BATCH);
     if (!gy || !hp_kmj || !d_out || !tok_mod || !dB_acc) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: null pointer");
     if (dtype != MOKA_BF16) return fail(MOKA_EINVAL, "moka_up_bwd_db_batch: bf16 storage only (fp32 storage: one moka_up_bwd call per projection)");
-    if (opts && opts->det_ws) {
+    if (int drc = check_det_opts("moka_up_bwd_db_batch", opts, false, T, 32, r, 1, M)) return drc;
+    if (opts_view(opts).det_ws) {
         const float s1[MOKA_MAX_MOD] = {1.f, 1.f, 1.f};                      // (s_out is carried by the pack: unused by the dB half)
         for (int i = 0; i < n; ++i) {
             int rc = moka_up_bwd(gy[i], hp_kmj[i], nullptr, tok_mod, s1, nullptr, dB_acc[i], T, r, d_out[i], M, dtype, opts, stream);
@@ -5315,7 +5358,8 @@ int moka_down_bwd_da_batch(const void* const* dh_kmj, const void* const* x, cons
     if (!dh_kmj || !x || !d_in || !tok_mod || !dA_acc) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: null pointer");
     if (dropout_p != 0.f && !seeds) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: dropout without seeds");
     if (dtype != MOKA_BF16) return fail(MOKA_EINVAL, "moka_down_bwd_da_batch: bf16 storage only (fp32 storage: one moka_down_bwd call per projection)");
-    if (opts && opts->det_ws) {                          // deterministic mode: the per-run partial tiles are sized per call
+    if (int drc = check_det_opts("moka_down_bwd_da_batch", opts, false, T, 32, r, 1, M)) return drc;
+    if (opts_view(opts).det_ws) {                        // deterministic mode: the per-run partial tiles are sized per call
         for (int i = 0; i < n; ++i) {
             int rc = moka_down_bwd(nullptr, dh_kmj[i], x[i], nullptr, tok_mod, dA_acc + (size_t)i * M, nullptr,
                                    T, d_in[i], r, M, dropout_p, seeds ? seeds[i] : 0ull, dtype, opts, stream);
@@ -5323,6 +5367,7 @@ int moka_down_bwd_da_batch(const void* const* dh_kmj, const void* const* x, cons
         }
         return MOKA_OK;
     }
+    DetScope det_scope(opts);                            // (company, seed_dev)
     WgradBatch gb;
     memset(&gb, 0, sizeof(gb));
     for (int i = 0; i < n; ++i) {

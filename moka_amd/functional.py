@@ -8,7 +8,6 @@ with the explicit backward the reference leaves to autograd (SURVEY.md section 8
 from __future__ import annotations
 
 import ctypes
-import threading
 from ctypes import POINTER, byref, c_float, c_void_p
 from typing import List, Optional, Sequence, Tuple
 
@@ -18,49 +17,12 @@ from . import _lib
 from .routing import MokaRouting
 
 
-_LAUNCH = threading.local()          # .stream: launch-stream override of this thread (see _launch_on)
-
-
 def _launch_stream(device) -> "torch.cuda.Stream":
-    ov = getattr(_LAUNCH, "stream", None)
-    return ov if ov is not None else torch.cuda.current_stream(device)
+    return torch.cuda.current_stream(device)
 
 
 def _stream_ptr(device) -> c_void_p:
-    return c_void_p(_launch_stream(device).cuda_stream)
-
-
-class _launch_on:
-    """Enqueue the library's launches on `stream` WITHOUT making it torch's current stream: the tensors the wrappers allocate keep
-    coming from the current stream's pool, so a side-stream kernel writes into memory that is handed back to the allocator of the
-    stream that later joins it -- no record_stream, no cross-stream allocator traffic (with `torch.cuda.stream(side)` +
-    `record_stream` the whole decoder stack went from 344 to 509 ms per step)."""
-
-    def __init__(self, stream):
-        self.stream = stream
-
-    def __enter__(self):
-        self.prev = getattr(_LAUNCH, "stream", None)
-        _LAUNCH.stream = self.stream
-        if DEBUG_LAUNCH_ON:
-            self._freed = _blocks_freed(self.stream.device)
-
-    def __exit__(self, *exc):
-        _LAUNCH.stream = self.prev
-        if DEBUG_LAUNCH_ON and exc[0] is None and _blocks_freed(self.stream.device) != self._freed:
-            # what makes the scheme safe is that NOTHING allocated for these launches dies before the current stream has joined `stream`:
-            # a block freed in here returns to the current stream's pool and may be handed out again while the side kernel still uses it
-            raise _lib.MokaError("moka_amd: a device allocation was freed inside a _launch_on(side) region (a temporary in a wrapper?): the "
-                                 "side-stream launches are not ordered against its reuse on the current stream")
-        return False
-
-
-# debug hook (MOKA_DEBUG_LAUNCH_ON=1, or set by a test): every _launch_on region checks that the caching allocator freed no block inside it
-DEBUG_LAUNCH_ON = __import__("os").environ.get("MOKA_DEBUG_LAUNCH_ON") == "1"
-
-
-def _blocks_freed(device) -> int:
-    return int(torch.cuda.memory_stats(device).get("active.all.freed", 0))
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _require_device(t: torch.Tensor, name: str):
@@ -100,7 +62,7 @@ def _floats(vals: Sequence[float]):
 # 1:1 wrappers of the C entry points
 # --------------------------------------------------------------------------------------
 def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: int, s_in: float,
-             dropout_p: float = 0.0, seed: int = 0, dtype: int = 0) -> torch.Tensor:
+             dropout_p: float = 0.0, seed: int = 0, dtype: int = 0, seed_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x2 [T,d_in] bf16 -> part [ks,T,RP] fp32 (split-K partials of s_in * drop(x) A_mod^T)."""
     lib = _lib.load()
     T, d_in = x2.shape
@@ -109,7 +71,7 @@ def down_fwd(x2: torch.Tensor, A: Sequence[torch.Tensor], rt: MokaRouting, r: in
     part = torch.empty((ks, T, RP), dtype=torch.float32, device=x2.device)
     _lib.check(lib.moka_down_fwd(x2.data_ptr(), _ptrs(A), rt.tok_mod.data_ptr(), part.data_ptr(),
                                  T, d_in, r, len(A), float(s_in), float(dropout_p), int(seed), dtype,
-                                 _stream_ptr(x2.device)), "moka_down_fwd")
+                                 _det_opts(x2.device, T, d_in, r, 1, len(A), seed_dev, want_det=False), _stream_ptr(x2.device)), "moka_down_fwd")
     return part
 
 
@@ -226,7 +188,7 @@ def cross_bwd(g_part: torch.Tensor, h: torch.Tensor, rt: MokaRouting, r: int, s_
 
 def down_bwd_(bst: BwdState, x2: torch.Tensor, AT: Optional[torch.Tensor], rt: MokaRouting, r: int,
               dA_acc: Optional[Sequence[torch.Tensor]], dx2: Optional[torch.Tensor],
-              dropout_p: float = 0.0, seed: int = 0, dtype: int = 0):
+              dropout_p: float = 0.0, seed: int = 0, dtype: int = 0, seed_dev: Optional[torch.Tensor] = None):
     """dA_acc[m] [r,d_in] fp32 += ; dx2 [T,d_in] bf16 += (either may be None)."""
     lib = _lib.load()
     T, d_in = x2.shape
@@ -234,7 +196,7 @@ def down_bwd_(bst: BwdState, x2: torch.Tensor, AT: Optional[torch.Tensor], rt: M
                                  None if AT is None else AT.data_ptr(), rt.tok_mod.data_ptr(),
                                  None if dA_acc is None else _ptrs(dA_acc), None if dx2 is None else dx2.data_ptr(),
                                  T, d_in, r, rt.M, float(dropout_p), int(seed), dtype,
-                                 _det_opts(x2.device, T, d_in, r, 1, rt.M) if dA_acc is not None else None,
+                                 _det_opts(x2.device, T, d_in, r, 1, rt.M, seed_dev, want_det=dA_acc is not None),
                                  _stream_ptr(x2.device)), "moka_down_bwd")
 
 
@@ -267,7 +229,7 @@ def _optptrs(tensors: Sequence[Optional[torch.Tensor]]):
 
 
 def down_fwd_group(x2: torch.Tensor, A: Sequence[Sequence[torch.Tensor]], rt: MokaRouting, r: int, s_in: float,
-                   dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+                   dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None, seed_dev: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """One read of x2 [T,d_in] for the G down-projections A[g][m]; returns the G split-K partial buffers."""
     lib = _lib.load()
     T, d_in = x2.shape
@@ -279,7 +241,7 @@ def down_fwd_group(x2: torch.Tensor, A: Sequence[Sequence[torch.Tensor]], rt: Mo
     _lib.check(lib.moka_down_fwd_group(x2.data_ptr(), _ptrs(flat), rt.tok_mod.data_ptr(), _ptrs(parts),
                                        T, d_in, r, M, G, float(s_in), float(dropout_p),
                                        _u64s(seeds if seeds is not None else [0] * G), _lib.MOKA_BF16,
-                                       _stream_ptr(x2.device)), "moka_down_fwd_group")
+                                       _det_opts(x2.device, T, d_in, r, G, M, seed_dev, want_det=False), _stream_ptr(x2.device)), "moka_down_fwd_group")
     return parts
 
 
@@ -397,7 +359,7 @@ def cross_bwd_group(g_parts: Sequence[torch.Tensor], hs: Sequence[torch.Tensor],
 
 def down_bwd_group_(bsts: Sequence[BwdState], x2: torch.Tensor, ATs: Optional[Sequence[torch.Tensor]], rt: MokaRouting, r: int,
                     dA_accs: Optional[Sequence[Sequence[torch.Tensor]]], dx2: Optional[torch.Tensor],
-                    dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None):
+                    dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None, seed_dev: Optional[torch.Tensor] = None):
     """dA_accs[g][m] += (one read of x2 for all G); dx2 += sum_g dh_g A_g (one read-modify-write)."""
     lib = _lib.load()
     T, d_in = x2.shape
@@ -407,12 +369,13 @@ def down_bwd_group_(bsts: Sequence[BwdState], x2: torch.Tensor, ATs: Optional[Se
                                        None if dA_accs is None else _ptrs([a for Ag in dA_accs for a in Ag]),
                                        None if dx2 is None else dx2.data_ptr(), T, d_in, r, rt.M, G, float(dropout_p),
                                        _u64s(seeds if seeds is not None else [0] * G), _lib.MOKA_BF16,
-                                       _det_opts(x2.device, T, d_in, r, G, rt.M) if dA_accs is not None else None, _stream_ptr(x2.device)),
+                                       _det_opts(x2.device, T, d_in, r, G, rt.M, seed_dev, want_det=dA_accs is not None), _stream_ptr(x2.device)),
                "moka_down_bwd_group")
 
 
 def down_bwd_da_batch_(dh_kmjs: Sequence[torch.Tensor], xs: Sequence[torch.Tensor], rt: MokaRouting, r: int,
-                       dA_accs: Sequence[Sequence[torch.Tensor]], dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None):
+                       dA_accs: Sequence[Sequence[torch.Tensor]], dropout_p: float = 0.0, seeds: Optional[Sequence[int]] = None,
+                       seed_dev: Optional[torch.Tensor] = None):
     """dA_accs[i][m] += for n independent projections of one token set (their own x [T, d_in_i] and operand pack) in ONE launch: what a
     trainer defers per decoder layer (moka_down_bwd_da_batch; with the deterministic mode on: one launch per projection)."""
     lib = _lib.load()
@@ -421,7 +384,7 @@ def down_bwd_da_batch_(dh_kmjs: Sequence[torch.Tensor], xs: Sequence[torch.Tenso
     _lib.check(lib.moka_down_bwd_da_batch(_ptrs(dh_kmjs), _ptrs(xs), (ctypes.c_int * n)(*d_ins), rt.tok_mod.data_ptr(),
                                           _ptrs([a for Ai in dA_accs for a in Ai]), n, T, r, rt.M, float(dropout_p),
                                           _u64s(seeds if seeds is not None else [0] * n), _lib.MOKA_BF16,
-                                          _det_opts(xs[0].device, T, max(d_ins), r, 1, rt.M), _stream_ptr(xs[0].device)),
+                                          _det_opts(xs[0].device, T, max(d_ins), r, 1, rt.M, seed_dev), _stream_ptr(xs[0].device)),
                "moka_down_bwd_da_batch")
 
 
@@ -455,7 +418,6 @@ def _token_scale(rt: MokaRouting, s_out: Sequence[float], device) -> torch.Tenso
 # backward call as `moka_opts`).  One workspace per (device, stream): calls that run concurrently on two streams never share one.
 _DET_ON = {}            # device -> True
 _DET_WS = {}            # (device, stream handle) -> uint8 workspace tensor
-_DET_RETIRED = []       # outgrown workspaces kept until set_deterministic(False)
 
 
 def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G: int = 3, M: int = 3, device=None) -> None:
@@ -471,7 +433,6 @@ def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G:
         _DET_ON.pop(dev, None)
         for k in [k for k in _DET_WS if k[0] == dev]:
             del _DET_WS[k]
-        _DET_RETIRED[:] = [w_ for w_ in _DET_RETIRED if w_.device != dev]
         return
     _DET_ON[dev] = True
     if T and C_max:
@@ -479,24 +440,33 @@ def set_deterministic(enabled: bool, T: int = 0, C_max: int = 0, r: int = 16, G:
             raise ValueError("set_deterministic: bad T / C_max / r / G / M")
 
 
-def _det_opts(device, T: int, C_max: int, r: int, G: int, M: int):
-    """moka_opts of one backward call: None (atomics) unless set_deterministic is on for the device."""
+def _det_opts(device, T: int, C_max: int, r: int, G: int, M: int, seed_dev: Optional[torch.Tensor] = None, want_det: bool = True):
+    """moka_opts of one call: the deterministic-mode workspace (set_deterministic on for the device and the call produces weight gradients)
+    and / or the device-resident part of the dropout seed (``seed_dev``: an int64 tensor of one element); None when neither applies."""
+    sd = None if seed_dev is None else seed_dev.data_ptr()
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    if not _DET_ON.get(dev):
-        return None
+    if not want_det or not _DET_ON.get(dev):
+        return None if sd is None else ctypes.byref(_lib.MokaOpts(seed_dev=sd))
     n = int(_lib.load().moka_deterministic_ws_bytes(int(T), int(C_max), int(r), int(G), int(M)))
     if n == 0:
-        return None
+        return None if sd is None else ctypes.byref(_lib.MokaOpts(seed_dev=sd))
     key = (dev, _launch_stream(dev).cuda_stream)
     ws = _DET_WS.get(key)
     if ws is None or ws.numel() < n:
-        if ws is not None and getattr(_LAUNCH, "stream", None) is not None:
-            _DET_RETIRED.append(ws)                  # (outgrown inside a _launch_on region: not handed back to the current stream's pool in there)
         ws = torch.empty(n, dtype=torch.uint8, device=dev)
         _DET_WS[key] = ws
-    return ctypes.byref(_lib.MokaOpts(ws.data_ptr(), ws.numel()))
+    return ctypes.byref(_lib.MokaOpts(ws.data_ptr(), ws.numel(), seed_dev=sd))
+
+
+def effective_seed(seed: int, epoch: int) -> int:
+    """The seed whose mask a call with (seed, *seed_dev == epoch) uses: 32-bit halves, low ^ low and high + high (include/moka_hip.h,
+    moka_opts.seed_dev) -- what a checker hands to ``dropout_mask`` to replay a captured step's masks."""
+    seed, epoch = int(seed) & (2 ** 64 - 1), int(epoch) & (2 ** 64 - 1)
+    lo = (seed ^ epoch) & 0xffffffff
+    hi = ((seed >> 32) + (epoch >> 32)) & 0xffffffff
+    return (hi << 32) | lo
 
 
 def draw_seed() -> int:
@@ -546,42 +516,16 @@ def _split_like(flat: torch.Tensor, shapes: Sequence[Tuple[int, int]]) -> List[t
 # (tests/test_gpu_fused.py); a module-level switch for A/B runs, not a tuning knob.
 FUSE_FORWARD = True
 
-# Overlap of the adapter's x-only / gy-only halves with the frozen base GEMM of the same projection (attach(overlap_base=True),
-# set_overlap_base): the down-projection (+ weight shadows) runs on a side stream beside F.linear and is joined in front of the
-# up-projection; in the backward the pass over gy and the rank-space backward run beside gy.W and are joined in front of the dx pass.
-# Same kernels, same bits; what it buys is measured per configuration (bench.py --e2e --overlap-base) -- off by default.
-OVERLAP_BASE = False
-_SIDE_STREAMS = {}
-
-
-def set_overlap_base(enabled: bool) -> None:
-    global OVERLAP_BASE
-    OVERLAP_BASE = bool(enabled)
-
-
-def _side_stream(device) -> "torch.cuda.Stream":
-    dev = torch.device(device)
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
-    st = _SIDE_STREAMS.get(dev)
-    if st is None:
-        # (high priority: measured on the 7B stack, 4 x 2048 tokens: 348.6 ms sequential, 350.3 ms with the side stream at high priority, 468 ms at the GEMM's own priority -- interleaved workgroups cost the hipBLASLt kernels far more than the overlap hides; MOKA_SIDE_PRIORITY for A/B runs)
-        import os
-        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MOKA_SIDE_PRIORITY", "-1")))
-    return st
-
-
-
 # --------------------------------------------------------------------------------------
 # autograd node of one adapted projection
 # --------------------------------------------------------------------------------------
 class AdapterSpec:
     """Static description of one adapted projection (what varies between AVT and VT)."""
 
-    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed", "sinks", "defer")
+    __slots__ = ("r", "s_in", "s_out", "w", "inv_sqrt_dk", "dropout_p", "seed", "sinks", "defer", "shadows", "seed_dev")
 
     def __init__(self, r: int, s_in: float, s_out: Sequence[float], w: float, inv_sqrt_dk: float,
-                 dropout_p: float = 0.0, seed: Optional[int] = None, sinks=None, defer=None):
+                 dropout_p: float = 0.0, seed: Optional[int] = None, sinks=None, defer=None, shadows=None, seed_dev=None):
         self.r, self.s_in, self.s_out, self.w, self.inv_sqrt_dk = int(r), float(s_in), [float(s) for s in s_out], float(w), float(inv_sqrt_dk)
         self.dropout_p = float(dropout_p)
         self.seed = (draw_seed() if seed is None else int(seed)) if self.dropout_p > 0.0 else 0
@@ -593,6 +537,14 @@ class AdapterSpec:
         # only: the backward then runs the dx half of moka_down_bwd on the dependency chain and hands the dA_m half to `defer`,
         # which launches it later on a side stream (beside the next layer's chain), before the gradients are used.
         self.defer = defer
+        # shadows = (BwT [RP, d_out], AT [M, d_in, RP]) bf16: PERSISTENT weight shadows kept by whoever owns the weights
+        # (moka_amd.parallel.attach rewrites them behind every optimizer update, one batched launch per gradient bucket).  The forward
+        # then launches no moka_weight_shadows and the backward reads these; None: the node computes them per call.
+        self.shadows = shadows
+        # seed_dev: int64 device tensor of one element the dropout kernels fold into `seed` when they start (moka_opts.seed_dev).  0 in
+        # live training (the seed drawn per call is the whole seed); a captured step (schedule.GraphedTrainStep) rewrites it before every
+        # replay, so replays of the frozen launch arguments still draw fresh masks.  None: no device part.
+        self.seed_dev = seed_dev if self.dropout_p > 0.0 else None
 
 
 class MokaLinearFn(torch.autograd.Function):
@@ -621,23 +573,12 @@ class MokaLinearFn(torch.autograd.Function):
         Bw_c = Bw if Bw.is_contiguous() else Bw.contiguous()
         fused = (dt == _lib.MOKA_BF16 and FUSE_FORWARD and
                  _lib.up_fwd_fused_pays(x2.shape[0], _lib.ksplit(x2.shape[0], d_in, spec.r), [Bw.shape[0]], spec.r, dt))
-        overlap = OVERLAP_BASE and fused and W is not None
-        shadows = None
-        if overlap:
-            # the x-only half of the adapter beside the base GEMM (it is HBM-bound, the GEMM compute-bound)
-            cur, side = torch.cuda.current_stream(x2.device), _side_stream(x2.device)
-            side.wait_stream(cur)
-            with _launch_on(side):
-                part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
-                shadows = weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
+        kept = spec.shadows if dt == _lib.MOKA_BF16 else None          # persistent (BwT, AT) of the weights' owner
         if W is not None:
             y = torch.nn.functional.linear(x2, W, bias)               # frozen base, stock PyTorch-ROCm
         else:                                                         # adapter term alone (per-sample adapter_names: several adapters add to one base output)
             y = torch.zeros((x2.shape[0], Bw.shape[0]), dtype=x2.dtype, device=x2.device)
-        if overlap:
-            cur.wait_stream(side)
-        else:
-            part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt)
+        part = down_fwd(x2, A, rt, spec.r, spec.s_in, spec.dropout_p, spec.seed, dtype=dt, seed_dev=spec.seed_dev)
         if dt == _lib.MOKA_F32:
             # fp32 storage: the rank-space rows themselves are the operands (no bf16 packs, no weight shadows)
             st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, want_hp=True)
@@ -648,10 +589,14 @@ class MokaLinearFn(torch.autograd.Function):
             # two launches on the dependency chain: the up-projection computes the interaction itself from the slices and writes what
             # the backward reads from the rank space (h, hp_kmj); the weight shadows are functions of the weights alone
             st = up_fwd_fused_(y, part, Bw_c, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, want_state=True)
-            st.BwT, st.AT = shadows if shadows is not None else weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
+            st.BwT, st.AT = kept if kept is not None else weight_shadows(Bw_c, A if ctx.needs_input_grad[0] else None, spec.r)
             ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
         else:
-            st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
+            if kept is not None:
+                st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk)
+                st.BwT, st.AT = kept
+            else:
+                st = cross_fwd(part, rt, spec.r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw_c, A=A if ctx.needs_input_grad[0] else None)
             up_fwd_(y, st.hp_tok, Bw_c, rt, spec.r)
             ctx.save_for_backward(x2, W, Bw_c, st.h, st.hp_kmj, st.BwT, st.AT, *A)
         ctx.rt, ctx.spec, ctx.x_shape, ctx.has_bias, ctx.dt = rt, spec, x.shape, bias is not None, dt
@@ -684,17 +629,8 @@ class MokaLinearFn(torch.autograd.Function):
         dt = ctx.dt
         # dB is needed by the optimizer only: where it is a pass of its own over gy anyway (r > 32), it leaves the dependency chain like dA_m
         split_dB = spec.sinks is not None and spec.defer is not None and dB_acc is not None and _lib.up_bwd_passes(r, dt) == 2
-        overlap = OVERLAP_BASE and dt == _lib.MOKA_BF16 and need_x and W is not None
         bst = None
-        if overlap:
-            # the gy-only half of the adapter (pass over gy, rank-space backward) beside the base input-gradient GEMM
-            cur, side = torch.cuda.current_stream(gy2.device), _side_stream(gy2.device)
-            side.wait_stream(cur)
-            with _launch_on(side):
-                g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
-                bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
-        else:
-            g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
+        g_part = up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, None if split_dB else dB_acc, dtype=dt)
         if split_dB:
             fn_db = lambda: up_bwd(gy2, hp_kmj, BwT, rt, r, spec.s_out, dB_acc, dtype=dt, want_g=False)   # noqa: E731
             if dt == _lib.MOKA_BF16 and getattr(spec.defer, "accepts_da", False):
@@ -704,12 +640,8 @@ class MokaLinearFn(torch.autograd.Function):
         dx2 = None
         if need_x:                                                   # frozen base: dx only, never dW
             dx2 = torch.matmul(gy2, W) if W is not None else torch.zeros_like(x2)
-        if overlap:
-            cur.wait_stream(side)
         if need_A or need_x:
-            if bst is not None:
-                pass
-            elif dt == _lib.MOKA_F32:
+            if dt == _lib.MOKA_F32:
                 bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk, want_dh=True)
                 bst.dh_tok, bst.dh_kmj = bst.dh * spec.s_in, None    # the fp32 rows, scaled, stand in for the packs
                 AT = torch.stack(list(A)).contiguous()
@@ -717,15 +649,15 @@ class MokaLinearFn(torch.autograd.Function):
                 bst = cross_bwd(g_part, h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
             if spec.sinks is not None and spec.defer is not None and dA_acc is not None:
                 if dx2 is not None:
-                    down_bwd_(bst, x2, AT, rt, r, None, dx2, spec.dropout_p, spec.seed, dtype=dt)
-                fn = lambda bst=bst, x2=x2, AT=AT, dA_acc=dA_acc: down_bwd_(bst, x2, AT, rt, r, dA_acc, None, spec.dropout_p, spec.seed, dtype=dt)   # noqa: E731
+                    down_bwd_(bst, x2, AT, rt, r, None, dx2, spec.dropout_p, spec.seed, dtype=dt, seed_dev=spec.seed_dev)
+                fn = lambda bst=bst, x2=x2, AT=AT, dA_acc=dA_acc: down_bwd_(bst, x2, AT, rt, r, dA_acc, None, spec.dropout_p, spec.seed, dtype=dt, seed_dev=spec.seed_dev)   # noqa: E731
                 if dt == _lib.MOKA_BF16 and getattr(spec.defer, "accepts_da", False):
                     # (described as well: attach() sends a decoder layer's dA_m halves out as ONE launch, moka_down_bwd_da_batch)
-                    spec.defer(fn, [x2, bst.dh_tok, bst.dh_kmj, AT], da=((rt, r, float(spec.dropout_p)), [(bst.dh_kmj, x2, list(dA_acc), spec.seed or 0)]))
+                    spec.defer(fn, [x2, bst.dh_tok, bst.dh_kmj, AT], da=((rt, r, float(spec.dropout_p), spec.seed_dev), [(bst.dh_kmj, x2, list(dA_acc), spec.seed or 0)]))
                 else:
                     spec.defer(fn, [x2, bst.dh_tok, bst.dh_kmj, AT])
             else:
-                down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed, dtype=dt)
+                down_bwd_(bst, x2, AT, rt, r, dA_acc, dx2, spec.dropout_p, spec.seed, dtype=dt, seed_dev=spec.seed_dev)
         gB, gA = None, [None] * len(A)
         if flat is not None:
             cast = _split_like(flat.to(Bw.dtype), shapes)             # one cast kernel for all weight gradients
@@ -776,7 +708,7 @@ class MokaLinearGroupFn(torch.autograd.Function):
                 _require_bf16(a, "lora_A")
         sp = specs[0]
         for o in specs[1:]:
-            if (o.r, o.s_in, o.s_out, o.w, o.inv_sqrt_dk, o.dropout_p) != (sp.r, sp.s_in, sp.s_out, sp.w, sp.inv_sqrt_dk, sp.dropout_p):
+            if (o.r, o.s_in, o.s_out, o.w, o.inv_sqrt_dk, o.dropout_p) != (sp.r, sp.s_in, sp.s_out, sp.w, sp.inv_sqrt_dk, sp.dropout_p) or o.seed_dev is not sp.seed_dev:
                 raise ValueError("moka_amd: the projections of one group must share r, scaling, blc/attn weight and dropout")
         if len(sp.s_out) != rt.M or M != rt.M:
             raise ValueError(f"routing describes {rt.M} modalities but {M} adapters / {len(sp.s_out)} scales were given")
@@ -791,26 +723,22 @@ class MokaLinearGroupFn(torch.autograd.Function):
         seeds = [s_.seed for s_ in specs]
         need_x = ctx.needs_input_grad[0]
         fused = FUSE_FORWARD and _lib.up_fwd_fused_pays(x2.shape[0], _lib.ksplit(x2.shape[0], d_in, sp.r, len(Bws)), [b.shape[0] for b in Bws], sp.r)
-        overlap = OVERLAP_BASE and fused
-        shadows = None
-        if overlap:                                                  # (see MokaLinearFn.forward)
-            cur, side = torch.cuda.current_stream(x2.device), _side_stream(x2.device)
-            side.wait_stream(cur)
-            with _launch_on(side):
-                parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
-                shadows = weight_shadows_group(Bws, As if need_x else None, sp.r)
+        kept = [s_.shadows for s_ in specs] if all(s_.shadows is not None for s_ in specs) else None     # persistent (BwT, AT) per projection
         ys = [torch.nn.functional.linear(x2, Ws[g], biases[g]) for g in range(G)]      # frozen base, stock PyTorch-ROCm
-        if overlap:
-            cur.wait_stream(side)
-        else:
-            parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds)
+        parts = down_fwd_group(x2, As, rt, sp.r, sp.s_in, sp.dropout_p, seeds, seed_dev=sp.seed_dev)
         if fused:
             sts = up_fwd_fused_group_(ys, parts, Bws, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, want_state=True)     # (see MokaLinearFn.forward)
-            BwTs, ATs = shadows if shadows is not None else weight_shadows_group(Bws, As if need_x else None, sp.r)
+            if kept is not None:
+                BwTs, ATs = [k[0] for k in kept], [k[1] for k in kept]
+            else:
+                BwTs, ATs = weight_shadows_group(Bws, As if need_x else None, sp.r)
             for g in range(G):
                 sts[g].BwT, sts[g].AT = BwTs[g], (ATs[g] if ATs is not None else None)
         else:
             sts = cross_fwd_group(parts, rt, sp.r, sp.s_out, sp.w, sp.inv_sqrt_dk, Bws, As if need_x else None)
+            if kept is not None:
+                for g in range(G):
+                    sts[g].BwT, sts[g].AT = kept[g]
             up_fwd_group_(ys, [st.hp_tok for st in sts], Bws, rt, sp.r)
         saved = [x2]
         for g in range(G):
@@ -864,16 +792,8 @@ class MokaLinearGroupFn(torch.autograd.Function):
             flat, acc = _grad_accumulators(shapes, dev) if shapes else (None, [])
         dB_accs = acc[:G] if need_B else None
         split_dB = use_sinks and sp.defer is not None and dB_accs is not None and _lib.up_bwd_passes(r, _lib.MOKA_BF16) == 2
-        overlap = OVERLAP_BASE and need_x
         bsts = None
-        if overlap:                                                  # (see MokaLinearFn.backward)
-            cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            side.wait_stream(cur)
-            with _launch_on(side):
-                g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
-                bsts = cross_bwd_group(g_parts, hs, rt, r, sp.s_in, sp.w, sp.inv_sqrt_dk)
-        else:
-            g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
+        g_parts = up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, None if split_dB else dB_accs)
         if split_dB:                                                 # (see MokaLinearFn.backward)
             fn_db = lambda: up_bwd_group(gy2, hp_kmjs, BwTs, rt, r, sp.s_out, dB_accs, want_g=False)   # noqa: E731
             if getattr(sp.defer, "accepts_da", False):
@@ -885,8 +805,6 @@ class MokaLinearGroupFn(torch.autograd.Function):
             dx2 = torch.matmul(gy2[0], Ws[0])                        # frozen base: dx only, never dW
             for g in range(1, G):
                 dx2.addmm_(gy2[g], Ws[g])
-        if overlap:
-            cur.wait_stream(side)
         dA_accs = None
         if need_A or need_x:
             if bsts is None:
@@ -897,15 +815,15 @@ class MokaLinearGroupFn(torch.autograd.Function):
             seeds_ = [s_.seed for s_ in specs]
             if use_sinks and sp.defer is not None and dA_accs is not None:
                 if dx2 is not None:
-                    down_bwd_group_(bsts, x2, ATs, rt, r, None, dx2, sp.dropout_p, seeds_)
-                fn = lambda: down_bwd_group_(bsts, x2, None, rt, r, dA_accs, None, sp.dropout_p, seeds_)   # noqa: E731
+                    down_bwd_group_(bsts, x2, ATs, rt, r, None, dx2, sp.dropout_p, seeds_, seed_dev=sp.seed_dev)
+                fn = lambda: down_bwd_group_(bsts, x2, None, rt, r, dA_accs, None, sp.dropout_p, seeds_, seed_dev=sp.seed_dev)   # noqa: E731
                 keep_ = [x2] + [b.dh_tok for b in bsts] + [b.dh_kmj for b in bsts]
                 if getattr(sp.defer, "accepts_da", False):
-                    sp.defer(fn, keep_, da=((rt, r, float(sp.dropout_p)), [(bsts[g].dh_kmj, x2, list(dA_accs[g]), seeds_[g] or 0) for g in range(G)]))
+                    sp.defer(fn, keep_, da=((rt, r, float(sp.dropout_p), sp.seed_dev), [(bsts[g].dh_kmj, x2, list(dA_accs[g]), seeds_[g] or 0) for g in range(G)]))
                 else:
                     sp.defer(fn, keep_)
             else:
-                down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, seeds_)
+                down_bwd_group_(bsts, x2, ATs if need_x else None, rt, r, dA_accs, dx2, sp.dropout_p, seeds_, seed_dev=sp.seed_dev)
         cast = _split_like(flat.to(x2.dtype), shapes) if flat is not None else []      # one cast kernel for all weight gradients
         grads = []
         for g in range(G):

@@ -229,6 +229,8 @@ class Linear(nn.Module, LoraLayer):
     # lora_A['image']]} of the flat data-parallel gradient buffer (None: ordinary autograd gradients)
     _moka_sinks = None
     _moka_defer = None          # attach(defer_dA=True): callable that takes the dA_m half of the backward off the dependency chain
+    _moka_seed_dev = None       # attach(): the device-resident part of the dropout seed (0 live; a captured step rewrites it per replay)
+    _moka_shadows = None        # attach(): persistent (BwT, AT) weight shadows of the masked (text + image) plan, rewritten behind every optimizer update
 
     def _sinks(self, n_adapters: int):
         sk = self._moka_sinks
@@ -254,7 +256,7 @@ class Linear(nn.Module, LoraLayer):
             A_i = self.lora_A["image"].weight
             rt = GLOBAL_ROUTING_CACHE.get("vt", [my_text_mask, my_image_mask, question_mask])
             spec = AdapterSpec(r, 1.0, [self.scaling["text"], self.scaling["image"]], self.attn_weight, 1.0 / math.sqrt(r), dropout_p=p,
-                               sinks=self._sinks(2), defer=self._moka_defer)
+                               sinks=self._sinks(2), defer=self._moka_defer, shadows=self._moka_shadows, seed_dev=self._moka_seed_dev)
             return (W, base.bias, B_t, [A_t, A_i], rt, spec)
         # masks None (cached decode steps): plain LoRA with the text adapter (layer.py:672-678)
         B_, S_ = (x.shape[0], x.shape[1]) if x.dim() == 3 else (1, x.shape[0])

@@ -402,17 +402,42 @@ class AdapterDataParallel:
         self._opt_begun = False
         self._opt_done: List = []                    # [lo, hi) ranges of the flat buffers already updated in this step
         self._bwd_active = False                     # a backward pass has reported work since the last finish() / step()
-        self._warned_no_clip = False
+        self.unclipped_steps = 0                     # step(max_grad_norm=...) calls that could not clip (optimizer_in_backward)
         self._pass_running = False                   # ... and is still running (``_mark_pass``: cleared by an engine callback at its end)
+        # persistent weight shadows (attach(persistent_shadows=True)): (group index, module, lora_B, [lora_A_m], BwT, AT) per adapted projection
+        self._shadowed: list = []
+        self._group_bounds: list = []                # [lo, hi) of every parameter group (decoder layer) in the flat buffers
+        self._graph = None                           # schedule.GraphedTrainStep while it captures: hub stream, chain count, per-chain reports
+        # the device-resident part of every adapted projection's dropout seed (moka_opts.seed_dev): 0 in live training -- the seed drawn
+        # per call is the whole seed -- rewritten before every replay of a captured step, whose launch arguments are frozen
+        self.seed_epoch = torch.zeros(1, dtype=torch.int64, device=bucket.flat.device) if bucket.flat.is_cuda else None
 
     # ---------------------------------------------------------------- backward side
     def _opt_slice(self, lo: int, hi: int) -> None:
-        """AdamW on parameters [lo, hi) on the CURRENT stream (coefficients of the step uploaded on that stream the first time)."""
+        """AdamW on parameters [lo, hi) on the CURRENT stream (coefficients of the step uploaded on that stream the first time), then the
+        weight shadows of the projections whose parameters just changed."""
         if not self._opt_begun:
             self.optimizer.begin_step()              # (hyper-parameters pulled now: MokaFlatOptimizer's param_groups, a scheduler's lr)
             self._opt_begun = True
         self.optimizer.step_range(lo, hi, grad_scale=1.0 / self.bucket.world, zero_grad=True)
         self._opt_done.append((lo, hi))
+        self.refresh_shadows(lo, hi)
+
+    def refresh_shadows(self, lo: Optional[int] = None, hi: Optional[int] = None) -> None:
+        """Rewrite the persistent weight shadows (BwT, AT) of the adapted projections whose parameters lie in [lo, hi) of the flat buffers
+        (default: all) from the current working copies, on the current stream: one ``moka_weight_shadows_batch`` launch per 16 projections."""
+        if not self._shadowed:
+            return
+        from . import functional as F
+        pick = [it for it in self._shadowed
+                if lo is None or (self._group_bounds[it[0]][0] >= lo and self._group_bounds[it[0]][1] <= hi)]
+        by_shape = {}
+        for it in pick:
+            by_shape.setdefault((it[2].shape[1], len(it[3])), []).append(it)
+        with torch.no_grad():
+            for (r, _m), items in by_shape.items():
+                F.weight_shadows_batch_([it[2].detach() for it in items], [[a.detach() for a in it[3]] for it in items], int(r),
+                                        [it[4] for it in items], [it[5] for it in items])
 
     def _defer(self, fn, tensors, da=None, db=None) -> None:
         """fn: the launch as a closure; da / db = (key, items): the same work described as problems of moka_down_bwd_da_batch (key =
@@ -433,48 +458,57 @@ class AdapterDataParallel:
         from . import functional as F
         from . import _lib
         dev = self.bucket.flat.device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+        if self._graph is not None:
+            # a step being captured (schedule.GraphedTrainStep): everything off the chains goes to the capture's ORIGIN stream (the hub) --
+            # a dependency between two forked streams crashes hipStreamEndCapture, and nothing on a chain ever waits for the hub
+            side = self._graph.hub
+        else:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
         main = torch.cuda.current_stream(dev)
-        self._side.wait_stream(main)
+        side.wait_stream(main)
 
         def key_of(desc):
-            return (desc[0], id(desc[1][0][0])) + tuple(desc[1][0][1:])
+            return (desc[0], id(desc[1][0][0])) + tuple(v if not isinstance(v, torch.Tensor) else id(v) for v in desc[1][0][1:])
 
         groups = {}
         for fn, tensors, desc in self._deferred:
             if desc is not None:
                 groups.setdefault(key_of(desc), []).append(desc[1])
         batched = {k for k, v in groups.items() if sum(len(d[1]) for d in v) > 1}
-        with torch.cuda.stream(self._side):
+        with torch.cuda.stream(side):
             for fn, tensors, desc in self._deferred:
                 if desc is None or key_of(desc) not in batched:
                     fn()
                 for t in tensors:
-                    t.record_stream(self._side)      # (the caching allocator must not hand the block out before the side kernel has read it)
+                    t.record_stream(side)            # (the caching allocator must not hand the block out before the side kernel has read it)
             for k in batched:
                 items = [it for d in groups[k] for it in d[1]]
                 head = groups[k][0][0]
                 for i in range(0, len(items), _lib.MOKA_MAX_BATCH):
                     part = items[i:i + _lib.MOKA_MAX_BATCH]
                     if k[0] == "da":
-                        rt, r, p = head
-                        F.down_bwd_da_batch_([it[0] for it in part], [it[1] for it in part], rt, r, [it[2] for it in part], p, [it[3] for it in part])
+                        rt, r, p, sdev = head
+                        F.down_bwd_da_batch_([it[0] for it in part], [it[1] for it in part], rt, r, [it[2] for it in part], p, [it[3] for it in part], seed_dev=sdev)
                     else:
                         rt, r = head
                         F.up_bwd_db_batch_([it[0] for it in part], [it[1] for it in part], rt, r, [it[2] for it in part])
         self._deferred.clear()
-        self._side_busy = True
+        self._side_busy = self._graph is None
 
     def _join_deferred(self) -> None:
         self._flush_deferred()
-        if self._side_busy:
+        if self._side_busy and self._graph is None:
             torch.cuda.current_stream(self.bucket.flat.device).wait_stream(self._side)
             self._side_busy = False
 
     def _layer_done(self, l: int) -> None:
         _mark_pass(self)
         self._flush_deferred()                       # the layer's dA_m launches leave for the side stream now
+        if self._graph is not None:
+            self._graph.layer_done(self, l)          # (capture: the bucket's AdamW slice goes to the hub once EVERY chain has reported the layer)
+            return
         if not self.sync or l in self._done:
             return
         self._done.add(l)
@@ -495,7 +529,7 @@ class AdapterDataParallel:
         way (or already summed) and no step() / finish() in between means gradient accumulation without ``no_sync``: the next
         backward's kernels would add into memory an in-place all-reduce is working on, and those layers would not be shipped
         again.  DDP is merely slower in that situation; here it would be silently wrong, so it is an error."""
-        if self.sync and (self._done or self.bucket._pending) and torch.is_grad_enabled() and not _in_backward(self):
+        if self._graph is None and self.sync and (self._done or self.bucket._pending) and torch.is_grad_enabled() and not _in_backward(self):
             raise RuntimeError("moka_amd.parallel: a new forward started while gradient buckets of the previous backward are in flight. "
                                "Accumulate micro-batches under `with dp.no_sync():` (sync only on the last one), or call dp.step() / "
                                "dp.finish() after every backward.")
@@ -542,14 +576,15 @@ class AdapterDataParallel:
                 pos = max(pos, hi)
             self._opt_done.clear()
             self._opt_begun = False
-            if max_grad_norm is not None and max_grad_norm > 0 and not self._warned_no_clip:
+            if max_grad_norm is not None and max_grad_norm > 0:
                 # (the buckets of this step were updated inside the backward, before a global norm existed: nothing to refuse any more at this
-                #  point, and a step that mutates the parameters and then throws leaves the caller with neither; MokaFlatOptimizer refuses
-                #  the combination up front, a direct caller is told once)
+                #  point, and a step that mutates the parameters and then throws leaves the caller with neither.  MokaFlatOptimizer refuses
+                #  the combination up front; a direct caller is told on EVERY call -- a single warning is lost in a training log -- and the
+                #  count travels with state_dict())
                 import warnings
+                self.unclipped_steps += 1
                 warnings.warn("attach(optimizer_in_backward=True) updates a bucket before the global gradient norm exists: step(max_grad_norm=%g) "
-                              "does NOT clip in this mode" % max_grad_norm, RuntimeWarning, stacklevel=2)
-                self._warned_no_clip = True
+                              "does NOT clip in this mode (%d step(s) so far)" % (max_grad_norm, self.unclipped_steps), RuntimeWarning, stacklevel=2)
             return None
         self.finish(average=False)
         scale = 1.0 / self.bucket.world
@@ -558,6 +593,7 @@ class AdapterDataParallel:
             norm = self.bucket.flat.norm() * scale
             scale *= min(1.0, float(max_grad_norm) / (float(norm) + 1e-6))
         self.optimizer.step(grad_scale=scale, zero_grad=True)
+        self.refresh_shadows()
         return norm
 
     def grad_norm(self) -> torch.Tensor:
@@ -574,7 +610,8 @@ class AdapterDataParallel:
         """Everything a resume needs beyond the module's own state_dict: the fp32 master copy (the module parameters are its
         bf16 rounding) and the AdamW moments.  Tensors are references; ``torch.save`` them or ``clone()`` first."""
         return {"names": list(self.names), "offsets": list(self.offsets), "sizes": list(self.sizes), "master": self.master,
-                "optimizer": None if self.optimizer is None else self.optimizer.state_dict()}
+                "optimizer": None if self.optimizer is None else self.optimizer.state_dict(),
+                "optimizer_in_backward": bool(self.opt_in_backward), "unclipped_steps": int(self.unclipped_steps)}
 
     def load_state_dict(self, sd: dict) -> None:
         if list(sd["names"]) != self.names or list(sd["offsets"]) != self.offsets:
@@ -584,6 +621,7 @@ class AdapterDataParallel:
             self.work.copy_(self.master)             # bf16 working copies (fp32 parameters are views of the master itself)
         if self.optimizer is not None and sd.get("optimizer") is not None:
             self.optimizer.load_state_dict(sd["optimizer"])
+        self.refresh_shadows()
 
     def detached_state_dict(self, state_dict: Optional[dict] = None) -> dict:
         """``model.state_dict()`` (or the given one) with every tensor that is a view of the flat buffers cloned into its own
@@ -600,13 +638,15 @@ class AdapterDataParallel:
             if getattr(m, "_moka_sinks", None) is not None:
                 m._moka_sinks = None
                 m._moka_defer = None
+                m._moka_shadows = None
+                m._moka_seed_dev = None
 
 
 def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: bool = True, lr: float = 1e-4,
            betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
            comm_dtype: Optional[torch.dtype] = None, trainable=None, defer_dA: bool = True,
            optimizer_in_backward: bool = False, force_comm: bool = False, no_decay="hf",
-           overlap_base: Optional[bool] = None, tail_layers: Optional[int] = None, bucket_sizes=None) -> AdapterDataParallel:
+           tail_layers: Optional[int] = None, bucket_sizes=None, persistent_shadows: Optional[bool] = None) -> AdapterDataParallel:
     """Data-parallel training of a MokA-adapted model: one process per GPU, every rank holds the full frozen
     base and the full adapter, batches are sharded by sample, and the only exchange is the trainable-gradient sum.
 
@@ -644,15 +684,15 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
       the reference therefore trains without decay (``AudioVisualText/trainer.py`` does not override ``create_optimizer``): biases and
       the weights of normalisation layers; a callable ``(name, param, module) -> bool``; ``None`` = decay everywhere.
 
-    * ``overlap_base`` (None: leave the process-wide switch alone): the adapter's x-only half (down-projection, weight shadows) and
-      gy-only half (pass over gy, rank-space backward) run on a side stream beside the frozen base GEMM of the same projection and are
-      joined in front of the kernels that add to the GEMM's result (``functional.set_overlap_base``; same kernels, same bits).
+    * ``persistent_shadows`` (default: on with the built-in optimizer): the transposed weight copies the backward kernels read (``BwT``,
+      ``AT``: functions of the weights alone) are kept per adapted projection and rewritten where the weights change -- one batched
+      launch (``moka_weight_shadows_batch``) behind every optimizer update, per gradient bucket with ``optimizer_in_backward`` -- instead
+      of one launch per projection in every forward (7 x n_layers launches off the forward's dependency chain).  Whoever writes the
+      adapter weights by other means (``load_state_dict`` on the module, a manual ``copy_``) calls ``dp.refresh_shadows()`` afterwards;
+      ``dp.load_state_dict`` does.
 
     Replaces DeepSpeed ZeRO-2's bucketed reduce-scatter + partitioned optimizer of the reference configurations
     (``VisualText/zero_stage2_config.json:2-10``, ``AudioVisualText/trainer.py:163-218``)."""
-    if overlap_base is not None:
-        from . import functional as _F
-        _F.set_overlap_base(bool(overlap_base))
     pick = trainable if trainable is not None else (lambda n, p: p.requires_grad)
     named = [(n, p) for n, p in model.named_parameters() if pick(n, p)]
     if not named:
@@ -692,6 +732,7 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
     ids = sorted(set(layer_of))
     order = sorted(range(len(named)), key=lambda k: (layer_of[k], k))            # layer by layer, module order inside a layer
     names, offsets, sizes, ends = [], [], [], []
+    named_sorted, layer_sorted = [named[k][0] for k in order], [layer_of[k] for k in order]
     off, cur = 0, None
     for k in order:
         if cur is not None and layer_of[k] != cur:
@@ -761,18 +802,45 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
             sk["B"] = grad_view[n]
         else:
             sk["A"][slot] = grad_view[n]
+    group_of = {n: ids.index(l_) for n, l_ in zip(named_sorted, layer_sorted)}      # parameter name -> its group (decoder layer) in the flat buffers
+    if persistent_shadows is None:
+        persistent_shadows = bool(optimizer) and dev.type == "cuda"
     for mod, sk in mods.values():
         mod._moka_sinks = {"B": sk["B"], "A": [sk["A"][i] for i in sorted(sk["A"])]}
         if defer_dA and dev.type == "cuda":
             mod._moka_defer = dp._defer
+        if dev.type == "cuda":
+            mod._moka_seed_dev = dp.seed_epoch
+        if persistent_shadows and dev.type == "cuda":
+            pn = {slot: n for n, (m_, slot) in sink_of.items() if m_ is mod}
+            Bw = by_name[pn["B"]]
+            As = [by_name[pn[i]] for i in sorted(k for k in pn if k != "B")]
+            if Bw.dtype == torch.bfloat16 and all(a.dtype == torch.bfloat16 for a in As):
+                from . import _lib as _L
+                RP = _L.rank_pad(Bw.shape[1])
+                BwT = torch.empty((RP, Bw.shape[0]), dtype=torch.bfloat16, device=dev)
+                AT = torch.empty((len(As), As[0].shape[1], RP), dtype=torch.bfloat16, device=dev)
+                mod._moka_shadows = (BwT, AT)
+                dp._shadowed.append((group_of[pn["B"]], mod, Bw, As, BwT, AT))
+    dp._group_bounds = [(ends[i - 1] if i else 0, ends[i]) for i in range(len(ends))]
+    dp.refresh_shadows()
     dp.kernel_fed = [n for n in names if n in fed]
     dp.hooked = [n for n in names if n not in fed]
     # every other trainable parameter: fold the autograd gradient into the flat buffer the moment it has been accumulated
     def fold(view):
         def hook(p):
-            if p.grad is not None:
+            if p.grad is None:
+                return
+            if dp._graph is not None:
+                # (capture: the chains run side by side and would race on the read-modify-write of the shared slice: the fold goes to the hub)
+                hub, g = dp._graph.hub, p.grad
+                hub.wait_stream(torch.cuda.current_stream(view.device))
+                with torch.cuda.stream(hub):
+                    view.add_(g.to(view.dtype).view_as(view))
+                g.record_stream(hub)
+            else:
                 view.add_(p.grad.to(view.dtype).view_as(view))
-                p.grad = None
+            p.grad = None
         return hook
     for n in dp.hooked:
         dp._handles.append(by_name[n].register_post_accumulate_grad_hook(fold(grad_view[n])))

@@ -77,6 +77,8 @@ class Linear(nn.Linear, LoraLayer):
     # data-parallel gradient buffer -- the weight-gradient kernels accumulate into them directly (None: autograd gradients)
     _moka_sinks = None
     _moka_defer = None          # attach(defer_dA=True): callable that takes the dA_m half of the backward off the dependency chain
+    _moka_seed_dev = None       # attach(): the device-resident part of the dropout seed (0 live; a captured step rewrites it per replay)
+    _moka_shadows = None        # attach(): persistent (BwT, AT) weight shadows of the full-M plan, rewritten behind every optimizer update
 
     def _sinks(self, n_adapters: int):
         sk = self._moka_sinks
@@ -86,7 +88,7 @@ class Linear(nn.Linear, LoraLayer):
         # lora_dropout acts on x before every A_m (lora.py:477); one counter-based mask per call
         p = self.lora_dropout_p if self.training else 0.0
         return AdapterSpec(self.d_k, self.scaling[0], [1.0] * self.lora_num, self.blc_weight, 1.0 / math.sqrt(self.d_k), dropout_p=p,
-                           sinks=self._sinks(self.lora_num), defer=self._moka_defer)
+                           sinks=self._sinks(self.lora_num), defer=self._moka_defer, shadows=self._moka_shadows, seed_dev=self._moka_seed_dev)
 
     def _adapter_weights(self, dtype):
         A = [getattr(self, f"lora_A{i}").weight for i in range(self.lora_num)]

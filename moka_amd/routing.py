@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -271,6 +272,67 @@ def routing_for_samples(B: int, S: int, samples: Sequence[int], device) -> MokaR
     return MokaRouting(MokaRouting._pad_tok_mod(tok), kpos, klen, B, S, 0, 1)
 
 
+_OVERRIDE = threading.local()
+
+
+class use_routing:
+    """``with use_routing(rt): model(...)``: every masked adapter call of this thread takes ``rt`` instead of compiling the masks it is
+    handed (``RoutingCache.get``).  What a captured training step needs (``schedule.GraphedTrainStep``): compiling masks reads the device
+    back once per batch, which a stream capture forbids -- the step's routing lives in ``StaticRouting`` buffers the graph's launches point
+    at, refreshed from the batch's masks before every replay."""
+
+    def __init__(self, rt: Optional["MokaRouting"]):
+        self.rt = rt
+
+    def __enter__(self):
+        self.prev = getattr(_OVERRIDE, "rt", None)
+        _OVERRIDE.rt = self.rt
+        return self.rt
+
+    def __exit__(self, *exc):
+        _OVERRIDE.rt = self.prev
+        return False
+
+
+class StaticRouting(MokaRouting):
+    """A routing at FIXED device addresses with room for ``key_capacity`` key slots per sample: the launches of a captured step point at its
+    buffers, ``load(rt)`` copies a batch's routing into them (no allocation, no read-back; the source routing was compiled outside the
+    capture).  The kernels read ``klen[b]`` keys of sample b, so spare capacity costs nothing but workspace."""
+
+    def __init__(self, like: MokaRouting, key_capacity: Optional[int] = None):
+        if like.dup_src is not None:
+            raise ValueError("StaticRouting: tokens of several modalities (virtual tokens) change the token count per batch; not capturable")
+        dev = like.device
+        cap = int(key_capacity) if key_capacity is not None else (like.Lk_max + 63) // 64 * 64 + 64
+        cap = max(cap, like.Lk_max, 1)
+        self.tok_mod = like.tok_mod.clone()
+        self.kpos = torch.full((like.B, cap), -1, dtype=torch.int32, device=dev)
+        self.ktok = torch.full((like.B, cap), -1, dtype=torch.int32, device=dev)
+        self.klen = like.klen.clone()
+        self.kslot = like.kslot.clone()
+        self.B, self.S, self.Lk_max, self.M, self.T = like.B, like.S, cap, like.M, like.T
+        self._ws = {}
+        self.struct = _lib.MokaRoutingStruct(self.tok_mod.data_ptr(), self.ktok.data_ptr(), self.klen.data_ptr(), self.kslot.data_ptr(),
+                                             like.B, like.S, cap, like.M)
+        self.dup_src, self.S_real = None, like.S
+        self.load(like)
+
+    def load(self, rt: MokaRouting) -> None:
+        if (rt.B, rt.S, rt.M) != (self.B, self.S, self.M) or rt.dup_src is not None:
+            raise ValueError(f"StaticRouting.load: the batch's routing is B={rt.B} S={rt.S} M={rt.M} (virtual tokens: {rt.dup_src is not None}), "
+                             f"the captured step was built for B={self.B} S={self.S} M={self.M}")
+        if rt.Lk_max > self.Lk_max:
+            raise ValueError(f"StaticRouting.load: {rt.Lk_max} key slots exceed the captured capacity {self.Lk_max} (re-capture with a larger key_capacity)")
+        n = rt.ktok.shape[1]
+        self.tok_mod.copy_(rt.tok_mod)
+        self.ktok.fill_(-1)
+        self.ktok[:, :n].copy_(rt.ktok)
+        self.kpos.fill_(-1)
+        self.kpos[:, :n].copy_(rt.kpos)
+        self.klen.copy_(rt.klen)
+        self.kslot.copy_(rt.kslot)
+
+
 class RoutingCache:
     """Routing keyed on the identity of the mask tensors (storage pointer, offset, shape, strides, dtype, version
     counter): the decoder passes the very same mask objects to all 7 x n_layers projections of a forward, so one
@@ -322,6 +384,9 @@ class RoutingCache:
         self._items.clear()
 
     def get(self, kind: str, masks: Sequence[torch.Tensor]) -> MokaRouting:
+        ov = getattr(_OVERRIDE, "rt", None)
+        if ov is not None:                       # (use_routing: a captured step's static routing)
+            return ov
         key = self._key(kind, masks)
         if key is None:
             return self._build(kind, masks)

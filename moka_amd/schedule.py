@@ -75,12 +75,16 @@ class AdapterUnit:
     members: dicts with d_in, d_out, A (list of M [r, d_in] bf16), dA (fp32 sinks), Bw [d_out, r], dB, y [T, d_out] (base output / gy,
     updated in place), h, hp_kmj, BwT, AT (saved forward -> backward); x / dx: the shared input and input gradient [T, d_in]."""
 
-    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False, company=1):
+    def __init__(self, label, members, T, r, M, rt, x, dx, scratch, s_in, s_out, w, c, drop_p, seeds, own_dh_kmj=None, fused=False, company=1,
+                 seed_dev=None):
         G = len(members)
         # moka_opts.company: how many independent chains run side by side (the pass over gy then sizes its token runs for its share of the CUs;
-        # the dx pass of a wide input takes fewer, longer workgroups)
-        self.opts = _lib.MokaOpts(None, 0, int(company))
-        ob = byref(self.opts) if company > 1 else None
+        # the dx pass of a wide input takes fewer, longer workgroups); moka_opts.seed_dev: the device word every replay's dropout masks follow
+        sd = seed_dev.data_ptr() if (seed_dev is not None and drop_p > 0.0) else None
+        self.opts = _lib.MokaOpts(None, 0, int(company), sd)
+        self.opts_seed = _lib.MokaOpts(seed_dev=sd)                          # (for the calls that take no company hint)
+        ob = byref(self.opts) if (company > 1 or sd is not None) else None
+        os_ = byref(self.opts_seed) if sd is not None else None
         # per unit: the library's advice for this shape (moka_up_fwd_fused_pays: e.g. not for the 70B widths' single projections)
         self.fused = bool(fused and _lib.up_fwd_fused_pays(T, _lib.ksplit(T, members[0]["d_in"], r, G), [m["d_out"] for m in members], r))
         self.label, self.G, self.T = label, G, T
@@ -103,16 +107,16 @@ class AdapterUnit:
         dh_kmj = P([(own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]) for g in range(G)])
         ws = P([rt.cross_ws(r, g) for g in range(G)])
         so = (c_float * M)(*s_out)
-        sd = (ctypes.c_ulonglong * G)(*seeds)
+        sds = (ctypes.c_ulonglong * G)(*seeds)
         do = I(self.d_outs)
         tm = rt.tok_mod.data_ptr()
-        self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sd, do, x, dx)
+        self.keep = (members, A, dA, Bw, dB, y, h, hp_kmj, BwT, AT, part, hp_tok, dh_tok, dh_kmj, ws, so, sds, do, x, dx, seed_dev)
         # (defer_da layer: the dA_m halves of a whole decoder layer as one moka_down_bwd_da_batch launch)
         self.da_items = [((own_dh_kmj[g] if own_dh_kmj is not None else scratch[g]["dh_kmj"]), x, self.d_in, members[g]["dA"], seeds[g]) for g in range(G)]
         self.sh_items = [(m["Bw"], m["d_out"], m["A"], self.d_in, m["BwT"], m["AT"]) for m in members]
         self.db_items = [(members[g]["y"], members[g]["hp_kmj"], members[g]["d_out"], members[g]["dB"]) for g in range(G)]
         self.calls = {
-            "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sd, 0)),
+            "moka_down_fwd": ("moka_down_fwd_group", (x.data_ptr(), A, tm, part, T, self.d_in, r, M, G, s_in, drop_p, sds, 0, os_)),
             "moka_cross_fwd": ("moka_cross_fwd_group", (part, ks_in, byref(rt.struct), so, Bw, do, A, self.d_in, h, None, hp_tok, hp_kmj,
                                                         BwT, AT, G, r, w, c)),
             "moka_up_fwd": ("moka_up_fwd_group", (hp_tok, Bw, tm, y, T, r, do, G, 0)),
@@ -130,13 +134,13 @@ class AdapterUnit:
             "moka_up_bwd:dB": ("moka_up_bwd_group", (y, hp_kmj, BwT, tm, so, None, dB, T, r, do, M, G, 0, ob)),
             "moka_cross_bwd": ("moka_cross_bwd_group", (part, ks_out, h, byref(rt.struct), s_in, None, dh_tok, dh_kmj, ws, G, r, w, c)),
             "moka_down_bwd": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                      drop_p, sd, 0, ob)),
+                                                      drop_p, sds, 0, ob)),
             # the two halves of moka_down_bwd as separate calls (either output may be NULL): dx stays on the dependency chain,
             # dA_m is needed by the optimizer only
             "moka_down_bwd:dx": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, None, dx.data_ptr(), T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0, ob)),
+                                                         drop_p, sds, 0, ob)),
             "moka_down_bwd:dA": ("moka_down_bwd_group", (dh_tok, dh_kmj, x.data_ptr(), AT, tm, dA, None, T, self.d_in, r, M, G,
-                                                         drop_p, sd, 0, None)),
+                                                         drop_p, sds, 0, os_)),
         }
         # algorithmic bytes per launch, SURVEY 8(d) split by entry point and summed over the members (the
         # per-projection definition: a group that reads x once is still credited G reads -- the roofline
@@ -170,13 +174,14 @@ class AdapterWorkload(_Bag):
 def make_layer_batches(units: Sequence[AdapterUnit], per: int, n_layers: int, rt, Tc: int, r: int, M: int, drop_p: float):
     """Argument lists of moka_down_bwd_da_batch / moka_up_bwd_db_batch for every layer of a chain (the layer's units in backward order)."""
     layer_da, layer_db = [], []
+    os_ = byref(units[0].opts_seed) if (units and units[0].opts_seed.seed_dev) else None
     for l in range(n_layers):
         items = [it for u in reversed(units[l * per:(l + 1) * per]) for it in u.da_items]
         n = len(items)
         layer_da.append(((c_void_p * n)(*[it[0].data_ptr() for it in items]), (c_void_p * n)(*[it[1].data_ptr() for it in items]),
                          (ctypes.c_int * n)(*[it[2] for it in items]), rt.tok_mod.data_ptr(),
                          (c_void_p * (n * M))(*[a.data_ptr() for it in items for a in it[3]]), n, Tc, r, M, drop_p,
-                         (ctypes.c_ulonglong * n)(*[it[4] for it in items]), 0, None))
+                         (ctypes.c_ulonglong * n)(*[it[4] for it in items]), 0, os_))
         dbi = [it for u in reversed(units[l * per:(l + 1) * per]) for it in u.db_items]
         layer_db.append(((c_void_p * n)(*[it[0].data_ptr() for it in dbi]), (c_void_p * n)(*[it[1].data_ptr() for it in dbi]),
                          (ctypes.c_int * n)(*[it[2] for it in dbi]), rt.tok_mod.data_ptr(), (c_void_p * n)(*[it[3].data_ptr() for it in dbi]),
@@ -375,6 +380,11 @@ def run_backward(lib, ch, sp, n_layers, on_layer_done=None, rec=None, lo=0, defe
                 ev_u = torch.cuda.Event()
                 ev_u.record(main)
             C("moka_down_bwd:dx", u, sp, None)
+            if per_unit and cfg.skip and cfg.skips("moka_down_bwd:dx"):
+                # (ablation of the dx family: the unit's fork must still see a CHAIN node captured first -- the executor follows a fork's
+                #  first out-edge -- so a 256-byte memset stands where the dx launch stood)
+                with torch.cuda.stream(main):
+                    ch.setdefault("_placeholder", torch.zeros(64, device=main.device)).zero_()
             if per_unit:
                 side.wait_event(ev_u)
                 if split_db:
@@ -487,6 +497,10 @@ class GraphedAdapterStep:
         self._keep = []
         self.comm_ev = [] if comm else None
         self.live_side = torch.cuda.Stream(device=self.dev) if cfg.defer_da != "off" else None
+        # the device word the units' dropout kernels fold into their seeds (moka_opts.seed_dev): rewritten in front of every step, so a
+        # replayed graph -- whose launch arguments, seeds included, are frozen -- still draws a fresh keep mask per step
+        self.seed_epoch = wl.get("seed_epoch")
+        self._epoch = 0
         if self.opt_in_bwd:
             opt.set_device_step(0)                       # (allocates the device-side coefficient state; no step counted)
             if comm:
@@ -649,6 +663,9 @@ class GraphedAdapterStep:
         cfg, lib, wl, opt, bucket, L = self.cfg, self.lib, self.wl, self.opt, self.bucket, self.L
         main_stream = self.main_stream
         sp = c_void_p(main_stream.cuda_stream)
+        if self.seed_epoch is not None:
+            self._epoch = (self._epoch + 0x9E3779B97F4A7C15) & 0x7fffffffffffffff       # (a fill kernel on the launch stream: stream-ordered in front of the replay)
+            self.seed_epoch.fill_(self._epoch)
         if opt is None or cfg.skips("optimizer"):
             bucket.zero_()                               # (the optimizer kernel leaves the gradient buffer zeroed)
         if self.opt_in_bwd:
@@ -726,3 +743,206 @@ class GraphedAdapterStep:
             if self.opt_in_bwd:
                 self.opt.t += 1
         return round(min(hs), 3)
+
+
+# ======================================================================================================================================
+# the trainer path: a whole decoder stack driven through autograd, captured in the same hub shape
+# ======================================================================================================================================
+def _split_batch(batch, sizes):
+    """dict / tuple / list of tensors (batch dimension 0) -> one such container per part."""
+    def cut(t):
+        return list(torch.split(t, sizes, dim=0)) if isinstance(t, torch.Tensor) else [t] * len(sizes)
+    if isinstance(batch, dict):
+        cols = {k: cut(v) for k, v in batch.items()}
+        return [{k: cols[k][i] for k in batch} for i in range(len(sizes))]
+    if isinstance(batch, (tuple, list)):
+        cols = [cut(v) for v in batch]
+        return [type(batch)(c[i] for c in cols) for i in range(len(sizes))]
+    return cut(batch)
+
+
+def _tensors(part):
+    if isinstance(part, dict):
+        return [v for v in part.values() if isinstance(v, torch.Tensor)]
+    if isinstance(part, (tuple, list)):
+        return [v for v in part if isinstance(v, torch.Tensor)]
+    return [part]
+
+
+def _clone_part(part):
+    c = lambda v: v.clone() if isinstance(v, torch.Tensor) else v                 # noqa: E731
+    if isinstance(part, dict):
+        return {k: c(v) for k, v in part.items()}
+    if isinstance(part, (tuple, list)):
+        return type(part)(c(v) for v in part)
+    return c(part)
+
+
+class GraphedTrainStep:
+    """ONE training step of a model -- forward, backward, deferred weight gradients, fused AdamW, weight shadows -- as ONE hub-shaped
+    hipGraph, the micro-batch processed as ``chains`` part-batches on forked streams.
+
+        dp = moka_amd.parallel.attach(model, ...)                # the reference's get_peft_model(...) model
+        step = GraphedTrainStep(dp, lambda part: model(**part).loss, example_batch, chains=2,
+                                routing_fn=lambda part: MokaRouting.from_avt_masks([part["m_t"], part["m_v"], part["m_a"], part["m_q"]]))
+        for batch in loader:
+            loss = step(batch)                                   # copies the batch into the static inputs, replays
+
+    What the reference runs as ``Trainer.training_step`` + DeepSpeed's hooks + ``optimizer.step()`` (``AudioVisualText/trainer.py:163-218``,
+    ``VisualText/train/train.py:601-617``) is here a replay: the step is captured once through autograd (``MokaLinearFn`` and every stock
+    PyTorch-ROCm op of the frozen base alike), so the launch order, the part-batch chains and everything ``attach`` takes off the
+    dependency chains (dA_m per layer, AdamW slice + weight shadows per gradient bucket) are the graph's.
+
+    * ``step_fn(part) -> loss``: the MEAN loss of the part's samples; the step's loss is the sample-weighted mean of the parts (the gradient
+      of the whole micro-batch's mean loss).  Shapes are static: every batch must have the example's shapes;
+    * ``routing_fn(part) -> MokaRouting`` (or None for models without masked adapters): compiled from the batch's masks OUTSIDE the graph
+      (one host read-back per part) and copied into the ``StaticRouting`` buffers the captured launches point at; inside the captured
+      forward the adapters take that routing whatever masks they are handed (``routing.use_routing``);
+    * the chains are captured one after the other (the whole forward + backward of part 0, then part 1: an autograd pass cannot be
+      interleaved), which only orders the HUB's launches; at replay the chains run side by side;
+    * the AdamW coefficients are written by a live one-thread launch in front of every replay (``FlatAdamW.begin_step``), so learning-rate
+      schedules work; gradient clipping does not exist in this mode (a bucket is updated before the global norm exists) and neither do
+      collectives (RCCL inside a capture crashes the runtime): one GPU, or the live path of ``attach`` for N > 1;
+    * lora_dropout: the per-call seeds are drawn at capture time and frozen with the launch arguments; what varies per replay is the device
+      word every dropout kernel folds into its seed (``moka_opts.seed_dev`` = ``dp.seed_epoch``), drawn from torch's CPU generator and
+      written in front of every replay: fresh keep masks every step, the same ones in the step's forward and backward.
+    dp = None: the same capture around a model without ``attach`` (no optimizer, no hub work): what ``bench.py --e2e`` times the frozen base with."""
+
+    def __init__(self, dp, step_fn: Callable, example_batch, chains: int = 2, routing_fn: Optional[Callable] = None,
+                 key_capacity: Optional[int] = None, warmup: int = 2, chain_priority: str = "normal", device=None):
+        from .routing import StaticRouting
+        self.dp, self.step_fn, self.routing_fn = dp, step_fn, routing_fn
+        ts = _tensors(example_batch)
+        if not ts:
+            raise ValueError("GraphedTrainStep: the example batch holds no tensors")
+        B = ts[0].shape[0]
+        self.n = max(1, min(int(chains), B))
+        self.sizes = [B // self.n + (1 if c < B % self.n else 0) for c in range(self.n)]
+        self.weights = [sz / float(B) for sz in self.sizes]
+        self.dev = torch.device(device) if device is not None else ts[0].device
+        if self.dev.type != "cuda":
+            raise _lib.MokaError("GraphedTrainStep captures HIP streams: the batch lives on %s" % self.dev)
+        if dp is not None:
+            if dp.optimizer is None:
+                raise ValueError("GraphedTrainStep needs attach(..., optimizer=True): the fused AdamW slices are part of the captured step")
+            if dp.bucket.comm:
+                raise ValueError("GraphedTrainStep: collectives cannot be captured (RCCL inside a stream capture crashes the runtime); "
+                                 "use the live path of attach() for N > 1")
+        self.parts = [_clone_part(p) for p in _split_batch(example_batch, self.sizes)]
+        self.rts = [StaticRouting(routing_fn(p), key_capacity) for p in self.parts] if routing_fn is not None else [None] * self.n
+        self.pri = -1 if chain_priority == "high" else 0
+        self.warmup = int(warmup)
+        self.graph, self.loss, self._hc, self._reports, self.hub = None, None, None, {}, None
+        self.capture()
+
+    # ---- what AdapterDataParallel calls while this step is being captured
+    def layer_done(self, dp, l: int) -> None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))                 # (the chain's stream: its in-chain gradients of the layer are in front of it)
+        evs = self._reports.setdefault(l, [])
+        evs.append(ev)
+        if len(evs) == self.n and dp.bucket.is_bucket_first(l):
+            for e_ in evs:
+                self.hub.wait_event(e_)
+            with torch.cuda.stream(self.hub):
+                dp._opt_slice(*dp.bucket.bucket_bounds(l))             # (+ the bucket's weight shadows, behind every chain's dA_m of its layers)
+
+    def _run_part(self, c: int):
+        from .routing import use_routing
+        with use_routing(self.rts[c]):
+            loss = self.step_fn(self.parts[c])
+            (loss * self.weights[c]).backward()
+        return loss.detach() * self.weights[c]
+
+    def capture(self) -> None:
+        dp, dev = self.dp, self.dev
+        graph = torch.cuda.CUDAGraph()
+        hc = HubCapture(graph, self.n, dev, priority=self.pri)
+        # ---- warm-up: the step live on the very streams of the capture (library handles and workspaces are per stream), state restored afterwards
+        snap = None
+        if dp is not None:
+            o = dp.optimizer
+            snap = (dp.master.clone(), dp.work.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.t)
+        torch.cuda.synchronize(dev)
+        for _ in range(self.warmup):
+            for c in range(self.n):
+                hc.branch[c].wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(hc.branch[c]):
+                    if dp is not None and c < self.n - 1:
+                        with dp.no_sync():
+                            self._run_part(c)
+                    else:
+                        self._run_part(c)
+                torch.cuda.current_stream(dev).wait_stream(hc.branch[c])
+            if dp is not None:
+                dp.step()
+        torch.cuda.synchronize(dev)
+        if dp is not None:
+            with torch.no_grad():
+                dp.master.copy_(snap[0])
+                dp.work.copy_(snap[1])
+                o.exp_avg.copy_(snap[2])
+                o.exp_avg_sq.copy_(snap[3])
+            o.t = snap[4]
+            dp.bucket.zero_()
+            dp.refresh_shadows()
+            torch.cuda.synchronize(dev)
+        # ---- capture
+        self._reports = {}
+        try:
+            if dp is not None:
+                dp._graph = self
+                dp._opt_begun = True             # (the coefficients come from the live begin_step() in front of every replay)
+                dp._opt_done.clear()
+                if o._state is None:
+                    o.set_device_step(o.t)
+            with hc:
+                self.hub = hc.cur
+                losses = []
+                for c in range(self.n):
+                    with torch.cuda.stream(hc.branch[c]):
+                        losses.append(self._run_part(c))
+                        if dp is not None:
+                            dp._flush_deferred()     # what the chain's last layers deferred
+                for st in hc.branch:
+                    hc.cur.wait_stream(st)
+                if dp is not None:
+                    # whatever no bucket hook covered (parameters outside the decoder stack, the first layer when its input carries no
+                    # gradient): behind every chain, on the hub
+                    done, pos, n_all = sorted(dp._opt_done), 0, dp.bucket.flat.numel()
+                    for lo, hi in done + [(n_all, n_all)]:
+                        if lo > pos:
+                            dp._opt_slice(pos, lo)
+                        pos = max(pos, hi)
+                self.loss = torch.stack(losses).sum()
+        finally:
+            if dp is not None:
+                dp._graph = None
+                dp._opt_begun = False
+                dp._opt_done.clear()
+                dp._done.clear()
+                dp._bwd_active = False
+        self.graph, self._hc = graph, hc
+        torch.cuda.synchronize(dev)
+
+    recapture = capture
+
+    def __call__(self, batch=None) -> torch.Tensor:
+        """Copy `batch` (None: keep the static inputs as they are) into the captured step's inputs, refresh the static routing, replay.
+        Returns the step's loss (a tensor the next replay overwrites)."""
+        if batch is not None:
+            new = _split_batch(batch, self.sizes)
+            for c in range(self.n):
+                for dst, src in zip(_tensors(self.parts[c]), _tensors(new[c])):
+                    if dst.shape != src.shape:
+                        raise ValueError(f"GraphedTrainStep: a batch tensor is {tuple(src.shape)}, the captured step was built for {tuple(dst.shape)}")
+                    dst.copy_(src, non_blocking=True)
+                if self.rts[c] is not None:
+                    self.rts[c].load(self.routing_fn(new[c]))
+        if self.dp is not None:
+            if self.dp.seed_epoch is not None:
+                from .functional import draw_seed
+                self.dp.seed_epoch.fill_(draw_seed())    # the device part of every dropout seed: this replay's masks (torch.manual_seed controls it)
+            self.dp.optimizer.begin_step()       # this step's coefficients (lr / betas of NOW), a one-thread launch in front of the replay
+        self.graph.replay()
+        return self.loss

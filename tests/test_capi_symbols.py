@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_rank_pad(lib):
-    assert lib.moka_version() == 603
+    assert lib.moka_version() == 700
     assert [lib.moka_tok_pad(t) for t in (1, 32, 33)] == [32, 32, 64]
     assert [lib.moka_rank_pad(r) for r in (1, 4, 8, 16, 17, 32, 33, 64)] == [16, 16, 16, 16, 32, 32, 64, 64]
     assert lib.moka_rank_pad(0) < 0 and lib.moka_rank_pad(65) < 0
@@ -65,20 +65,20 @@ def test_argument_validation_sets_error_message(lib):
     dummy = ctypes.c_void_p(64)
     arr = (ctypes.c_void_p * 1)(64)
     # unsupported dtype
-    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 7, None)     # 0 = MOKA_BF16, 1 = MOKA_F32
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 7, None, None)     # 0 = MOKA_BF16, 1 = MOKA_F32
     assert rc == -2 and b"MOKA_BF16" in lib.moka_last_error()
     # width not a multiple of 32
-    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0.0, 0, 0, None)
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 72, 4, 1, 1.0, 0.0, 0, 0, None, None)
     assert rc == -1 and b"multiple of 32" in lib.moka_last_error()
     # rank out of range
     rc = lib.moka_up_fwd(dummy, dummy, dummy, dummy, 16, 65, 64, 0, None)
     assert rc == -1 and b"rank" in lib.moka_last_error()
     # dropout probability out of range
-    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 1.5, 7, 0, None)
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 1.5, 7, 0, None, None)
     assert rc == -1 and b"dropout" in lib.moka_last_error()
     assert abs(lib.moka_dropout_scale(0.05) - 32768.0 / (32768 - 1638)) < 1e-6
     # null pointer
-    rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 0, None)
+    rc = lib.moka_down_fwd(None, arr, dummy, dummy, 16, 64, 4, 1, 1.0, 0.0, 0, 0, None, None)
     assert rc == -1 and b"null" in lib.moka_last_error()
 
 
@@ -105,6 +105,16 @@ def test_the_product_library_keeps_no_mutable_state(lib):
     so = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
     rc = lib.moka_up_bwd(dummy, dummy, dummy, dummy, so, None, dummy, 256, 4, 64, 3, 0, ctypes.byref(odd), None)
     assert rc == -1 and b"aligned" in lib.moka_last_error()
+    # moka_opts carries its own size: a struct too short to hold `company` is refused, a caller built against a SHORTER
+    # header (no seed_dev) is served with that field at its default, and a misaligned seed_dev fails before any launch
+    assert _lib.MokaOpts().struct_size == ctypes.sizeof(_lib.MokaOpts) == 40
+    short = _lib.MokaOpts(4096, need)
+    short.struct_size = 8
+    rc = lib.moka_up_bwd(dummy, dummy, dummy, dummy, so, None, dummy, 256, 4, 64, 3, 0, ctypes.byref(short), None)
+    assert rc == -1 and b"struct_size" in lib.moka_last_error()
+    bad_seed = _lib.MokaOpts(seed_dev=4100)
+    rc = lib.moka_down_fwd(dummy, arr, dummy, dummy, 256, 64, 4, 3, 1.0, 0.1, 7, 0, ctypes.byref(bad_seed), None)
+    assert rc == -1 and b"seed_dev" in lib.moka_last_error()
 
 
 def test_no_gpu_means_loud_failure():

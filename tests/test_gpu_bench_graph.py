@@ -73,3 +73,20 @@ def test_capture_failure_falls_back_to_live_launches_of_every_chain():
         a, b = outs["graph"]["entry_point_ms_per_pass"][k], outs["fallback"]["entry_point_ms_per_pass"][k]
         assert a > 0 and b > 0 and 0.5 < a / b < 2.0
     assert outs["fallback"]["value"] > 0 and outs["off"]["value"] > 0 and outs["graph"]["value"] >= 0.8 * outs["fallback"]["value"]
+
+
+@pytest.mark.parametrize("extra", [(), ("--chains", "1"), ("--defer-da", "layer")], ids=lambda e: " ".join(e) or "default")
+def test_default_schedule_with_optimizer_equals_live_steps(extra):
+    """the headline schedule WITH its optimizer -- two chains sharing gradient accumulators, AdamW slices and weight-shadow
+    rewrites on the hub behind per-branch events -- was never compared against live launches.  `bench.py --verify-graph` (without
+    --no-optimizer): 3 steps as the captured graph and 3 steps live from identical master / moments / activations."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layers", "5", "--seq", "512", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-traffic", "--verify-graph", *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    chk = out["graph_check"]
+    assert chk["steps"] == 3 and chk["grad_left_zero"], chk
+    assert chk["master_rel_diff"] <= 1e-5, chk                     # (fp32 atomics in a different order: last bits of the gradients)
+    assert chk["work_max_abs_diff"] <= 1e-3 and chk["shadow_max_abs_diff"] <= 1e-3, chk       # bf16 copies: an ulp where the master's last bits differ
+    assert chk["activations_max_rel_diff"] <= 1e-3, chk

@@ -470,10 +470,13 @@ def test_optimizer_in_backward_takes_the_same_steps(defer):
     err = ((outs[0][0] - outs[1][0]).norm() / outs[0][0].norm()).item()
     assert err <= 1e-5, err
     assert (outs[0][1].float() - outs[1][1].float()).abs().max().item() <= 2 ** -6      # bf16 copies: at most an ulp of rounding apart
-    # no clipping in this mode: said once, and the step neither throws behind the update nor changes anything
+    # no clipping in this mode: said on EVERY call (one warning is lost in a training log), counted in state_dict(), and the
+    # step neither throws behind the update nor changes anything
     with pytest.warns(RuntimeWarning, match="does NOT clip"):
         dp.step(max_grad_norm=1.0)
-    dp.step(max_grad_norm=1.0)
+    with pytest.warns(RuntimeWarning, match="2 step"):
+        dp.step(max_grad_norm=1.0)
+    assert dp.state_dict()["unclipped_steps"] == 2 and dp.state_dict()["optimizer_in_backward"] is True
     torch.cuda.synchronize()
 
 

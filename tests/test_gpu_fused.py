@@ -224,35 +224,3 @@ def test_autograd_node_is_bitwise_the_same_with_and_without_the_fused_forward(na
         F.set_deterministic(False, device=dev)
     for a_, b_ in zip(*outs):
         assert torch.equal(a_, b_)
-
-
-def test_overlap_with_the_base_gemm_gives_the_same_bits():
-    """functional.OVERLAP_BASE: the x-only / gy-only halves of the adapter on a side stream beside the frozen base GEMM (single nodes and
-    the q/k/v group node): y, dx and the weight gradients are identical (deterministic weight gradients)."""
-    from moka_amd import functional as F
-    from moka_amd.functional import AdapterSpec, moka_linear, moka_linear_group
-    dev = _dev()
-    bf = torch.bfloat16
-    cds = _group_data("avt", 2, 640, 1024, (1024, 512, 512), 16, 31)
-    spec0, rt, _ = _spec_and_routing(cds[0], dev)
-    F.set_deterministic(True, device=dev)
-    outs = []
-    try:
-        for ovl in (False, True):
-            F.set_overlap_base(ovl)
-            F.DEBUG_LAUNCH_ON = ovl                          # every _launch_on(side) region: no device block freed inside it
-            specs = [AdapterSpec(spec0.r, spec0.s_in, spec0.s_out, spec0.w, spec0.inv_sqrt_dk, 0.1, seed=100 + g) for g in range(3)]
-            x = cds[0].x.to(dev, bf).requires_grad_(True)
-            params = [(cd.W.to(dev, bf), None, cd.Bw.to(dev, bf).requires_grad_(True), [a.to(dev, bf).requires_grad_(True) for a in cd.A]) for cd in cds]
-            ys = moka_linear_group(x, params, rt, specs)
-            y1 = moka_linear(ys[0].detach().requires_grad_(True) if False else x, params[0][0], None, params[0][2], params[0][3], rt, specs[0])
-            torch.autograd.backward(list(ys) + [y1], [cd.gy.to(dev, bf) for cd in cds] + [cds[0].gy.to(dev, bf)])
-            torch.cuda.synchronize()
-            outs.append([t_.detach().clone() for t_ in ys] + [y1.detach().clone(), x.grad.clone()] +
-                        [p_[2].grad.clone() for p_ in params] + [a.grad.clone() for p_ in params for a in p_[3]])
-    finally:
-        F.set_overlap_base(False)
-        F.DEBUG_LAUNCH_ON = False
-        F.set_deterministic(False, device=dev)
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_)

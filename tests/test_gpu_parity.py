@@ -523,6 +523,33 @@ def test_dropout_layer_train_vs_eval():
     assert torch.equal(y1, y2) and not torch.equal(y1, y3) and not torch.equal(y1, y_eval)
 
 
+@pytest.mark.parametrize("p", [0.05, 0.1, 0.5])
+def test_dropout_mask_statistics(p):
+    """the keep mask's hash was changed in round 5 (24-bit products) and only an offline probe looked at its statistics.  The
+    extracted mask of a 4096 x 4096 input: keep rate = 1 - round(p * 32768) / 32768 to 4 sigma, rows / columns spread like independent
+    draws, and no correlation between neighbouring elements, elements 8 apart (the same slot of the next 16-byte chunk) or neighbouring rows."""
+    from moka_amd import functional as F
+    dev = _dev()
+    T = C_ = 4096
+    keep = 1.0 - round(p * 32768) / 32768.0
+    for seed in (1234, (7 << 40) + 99):
+        m = F.dropout_mask(p, seed, T, C_, dev).float()
+        n = T * C_
+        sd = (keep * (1 - keep)) ** 0.5
+        assert abs(m.mean().item() - keep) <= 4 * sd / n ** 0.5
+        # row / column means: binomial spread sd / sqrt(4096), within 15 % of it (a structured mask shows a larger -- or a zero -- spread)
+        for dim in (0, 1):
+            spread = m.mean(dim).std().item()
+            assert 0.85 * sd / 64 <= spread <= 1.15 * sd / 64, (p, dim, spread, sd / 64)
+        def corr(a, b):
+            return torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1].item()
+        lim = 4.0 / n ** 0.5                                     # 4 sigma of a sample correlation of independent bits
+        assert abs(corr(m[:, :-1], m[:, 1:])) <= lim
+        assert abs(corr(m[:, :-8], m[:, 8:])) <= lim
+        assert abs(corr(m[:-1], m[1:])) <= lim
+        assert abs(corr(m[:, 0::2], m[:, 1::2])) <= lim          # the two 16-bit halves of one hash dword
+
+
 # ------------------------------------------------------------------------------------------
 # grouped entry points (SURVEY 8(f1)): q/k/v and gate/up read the same x
 # ------------------------------------------------------------------------------------------

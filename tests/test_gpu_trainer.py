@@ -140,3 +140,86 @@ def test_fp32_storage_adapters_through_attach_and_the_fused_step():
             assert p.dtype == torch.float32 and p.grad is None
             worst = max(worst, ((p.detach() - pb[n].detach()).norm() / pb[n].detach().norm().clamp_min(1e-20)).item())
     assert worst <= 2e-4, worst
+
+
+def _batch2(dev, S=64, n=4, shift=0):
+    """_data() with the modality / question spans moved by `shift` tokens (a second batch with another routing)."""
+    rows = _data(S=S, n=n)
+    if shift:
+        for r_ in rows:
+            for k in ("m_t", "m_v", "m_a", "m_q"):
+                r_[k] = torch.roll(r_[k], shift, dims=0)
+    return {k: v.to(dev) for k, v in _collate(rows).items()}
+
+
+@pytest.mark.parametrize("chains", [1, 2])
+def test_graphed_train_step_equals_the_live_loop(chains):
+    """moka_amd.schedule.GraphedTrainStep: the whole step (forward, backward through MokaLinearFn, deferred dA_m, the bucket's AdamW slices
+    and weight shadows on the hub, a hooked projector parameter) captured as ONE hub-shaped hipGraph and replayed on changing batches ==
+    the live attach() loop on the same batches."""
+    from moka_amd.parallel import attach
+    from moka_amd.routing import MokaRouting
+    from moka_amd.schedule import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    batches = [_batch2(dev, shift=0), _batch2(dev, shift=3)]
+    steps, lr = 5, 2e-3
+    ref = TinyLM(dev)
+    dp_r = attach(ref, n_buckets=2, lr=lr, weight_decay=0.01)
+    ref_losses = []
+    n_rows = batches[0]["feats"].shape[0]
+    for i in range(steps):
+        # the live loop on the same part-batches (the step's arithmetic: every part's mean loss weighted by its share of the samples,
+        # accumulated into the flat gradient; a hooked bf16 parameter's gradient is rounded per part)
+        tot = 0.0
+        for c in range(chains):
+            lo_, hi_ = c * n_rows // chains, (c + 1) * n_rows // chains
+            part = {k: v[lo_:hi_] for k, v in batches[i % 2].items()}
+            ctx = dp_r.no_sync() if c < chains - 1 else torch.enable_grad()
+            with ctx:
+                loss = ref(**part)["loss"] * ((hi_ - lo_) / n_rows)
+                loss.backward()
+            tot += float(loss.detach())
+        dp_r.step()
+        ref_losses.append(tot)
+    m = TinyLM(dev)
+    dp = attach(m, n_buckets=2, lr=lr, weight_decay=0.01)
+    gs = GraphedTrainStep(dp, lambda p: m(**p)["loss"], batches[0], chains=chains,
+                          routing_fn=lambda p: MokaRouting.from_avt_masks([p["m_t"], p["m_v"], p["m_a"], p["m_q"]]))
+    init = attach(TinyLM(dev), n_buckets=2, lr=lr, weight_decay=0.01)
+    assert torch.equal(dp.master, init.master) and dp.optimizer.t == 0 and float(dp.bucket.flat.abs().max()) == 0.0   # the capture's warm-up steps were undone
+    losses = [float(gs(batches[i % 2])) for i in range(steps)]
+    torch.cuda.synchronize()
+    assert dp.optimizer.t == steps
+    if chains == 1:
+        assert losses[0] == ref_losses[0], (losses[0], ref_losses[0])          # same kernels on the same data before any update: the same bits
+    for a_, b_ in zip(losses, ref_losses):
+        assert abs(a_ - b_) <= 2e-3 * abs(b_) + 1e-6, (losses, ref_losses)
+    assert ref_losses[-1] < ref_losses[0]
+    err = ((dp.master - dp_r.master).norm() / dp_r.master.norm()).item()
+    assert err <= 2e-4, err
+    o = dp.offsets[dp.names.index("vl_projector.weight")]
+    w0 = TinyLM(dev).vl_projector.weight.float().reshape(-1)
+    assert (dp.master[o:o + w0.numel()] - w0).abs().max().item() > 1e-4          # the hooked (non-kernel-fed) projector trained inside the graph too
+    # the live path still works on the same handle after the capture (the graph state was left clean)
+    m(**batches[0])["loss"].backward()
+    dp.step()
+    torch.cuda.synchronize()
+
+
+def test_persistent_weight_shadows_equal_per_call_shadows():
+    """attach(persistent_shadows=True) (default): BwT / AT kept per projection and rewritten behind the optimizer == recomputed in every forward."""
+    from moka_amd.parallel import attach
+    dev = torch.device("cuda:0")
+    batch = _batch2(dev)
+    outs = []
+    for keep in (True, False):
+        m = TinyLM(dev)
+        dp = attach(m, n_buckets=2, lr=2e-3, weight_decay=0.0, persistent_shadows=keep)
+        assert bool(dp._shadowed) == keep
+        for _ in range(4):
+            m(**batch)["loss"].backward()
+            dp.step()
+        torch.cuda.synchronize()
+        outs.append(dp.master.clone())
+    err = ((outs[0] - outs[1]).norm() / outs[1].norm()).item()
+    assert err <= 1e-5, err                                                       # (same arithmetic; fp32 atomics order differs in the last bits)

@@ -72,7 +72,7 @@ def main():
         c = 1 / math.sqrt(r)
         sp = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
         return {
-            "down_fwd": lambda i: lib.moka_down_fwd(w["xs"][i % NBUF].data_ptr(), Ap, tm, w["part"].data_ptr(), T, d_in, r, M, 1.0, DROP, 1234, 0, sp()),
+            "down_fwd": lambda i: lib.moka_down_fwd(w["xs"][i % NBUF].data_ptr(), Ap, tm, w["part"].data_ptr(), T, d_in, r, M, 1.0, DROP, 1234, 0, None, sp()),
             "cross_fwd": lambda i: lib.moka_cross_fwd(w["part"].data_ptr(), _lib.ksplit(T, d_in, r), byref(rt.struct), so, w["Bw"].data_ptr(), d_out, Ap, d_in,
                                                       w["h"].data_ptr(), None, w["hp_tok"].data_ptr(), w["hp_kmj"].data_ptr(), w["BwT"].data_ptr(), w["AT"].data_ptr(), r, 1.0, c, sp()),
             "up_fwd": lambda i: lib.moka_up_fwd(w["hp_tok"].data_ptr(), w["Bw"].data_ptr(), tm, w["ys"][i % NBUF].data_ptr(), T, r, d_out, 0, sp()),
