@@ -234,15 +234,17 @@ Recorder, run_forward, run_backward, run_shadows = SCH.Recorder, SCH.run_forward
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters -- read from the committed summary of the
 # PMC passes of THIS build (tools/pmc_traffic.sh -> profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
 # in separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), never a constant in here.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 
 def kernel_source_sha256():
-    """sha256 over the kernel source + the C header: what a PMC traffic summary is stamped with (tools/pmc_traffic.py)."""
+    """sha256 over every file the library is built from (the translation units, their two headers, the C header): what a PMC traffic summary
+    is stamped with (tools/pmc_traffic.py)."""
     import hashlib
+    from moka_amd import build as _build
     h = hashlib.sha256()
-    for rel in ("moka_amd/csrc/moka_kernels.hip", "include/moka_hip.h"):
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    for path in _build.sources():
+        h.update(open(path, "rb").read())
     return h.hexdigest()
 
 
@@ -418,6 +420,7 @@ def end_to_end(args, dev):
         return (time.perf_counter() - t0) * 1e3 / n
 
     batch = {"h": h, "gout": gout, "m_t": masks[0], "m_v": masks[1], "m_a": masks[2], "m_q": masks[3]}
+    captures = []                                    # per captured step: the timed capture attempts (GraphedTrainStep.capture_log)
 
     def stack_loss(st):
         # (dx reaches the embeddings / projector in the real model: the stack's input carries a gradient; the "loss" is <out, gout>, whose
@@ -465,6 +468,7 @@ def end_to_end(args, dev):
         gs = SCH.GraphedTrainStep(dp, stack_loss(st), batch, chains=chains,
                                   routing_fn=(lambda p_: MokaRouting.from_avt_masks([p_["m_t"], p_["m_v"], p_["m_a"], p_["m_q"]])) if with_adapter else None)
         ms = clock(lambda: gs(None), n=5)
+        captures.append({"adapter": bool(with_adapter), "chains": chains, **attach_kw, "tries": gs.capture_log})
         del gs, dp, st
         import gc
         gc.collect()
@@ -490,7 +494,6 @@ def end_to_end(args, dev):
                    "attach_defer_dA_ms": round(att_defer, 2), "attach_defer_dA_adapter_ms": round(att_defer - base_live, 2),
                    "note": "defer_dA puts the dA_m launches on a side stream beside the NEXT layer's launches: beside the frozen base's hipBLASLt GEMMs the "
                            "streaming kernel costs the GEMMs more than it hides (the same finding as round 5's overlap_base, removed this round)"}
-    best = att_live
     for ch in ([1, 2] if args.e2e_chains2 else [1]):
         if ch > B:
             continue
@@ -503,12 +506,21 @@ def end_to_end(args, dev):
             say("attach(defer_dA=True), graphed, %d chain(s): %.2f ms" % (ch, d_ms))
             res["graphed_chains%d" % ch] = {"frozen_base_only_ms": round(b_ms, 2), "attach_ms": round(a_ms, 2), "adapter_ms": round(a_ms - b_ms, 2),
                                             "attach_defer_dA_ms": round(d_ms, 2), "adapter_share_of_step": round(1.0 - b_ms / a_ms, 4)}
-            best = min(best, a_ms, d_ms)
         except Exception as exc:                     # (a capture the runtime refuses is reported, not fatal: the live figures stand)
             res["graphed_chains%d" % ch] = {"error": repr(exc)[:300]}
             torch.cuda.synchronize()
-    res.update({"ms_per_step": round(best, 2), "tokens_per_s": round(B * S / (best * 1e-3), 1), "frozen_base_only_ms_per_step": round(base_live, 2),
-                "adapter_ms": round(att_live - base_live, 2), "adapter_share_of_step": round(1.0 - base_live / att_live, 4)})
+    res["captures"] = captures
+    g1 = res.get("graphed_chains1", {})
+    # the trainer path's figure: the captured step where it exists (host-independent), else the live attach() loop -- each against the
+    # frozen stack in the SAME launch mode
+    if "attach_ms" in g1:
+        a_ms, b_ms = min(g1["attach_ms"], g1["attach_defer_dA_ms"]), g1["frozen_base_only_ms"]
+        mode = "moka_amd.schedule.GraphedTrainStep (attach + MokaLinearFn captured as one single-list hipGraph)"
+    else:
+        a_ms, b_ms = min(att_live, att_defer), base_live
+        mode = "moka_amd.parallel.attach, live launches"
+    res.update({"ms_per_step": round(a_ms, 2), "tokens_per_s": round(B * S / (a_ms * 1e-3), 1), "frozen_base_only_ms_per_step": round(b_ms, 2),
+                "adapter_ms": round(a_ms - b_ms, 2), "adapter_share_of_step": round(1.0 - b_ms / a_ms, 4), "mode": mode})
     return res
 
 

@@ -467,7 +467,8 @@ class AdapterDataParallel:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
         main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)
+        if side != main:                             # (a one-chain capture is a single list: "off the chain" is then just "later on the same stream")
+            side.wait_stream(main)
 
         def key_of(desc):
             return (desc[0], id(desc[1][0][0])) + tuple(v if not isinstance(v, torch.Tensor) else id(v) for v in desc[1][0][1:])
@@ -834,7 +835,8 @@ def attach(model: nn.Module, n_buckets: int = 8, process_group=None, optimizer: 
             if dp._graph is not None:
                 # (capture: the chains run side by side and would race on the read-modify-write of the shared slice: the fold goes to the hub)
                 hub, g = dp._graph.hub, p.grad
-                hub.wait_stream(torch.cuda.current_stream(view.device))
+                if hub != torch.cuda.current_stream(view.device):
+                    hub.wait_stream(torch.cuda.current_stream(view.device))
                 with torch.cuda.stream(hub):
                     view.add_(g.to(view.dtype).view_as(view))
                 g.record_stream(hub)

@@ -437,8 +437,9 @@ class HubCapture:
     def __init__(self, graph: "torch.cuda.CUDAGraph", n_chains: int, device, priority: int = 0, root: Optional[Callable[[], None]] = None,
                  pool=None):
         self.graph, self.device, self.root = graph, device, root
-        self.hub = torch.cuda.Stream(device=device)
-        self.branch = [torch.cuda.Stream(device=device, priority=priority) for _ in range(n_chains)]
+        self.single = n_chains == 0                  # ONE list: everything -- the chain's launches and what is "off the chain" -- on the capture stream
+        self.hub = torch.cuda.Stream(device=device, priority=priority if self.single else 0)
+        self.branch = [self.hub] if self.single else [torch.cuda.Stream(device=device, priority=priority) for _ in range(n_chains)]
         self.anchor = torch.zeros(64, device=device)
         self._ctx = None
         self._pool = pool
@@ -452,13 +453,15 @@ class HubCapture:
             self.root()
         else:
             self.anchor.zero_()                      # (the root)
+        if self.single:
+            return self
         for st in self.branch:
             st.wait_stream(self.cur)                 # fork
         self.anchor.zero_()                          # the root's FIRST successor is on the hub: the walk runs down the hub before it sees a chain
         return self
 
     def __exit__(self, et, ev, tb):
-        if et is None:
+        if et is None and not self.single:
             for st in self.branch:
                 self.cur.wait_stream(st)             # join
         return self._ctx.__exit__(et, ev, tb)
@@ -842,8 +845,9 @@ class GraphedTrainStep:
         evs = self._reports.setdefault(l, [])
         evs.append(ev)
         if len(evs) == self.n and dp.bucket.is_bucket_first(l):
-            for e_ in evs:
-                self.hub.wait_event(e_)
+            if self.hub != torch.cuda.current_stream(self.dev):      # (a one-chain capture is a single list: the reports are in stream order already)
+                for e_ in evs:
+                    self.hub.wait_event(e_)
             with torch.cuda.stream(self.hub):
                 dp._opt_slice(*dp.bucket.bucket_bounds(l))             # (+ the bucket's weight shadows, behind every chain's dA_m of its layers)
 
@@ -854,17 +858,75 @@ class GraphedTrainStep:
             (loss * self.weights[c]).backward()
         return loss.detach() * self.weights[c]
 
-    def capture(self) -> None:
+    # ---- state a capture must not leave changed (its warm-up steps and its timed test replays are real optimizer steps)
+    def _snapshot(self):
+        dp = self.dp
+        if dp is None:
+            return None
+        o = dp.optimizer
+        return (dp.master.clone(), dp.work.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.t)
+
+    def _restore(self, snap) -> None:
+        dp = self.dp
+        if dp is None:
+            return
+        o = dp.optimizer
+        with torch.no_grad():
+            dp.master.copy_(snap[0])
+            dp.work.copy_(snap[1])
+            o.exp_avg.copy_(snap[2])
+            o.exp_avg_sq.copy_(snap[3])
+        o.t = snap[4]
+        dp.bucket.zero_()
+        dp.refresh_shadows()
+        torch.cuda.synchronize(self.dev)
+
+    def capture(self, tries: int = 3, accept: float = 1.05) -> None:
+        """Warm up, capture, and CHECK the capture: ROCm 7.2 maps the lists of a captured graph (hub, chains) onto a few in-order hardware
+        queues, and which ones depends on how many streams the process has created -- every few captures the hub shares a queue with a chain
+        and every wait of the hub stalls that chain (measured: the same step 420 instead of 349 ms at the 7B widths, 46 instead of 30 ms for
+        the adapter-only schedule).  So a capture is timed on two replays against the live step of the warm-up and redone (new streams, new
+        mapping) up to `tries` times while it is more than `accept` x slower than that; the fastest capture is kept.  Model, optimizer state
+        and step count are restored after every timed run."""
+        import time
+        best = None
+        self.capture_log = []
+        for attempt in range(max(1, int(tries))):
+            graph, hc, loss, live_ms = self._capture_once()
+            self.graph, self._hc, self.loss = graph, hc, loss
+            snap = self._snapshot()
+            self.__call__(None)
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                self.__call__(None)
+            torch.cuda.synchronize(self.dev)
+            ms = (time.perf_counter() - t0) * 1e3 / 2
+            self._restore(snap)
+            self.capture_log.append({"attempt": attempt, "replay_ms": round(ms, 3), "live_ms": round(live_ms, 3)})
+            if best is None or ms < best[0]:
+                best = (ms, graph, hc, loss)
+            if ms <= accept * live_ms:
+                break
+        self.replay_ms, self.graph, self._hc, self.loss = best
+        torch.cuda.synchronize(self.dev)
+
+    def _capture_once(self):
+        import time
         dp, dev = self.dp, self.dev
         graph = torch.cuda.CUDAGraph()
-        hc = HubCapture(graph, self.n, dev, priority=self.pri)
+        # ONE chain: one list.  A hub beside a single chain buys nothing under a frozen base (the streaming launches it would run beside the
+        # chain cost the base's GEMMs more than they hide) and makes the replay depend on which hardware queues the runtime maps the two
+        # lists onto (measured at the 7B widths: 369 / 411 ms per step from capture to capture, 342 live); a single list has no cross-list
+        # wait and replays the same everywhere.
+        hc = HubCapture(graph, 0 if self.n == 1 else self.n, dev, priority=self.pri)
         # ---- warm-up: the step live on the very streams of the capture (library handles and workspaces are per stream), state restored afterwards
-        snap = None
-        if dp is not None:
-            o = dp.optimizer
-            snap = (dp.master.clone(), dp.work.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.t)
+        snap = self._snapshot()
+        o = dp.optimizer if dp is not None else None
         torch.cuda.synchronize(dev)
-        for _ in range(self.warmup):
+        live_ms = float("inf")
+        for _ in range(max(1, self.warmup)):
+            t0 = time.perf_counter()
             for c in range(self.n):
                 hc.branch[c].wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(hc.branch[c]):
@@ -876,17 +938,9 @@ class GraphedTrainStep:
                 torch.cuda.current_stream(dev).wait_stream(hc.branch[c])
             if dp is not None:
                 dp.step()
-        torch.cuda.synchronize(dev)
-        if dp is not None:
-            with torch.no_grad():
-                dp.master.copy_(snap[0])
-                dp.work.copy_(snap[1])
-                o.exp_avg.copy_(snap[2])
-                o.exp_avg_sq.copy_(snap[3])
-            o.t = snap[4]
-            dp.bucket.zero_()
-            dp.refresh_shadows()
             torch.cuda.synchronize(dev)
+            live_ms = min(live_ms, (time.perf_counter() - t0) * 1e3)
+        self._restore(snap)
         # ---- capture
         self._reports = {}
         try:
@@ -904,8 +958,9 @@ class GraphedTrainStep:
                         losses.append(self._run_part(c))
                         if dp is not None:
                             dp._flush_deferred()     # what the chain's last layers deferred
-                for st in hc.branch:
-                    hc.cur.wait_stream(st)
+                if not hc.single:
+                    for st in hc.branch:
+                        hc.cur.wait_stream(st)
                 if dp is not None:
                     # whatever no bucket hook covered (parameters outside the decoder stack, the first layer when its input carries no
                     # gradient): behind every chain, on the hub
@@ -914,7 +969,7 @@ class GraphedTrainStep:
                         if lo > pos:
                             dp._opt_slice(pos, lo)
                         pos = max(pos, hi)
-                self.loss = torch.stack(losses).sum()
+                loss = torch.stack(losses).sum()
         finally:
             if dp is not None:
                 dp._graph = None
@@ -922,8 +977,8 @@ class GraphedTrainStep:
                 dp._opt_done.clear()
                 dp._done.clear()
                 dp._bwd_active = False
-        self.graph, self._hc = graph, hc
         torch.cuda.synchronize(dev)
+        return graph, hc, loss, live_ms
 
     recapture = capture
 

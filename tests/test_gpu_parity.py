@@ -499,6 +499,55 @@ def _dropout_replay(cd, p, strict_rate=True):
     assert not torch.equal(F.dropout_mask(p, seed, T, c.d_in, dev), F.dropout_mask(p, seed + 1, T, c.d_in, dev))
 
 
+@pytest.mark.parametrize("name,r_pad", [("avt_r16_q", 16), ("avt_r16_down", 16), ("vt_r16_q", 16), ("avt_r64", 64)])
+def test_device_resident_seed_epoch_equals_the_combined_seed(name, r_pad):
+    """moka_opts.seed_dev (ABI 0.7.0): a call with (seed, *seed_dev = e) draws the mask of the combined seed
+    ((seed_hi + e_hi) << 32) | (seed_lo ^ e_lo) -- what a captured step relies on: its launch arguments are frozen, the word in device
+    memory is rewritten before every replay.  The down-projection's slices, dx and dA_m are bit-identical to a call that gets the
+    combined seed as its launch argument; a different epoch gives a different mask; epoch 0 is the plain seed."""
+    from moka_amd import functional as F
+    if name not in C._CASES:
+        pytest.skip(name)
+    cd = C.make_case_data(name)
+    dev = _dev()
+    c = cd.case
+    M = len(cd.A)
+    spec, rt, _ = _spec_and_routing(cd, dev)
+    T, bf, p, r = c.B * c.S, torch.bfloat16, 0.1, c.r
+    x2 = cd.x.reshape(T, c.d_in).to(dev, bf).contiguous()
+    A = [a.to(dev, bf).contiguous() for a in cd.A]
+    Bw = cd.Bw.to(dev, bf).contiguous()
+    gy2 = cd.gy.reshape(T, c.d_out).to(dev, bf).contiguous()
+    seed = (0x1234 << 32) | 0x9abcdef1
+    F.set_deterministic(True, device=dev)
+    try:
+        def run(seed_arg, epoch):
+            sd = None if epoch is None else torch.tensor([epoch], dtype=torch.int64, device=dev)
+            part = F.down_fwd(x2, A, rt, r, spec.s_in, p, seed_arg, seed_dev=sd)
+            st = F.cross_fwd(part, rt, r, spec.s_out, spec.w, spec.inv_sqrt_dk, Bw=Bw, A=A)
+            bst = F.cross_bwd(F.up_bwd(gy2, st.hp_kmj, st.BwT, rt, r, spec.s_out, None), st.h, rt, r, spec.s_in, spec.w, spec.inv_sqrt_dk)
+            dA_acc = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]
+            dx2 = torch.zeros(T, c.d_in, dtype=bf, device=dev)
+            F.down_bwd_(bst, x2, st.AT, rt, r, dA_acc, dx2, p, seed_arg, seed_dev=sd)
+            dA2 = [torch.zeros(r, c.d_in, dtype=torch.float32, device=dev) for _ in range(M)]
+            F.down_bwd_da_batch_([bst.dh_kmj], [x2], rt, r, [dA2], p, [seed_arg], seed_dev=sd)
+            torch.cuda.synchronize()
+            return [part, dx2] + dA_acc + dA2
+        epoch = (0x0badcafe << 32) | 0x600dd00d
+        with_dev = run(seed, epoch)
+        combined = run(F.effective_seed(seed, epoch), None)
+        for a_, b_ in zip(with_dev, combined):
+            assert torch.equal(a_, b_)
+        plain = run(seed, None)
+        zero = run(seed, 0)
+        for a_, b_ in zip(plain, zero):
+            assert torch.equal(a_, b_)
+        assert not torch.equal(with_dev[0], plain[0]) and not torch.equal(with_dev[1], plain[1])
+        assert F.effective_seed(seed, 0) == seed and F.effective_seed(seed, epoch) != seed
+    finally:
+        F.set_deterministic(False, device=dev)
+
+
 def test_dropout_layer_train_vs_eval():
     """peft_hyper.Linear: eval() ignores lora_dropout, train() applies it and replays under the same torch seed."""
     from moka_amd.peft_hyper import Linear

@@ -223,3 +223,101 @@ def test_persistent_weight_shadows_equal_per_call_shadows():
         outs.append(dp.master.clone())
     err = ((outs[0] - outs[1]).norm() / outs[1].norm()).item()
     assert err <= 1e-5, err                                                       # (same arithmetic; fp32 atomics order differs in the last bits)
+
+
+def test_graphed_train_step_draws_fresh_dropout_masks_per_replay():
+    """lora_dropout under a captured step: the per-call seeds are frozen with the launch arguments, the device word every dropout kernel
+    folds into its seed (moka_opts.seed_dev = dp.seed_epoch) is rewritten from torch's CPU generator in front of every replay -- replays of
+    the same batch differ, replays under the same torch seed repeat bit for bit (what activation checkpointing / a resumed run need)."""
+    from moka_amd.parallel import attach
+    from moka_amd.routing import MokaRouting
+    from moka_amd.schedule import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    batch = _batch2(dev)
+    m = TinyLM(dev)
+    for mod in m.modules():
+        if hasattr(mod, "lora_dropout_p"):
+            mod.lora_dropout_p = 0.25
+    dp = attach(m, n_buckets=2, lr=0.0, weight_decay=0.0)                          # lr 0: the weights stand still, only the masks move
+    gs = GraphedTrainStep(dp, lambda p: m(**p)["loss"], batch, chains=2,
+                          routing_fn=lambda p: MokaRouting.from_avt_masks([p["m_t"], p["m_v"], p["m_a"], p["m_q"]]))
+    torch.manual_seed(11); a1 = float(gs(batch))
+    torch.manual_seed(12); a2 = float(gs(batch))
+    torch.manual_seed(11); a3 = float(gs(batch))
+    assert a1 != a2 and a1 == a3, (a1, a2, a3)
+    assert int(dp.seed_epoch.item()) != 0
+
+
+def _hf_rank(rank, world, port, tmp, q):
+    """One of `world` ranks of a torchrun-style launch (gloo: the ranks share the one GPU) driving transformers.Trainer."""
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": "0", "LOCAL_WORLD_SIZE": str(world)})      # (LOCAL_RANK 0 for both: one device)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)                   # (accelerate adopts an initialised group)
+    from transformers import Trainer, TrainingArguments
+    from moka_amd.parallel import MokaFlatOptimizer, attach, keep_out_of_ddp, trainer_callback
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    steps, lr = 3, 2e-3
+    rows = _data(n=4 * steps)
+    m = TinyLM(dev)
+    dp = attach(m, n_buckets=2, lr=lr, weight_decay=0.0)
+    opt = MokaFlatOptimizer(dp, lr=lr)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0)
+    args = TrainingArguments(output_dir=os.path.join(tmp, "r%d" % rank), per_device_train_batch_size=2, gradient_accumulation_steps=1, max_steps=steps,
+                             learning_rate=lr, max_grad_norm=0.0, report_to=[], save_strategy="no", logging_steps=1,
+                             remove_unused_columns=False, dataloader_pin_memory=False, seed=1, data_seed=1, dataloader_drop_last=False,
+                             disable_tqdm=True, ddp_backend="gloo")
+
+    class Seq(Trainer):
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    tr = Seq(model=m, args=args, train_dataset=rows, data_collator=_collate, optimizers=(opt, sched), callbacks=[trainer_callback(dp)])
+    keep_out_of_ddp(tr, dp)
+    tr.train()
+    torch.cuda.synchronize()
+    wrapped = type(tr.model_wrapped).__name__
+    q.put((rank, dp.master.cpu().numpy(), wrapped, dp.bucket.world, dp.optimizer.t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hf_trainer_under_two_ranks_stays_out_of_ddp(tmp_path):
+    """transformers.Trainer under a two-rank launch (what `torchrun --nproc_per_node` sets up; gloo, the ranks share
+    the one GPU) with keep_out_of_ddp: accelerate does NOT wrap the model in DistributedDataParallel (whose reducer would wait for autograd
+    gradients that never come), attach()'s bucketed all-reduce averages the ranks' gradients, both ranks end with the same parameters, and
+    those are the parameters of one process training on the union of the ranks' rows."""
+    import multiprocessing as mp
+    import socket
+    from moka_amd.parallel import attach
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hf_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r_, master, wrapped, world, t = q.get(timeout=600)
+        got[r_] = (torch.from_numpy(master), wrapped, world, t)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == "TinyLM" and got[0][2] == 2 and got[0][3] == 3         # unwrapped, two ranks, three optimizer steps
+    assert torch.equal(got[0][0], got[1][0])
+    # one process on the union of the rows (step k: rows 4k .. 4k + 3 -- rank 0 the first two, rank 1 the other two)
+    dev = torch.device("cuda:0")
+    rows = _data(n=12)
+    ref = TinyLM(dev)
+    dp_r = attach(ref, n_buckets=2, lr=2e-3, weight_decay=0.0)
+    for k in range(3):
+        batch = {kk: v.to(dev) for kk, v in _collate(rows[4 * k:4 * k + 4]).items()}
+        ref(**batch)["loss"].backward()
+        dp_r.step()
+    torch.cuda.synchronize()
+    err = ((got[0][0].to(dev) - dp_r.master).norm() / dp_r.master.norm()).item()
+    assert err <= 2e-3, err                       # (the hooked bf16 projector gradient is rounded per rank; AdamW at step 1-3 follows its sign)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Compact per-kernel resource table (VGPR / spills / scratch / LDS / occupancy) for the HIP library.
 cd "$(dirname "$0")/.."
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude moka_amd/csrc/moka_kernels.hip -o /tmp/_moka_res.so \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Imoka_amd/csrc -Wno-unused-function moka_amd/csrc/moka_kernels.hip -o /tmp/_moka_res.so \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re,subprocess
 cur=None;rows=[]

@@ -2,7 +2,7 @@
 // candidate replacements run in the kernel sequences of a training step on cold, rotating buffers, with a per-wave timeline:
 // lane 0 of every wave stamps the 100 MHz wall clock at kernel entry, after its first group, ... and at exit.  From the stamps:
 // when the first / last wave of a launch starts relative to the end of its predecessor (boundary + ramp), how long the waves
-// live, how long the tail is.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include tools/microbench/passlab.hip -o passlab
+// live, how long the tail is.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I moka_amd/csrc tools/microbench/passlab.hip -o passlab
 #define MOKA_TRACE
 #define MOKA_DIAGNOSTICS
 #include "../../moka_amd/csrc/moka_kernels.hip"

@@ -21,9 +21,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def source_sha256():
     """What ties a traffic summary to a build: the sha256 over the kernel source and the C header (bench.py recomputes it and refuses a
     summary measured on other kernels)."""
+    sys.path.insert(0, ROOT)
+    from moka_amd import build as _build
     h = hashlib.sha256()
-    for rel in ("moka_amd/csrc/moka_kernels.hip", "include/moka_hip.h"):
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    for path in _build.sources():
+        h.update(open(path, "rb").read())
     return h.hexdigest()
 
 
