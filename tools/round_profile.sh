@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end measurements on the GPU box -> gpurun_out/<tag>/ (copy what is judged into profiles/ with tools/round_collect.py).  usage: round_profile.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 N="--no-cpu-baseline --no-traffic"
@@ -26,7 +26,11 @@ b bench_nodrop --steps 40 --dropout 0 $N
 b bench_noopt --steps 40 --no-optimizer $N
 b bench_nogroup --steps 20 --no-group $N
 b bench_verify --steps 3 --no-optimizer --verify-graph $N      # the captured schedule == the live launches (graph_check)
-b bench_e2e --steps 3 --e2e $N
+b bench_verify_opt --steps 3 --verify-graph $N                 # ... and WITH the optimizer: 3 steps as the graph vs 3 steps live from identical state
+b bench_ablate --steps 20 --ablate all --no-cpu-baseline       # in-schedule marginal of every kernel family (ScheduleConfig.skip: no rebuilt library)
+for n in 1 2 3 4; do b bench_b${n}_class --steps 40 --batch $n --chains 2 --chain-split class $N; done    # chains INSIDE the samples (by token class)
+b bench_seed_off --steps 40 --seed-dev off $N                  # the dropout epoch in device memory (fresh masks per replay): what it costs
+b bench_e2e --steps 3 --e2e --ablate off $N                    # the trainer path: decoder stack + attach, live and as a captured GraphedTrainStep
 tools/prof_run.sh $TAG > /dev/null 2>&1
 for f in $OUT/bench*.json; do python - $f <<'PY'
 import json, os, sys
