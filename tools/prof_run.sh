@@ -5,7 +5,7 @@ REPO=$PWD
 mkdir -p gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o r -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" > $REPO/gpurun_out/$TAG/prof_run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o r -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --ablate off "$@" > $REPO/gpurun_out/$TAG/prof_run.log 2>&1
 cd $REPO
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB 40 > gpurun_out/$TAG/kernel_trace.md 2>&1
