@@ -891,8 +891,13 @@ def main():
                      "shadows": lambda u: u.algo["moka_weight_shadows"] / max(1, args.chains), "optimizer": lambda u: 0, "none": lambda u: 0}
         rows = {}
         for fam in fams:
-            base_ms = timed_schedule((), accept_ms=1.02 * ms_per_step)   # (re-measured beside every ablated schedule: the pair shares the box's clock state)
-            wo_ms = timed_schedule((fam,), accept_ms=0.0)
+            try:
+                base_ms = timed_schedule((), accept_ms=1.02 * ms_per_step)   # (re-measured beside every ablated schedule: the pair shares the box's clock state)
+                wo_ms = timed_schedule((fam,), accept_ms=0.0)
+            except Exception as exc:                 # (context for the line, never a reason to lose it: the headline has been measured)
+                print(f"bench: in-schedule ablation of `{fam}` failed ({exc!r}); roofline.in_schedule is null in this line", file=sys.stderr)
+                torch.cuda.synchronize()
+                break
             if base_ms is None or wo_ms is None:
                 continue
             nbytes = sum(fam_bytes[fam](u) for ch in wl["chains"] for u in ch["units"]) if fam != "optimizer" else 34 * wl["n_params"]
