@@ -782,11 +782,11 @@ def _clone_part(part):
 
 
 class GraphedTrainStep:
-    """ONE training step of a model -- forward, backward, deferred weight gradients, fused AdamW, weight shadows -- as ONE hub-shaped
-    hipGraph, the micro-batch processed as ``chains`` part-batches on forked streams.
+    """ONE training step of a model -- forward, backward, deferred weight gradients, fused AdamW, weight shadows -- as ONE hipGraph:
+    a single list (``chains=1``, the default: what pays under a frozen base), or ``chains`` part-batches on forked streams in the hub shape.
 
         dp = moka_amd.parallel.attach(model, ...)                # the reference's get_peft_model(...) model
-        step = GraphedTrainStep(dp, lambda part: model(**part).loss, example_batch, chains=2,
+        step = GraphedTrainStep(dp, lambda part: model(**part).loss, example_batch,
                                 routing_fn=lambda part: MokaRouting.from_avt_masks([part["m_t"], part["m_v"], part["m_a"], part["m_q"]]))
         for batch in loader:
             loss = step(batch)                                   # copies the batch into the static inputs, replays
@@ -801,8 +801,10 @@ class GraphedTrainStep:
     * ``routing_fn(part) -> MokaRouting`` (or None for models without masked adapters): compiled from the batch's masks OUTSIDE the graph
       (one host read-back per part) and copied into the ``StaticRouting`` buffers the captured launches point at; inside the captured
       forward the adapters take that routing whatever masks they are handed (``routing.use_routing``);
-    * the chains are captured one after the other (the whole forward + backward of part 0, then part 1: an autograd pass cannot be
-      interleaved), which only orders the HUB's launches; at replay the chains run side by side;
+    * ``chains > 1``: the chains are captured one after the other (the whole forward + backward of part 0, then part 1: an autograd pass
+      cannot be interleaved), which only orders the HUB's launches; at replay the chains run side by side.  Beside a frozen base this does
+      not pay (a streaming adapter launch next to a hipBLASLt GEMM slows the GEMM by more than it hides) and at the 7B widths the capture
+      did not finish within minutes on ROCm 7.2: opt-in, tested on small stacks;
     * the AdamW coefficients are written by a live one-thread launch in front of every replay (``FlatAdamW.begin_step``), so learning-rate
       schedules work; gradient clipping does not exist in this mode (a bucket is updated before the global norm exists) and neither do
       collectives (RCCL inside a capture crashes the runtime): one GPU, or the live path of ``attach`` for N > 1;
@@ -811,7 +813,7 @@ class GraphedTrainStep:
       written in front of every replay: fresh keep masks every step, the same ones in the step's forward and backward.
     dp = None: the same capture around a model without ``attach`` (no optimizer, no hub work): what ``bench.py --e2e`` times the frozen base with."""
 
-    def __init__(self, dp, step_fn: Callable, example_batch, chains: int = 2, routing_fn: Optional[Callable] = None,
+    def __init__(self, dp, step_fn: Callable, example_batch, chains: int = 1, routing_fn: Optional[Callable] = None,
                  key_capacity: Optional[int] = None, warmup: int = 2, chain_priority: str = "normal", device=None):
         from .routing import StaticRouting
         self.dp, self.step_fn, self.routing_fn = dp, step_fn, routing_fn
