@@ -629,3 +629,44 @@ def test_lr_scheduler_drives_the_optimizer_inside_the_backward():
                 MokaFlatOptimizer(dp, max_grad_norm=1.0)
     err = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
     assert err <= 1e-5, err
+
+
+def test_graphed_train_step_on_the_vt_mirror_equals_the_live_loop():
+    """schedule.GraphedTrainStep around the VISUAL-TEXT mirror (modified_peft.Linear: two adapters, exact question index set, samples whose
+    question spans differ): the captured step on two alternating batches == the live attach() loop, and the static routing is the one
+    `from_vt_masks` compiles for every batch (the captured launches read it whatever masks the modules are handed)."""
+    from moka_amd.parallel import attach
+    from moka_amd.routing import MokaRouting
+    from moka_amd.schedule import GraphedTrainStep
+    dev = torch.device("cuda:0")
+
+    def batches(dims):
+        h, gout, (t, i, q), _ = _batch("vt", dims, dev)
+        q2 = torch.zeros_like(q)
+        q2[0, 50:55] = True
+        q2[1, 62:80] = True
+        return [{"h": h, "gout": gout, "t": t, "i": i, "q": q}, {"h": h.flip(0).contiguous(), "gout": gout, "t": t, "i": i, "q": q2}]
+
+    def loss_of(st):
+        return lambda p: (st(p["h"], p["t"], p["i"], p["q"])[0].float() * p["gout"].float()).sum() * (0.25 / p["h"].shape[0])
+
+    st_r, dims = _build("vt", dev)
+    bs = batches(dims)
+    dp_r = attach(st_r, n_buckets=2, lr=1e-2, weight_decay=0.01)
+    f_r, ref = loss_of(st_r), []
+    for k in range(4):
+        loss = f_r(bs[k % 2])
+        loss.backward()
+        dp_r.step()
+        ref.append(float(loss.detach()))
+    st, _ = _build("vt", dev)
+    dp = attach(st, n_buckets=2, lr=1e-2, weight_decay=0.01)
+    gs = GraphedTrainStep(dp, loss_of(st), bs[0], routing_fn=lambda p: MokaRouting.from_vt_masks(p["t"], p["i"], p["q"]))
+    got = [float(gs(bs[k % 2])) for k in range(4)]
+    torch.cuda.synchronize()
+    assert got[0] == ref[0]                                       # the same kernels on the same data before any update
+    for a_, b_ in zip(got, ref):
+        assert abs(a_ - b_) <= 2e-3 * abs(b_) + 1e-6, (got, ref)
+    err = ((dp.master - dp_r.master).norm() / dp_r.master.norm()).item()
+    assert err <= 2e-4, err
+    assert gs.rts[0].klen.tolist() == MokaRouting.from_vt_masks(bs[1]["t"], bs[1]["i"], bs[1]["q"]).klen.tolist()     # the last batch's routing sits in the static buffers
