@@ -806,8 +806,10 @@ class GraphedTrainStep:
       not pay (a streaming adapter launch next to a hipBLASLt GEMM slows the GEMM by more than it hides) and at the 7B widths the capture
       did not finish within minutes on ROCm 7.2: opt-in, tested on small stacks;
     * the AdamW coefficients are written by a live one-thread launch in front of every replay (``FlatAdamW.begin_step``), so learning-rate
-      schedules work; gradient clipping does not exist in this mode (a bucket is updated before the global norm exists) and neither do
-      collectives (RCCL inside a capture crashes the runtime): one GPU, or the live path of ``attach`` for N > 1;
+      schedules work; gradient clipping does not exist in this mode (a bucket is updated before the global norm exists);
+    * N > 1 (``attach`` under an initialised process group): collectives cannot ride inside a capture (RCCL crashes the runtime), so the graph
+      ends with the LOCAL gradient and ONE all-reduce of the flat buffer + the fused AdamW + the shadow rewrite follow it live -- the
+      gradient sum is not hidden behind the backward in this mode (the live ``attach`` path overlaps it bucket by bucket);
     * lora_dropout: the per-call seeds are drawn at capture time and frozen with the launch arguments; what varies per replay is the device
       word every dropout kernel folds into its seed (``moka_opts.seed_dev`` = ``dp.seed_epoch``), drawn from torch's CPU generator and
       written in front of every replay: fresh keep masks every step, the same ones in the step's forward and backward.
@@ -830,9 +832,10 @@ class GraphedTrainStep:
         if dp is not None:
             if dp.optimizer is None:
                 raise ValueError("GraphedTrainStep needs attach(..., optimizer=True): the fused AdamW slices are part of the captured step")
-            if dp.bucket.comm:
-                raise ValueError("GraphedTrainStep: collectives cannot be captured (RCCL inside a stream capture crashes the runtime); "
-                                 "use the live path of attach() for N > 1")
+        # N > 1: collectives cannot be captured (RCCL inside a stream capture crashes the runtime), so the graph ends with the LOCAL gradient
+        # in the flat buffer; the all-reduce of the whole buffer and the fused AdamW + shadow rewrite follow it live (three launches + one
+        # collective per step: the gradient sum is not hidden behind the backward here -- 306 MB at the 7B widths, ~1-3 ms of a ~330 ms step)
+        self.opt_in_graph = dp is not None and not dp.bucket.comm
         self.parts = [_clone_part(p) for p in _split_batch(example_batch, self.sizes)]
         self.rts = [StaticRouting(routing_fn(p), key_capacity) for p in self.parts] if routing_fn is not None else [None] * self.n
         self.pri = -1 if chain_priority == "high" else 0
@@ -846,7 +849,7 @@ class GraphedTrainStep:
         ev.record(torch.cuda.current_stream(self.dev))                 # (the chain's stream: its in-chain gradients of the layer are in front of it)
         evs = self._reports.setdefault(l, [])
         evs.append(ev)
-        if len(evs) == self.n and dp.bucket.is_bucket_first(l):
+        if self.opt_in_graph and len(evs) == self.n and dp.bucket.is_bucket_first(l):
             if self.hub != torch.cuda.current_stream(self.dev):      # (a one-chain capture is a single list: the reports are in stream order already)
                 for e_ in evs:
                     self.hub.wait_event(e_)
@@ -893,6 +896,8 @@ class GraphedTrainStep:
         import time
         best = None
         self.capture_log = []
+        if self.dp is not None and not self.opt_in_graph:
+            tries = 1                            # (N > 1: every timed replay is a collective; the ranks must not disagree on how many there are)
         for attempt in range(max(1, int(tries))):
             graph, hc, loss, live_ms = self._capture_once()
             self.graph, self._hc, self.loss = graph, hc, loss
@@ -963,7 +968,7 @@ class GraphedTrainStep:
                 if not hc.single:
                     for st in hc.branch:
                         hc.cur.wait_stream(st)
-                if dp is not None:
+                if dp is not None and self.opt_in_graph:
                     # whatever no bucket hook covered (parameters outside the decoder stack, the first layer when its input carries no
                     # gradient): behind every chain, on the hub
                     done, pos, n_all = sorted(dp._opt_done), 0, dp.bucket.flat.numel()
@@ -996,10 +1001,17 @@ class GraphedTrainStep:
                     dst.copy_(src, non_blocking=True)
                 if self.rts[c] is not None:
                     self.rts[c].load(self.routing_fn(new[c]))
-        if self.dp is not None:
-            if self.dp.seed_epoch is not None:
+        dp = self.dp
+        if dp is not None:
+            if dp.seed_epoch is not None:
                 from .functional import draw_seed
-                self.dp.seed_epoch.fill_(draw_seed())    # the device part of every dropout seed: this replay's masks (torch.manual_seed controls it)
-            self.dp.optimizer.begin_step()       # this step's coefficients (lr / betas of NOW), a one-thread launch in front of the replay
+                dp.seed_epoch.fill_(draw_seed())         # the device part of every dropout seed: this replay's masks (torch.manual_seed controls it)
+            if self.opt_in_graph:
+                dp.optimizer.begin_step()                # this step's coefficients (lr / betas of NOW), a one-thread launch in front of the replay
         self.graph.replay()
+        if dp is not None and not self.opt_in_graph:
+            import torch.distributed as dist
+            dist.all_reduce(dp.bucket.flat, group=dp.bucket.group)      # (stream-ordered behind the replay; the optimizer kernel averages)
+            dp.optimizer.step(grad_scale=1.0 / dp.bucket.world, zero_grad=True)
+            dp.refresh_shadows()
         return self.loss

@@ -670,3 +670,59 @@ def test_graphed_train_step_on_the_vt_mirror_equals_the_live_loop():
     err = ((dp.master - dp_r.master).norm() / dp_r.master.norm()).item()
     assert err <= 2e-4, err
     assert gs.rts[0].klen.tolist() == MokaRouting.from_vt_masks(bs[1]["t"], bs[1]["i"], bs[1]["q"]).klen.tolist()     # the last batch's routing sits in the static buffers
+
+
+def _graph_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moka_amd.parallel import attach
+    from moka_amd.routing import MokaRouting
+    from moka_amd.schedule import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    h, gout, (masks,), sl = None, None, (None,), None
+    outs = []
+    for graphed in (False, True):
+        st, dims = _build("avt", dev)
+        dp = attach(st, n_buckets=2, lr=1e-2, weight_decay=0.01)
+        h, gout, (masks,), sl = _batch("avt", dims, dev)
+        if not graphed:                                        # the live loop of the same rank: bucketed all-reduce behind the backward, one fused AdamW
+            for _ in range(3):
+                _run(st, dp, h[rank:rank + 1], gout[rank:rank + 1], sl(rank, rank + 1), 0.5)
+                dp.step()
+        else:
+            mine = {"h": h[rank:rank + 1], "gout": gout[rank:rank + 1], **{"m%d" % k: m[rank:rank + 1] for k, m in enumerate(masks)}}
+            gs = GraphedTrainStep(dp, lambda p: (st(p["h"], [p["m0"], p["m1"], p["m2"], p["m3"]])[0].float() * p["gout"].float()).sum() * 0.5, mine,
+                                  routing_fn=lambda p: MokaRouting.from_avt_masks([p["m0"], p["m1"], p["m2"], p["m3"]]))
+            assert gs.opt_in_graph is False and len(gs.capture_log) == 1
+            for _ in range(3):
+                gs(mine)
+        torch.cuda.synchronize()
+        outs.append((dp.master.cpu().numpy(), dp.optimizer.t))
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_train_step_under_two_ranks_sums_the_gradient_behind_the_replay():
+    """GraphedTrainStep with collectives on (two gloo ranks on the one GPU, one sample each): RCCL cannot ride inside a capture, so the graph ends
+    with the local gradient and ONE all-reduce of the flat buffer + the fused AdamW follow it live; both ranks end with the same parameters, and
+    those are the parameters of the LIVE attach() loop of the same two ranks (bucketed all-reduce behind the backward)."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_graph_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (live0, t_l), (graph0, t_g) = got[0]
+    (live1, _), (graph1, _) = got[1]
+    assert t_l == t_g == 3 and (graph0 == graph1).all() and (live0 == live1).all()
+    a_, b_ = torch.from_numpy(graph0), torch.from_numpy(live0)
+    err = ((a_ - b_).norm() / b_.norm()).item()
+    assert err <= 1e-5, err                                    # the same arithmetic: only the order of the fp32 atomics differs
