@@ -651,7 +651,9 @@ def main():
         args.defer_da = "unit" if (args.chains > 1 and args.graph != "off") else "layer"
     args.hub = args.graph != "off" and (args.graph_topology == "hub" or args.chains > 1)
     if args.chain_priority == "auto":
-        args.chain_priority = "high" if args.graph == "all" else "normal"
+        # (rank pad 64, one chain + side stream: every launch fills the chip, the side stream's dA_m / dB launches are 13 ms of a 78 ms step, and a
+        #  high-priority chain only delays them: normal 77.37 / 77.52 against high 78.05 / 78.00 ms, two same-box pairs, tools/experiments/r06/run_j.sh)
+        args.chain_priority = "high" if (args.graph == "all" and args.rank <= 32) else "normal"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) under torch.distributed.run, exactly
