@@ -69,6 +69,8 @@ def synthetic_layout(S):
     Returns (tok_mod int64[S] with 0 = text, 1 = image, 2 = audio; question bool[S])."""
     k = S / 2048.0
     n_pre, n_img, n_mid, n_aud, n_q = int(16 * k), int(256 * k), int(16 * k), int(128 * k), int(64 * k)
+    if os.environ.get("MOKA_BENCH_LAYOUT") == "aligned":       # diagnostics only (tools/experiments): the same spans, every boundary on a multiple of 128 tokens
+        n_pre, n_mid, n_img, n_aud = 0, 0, (n_img + 127) // 128 * 128, (n_aud + 127) // 128 * 128
     tok = torch.zeros(S, dtype=torch.int64)
     q = torch.zeros(S, dtype=torch.bool)
     p = n_pre

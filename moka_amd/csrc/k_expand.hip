@@ -603,18 +603,23 @@ __global__ void __launch_bounds__(512, 4) moka_yt_kernel(const ExpandBatch ab, i
 
 // ------------------------------------------------------------------------------------------
 // E (rank pad 64, one projection): dx += mask o (dh . A_mod(t)) in the token-owning form of moka_yt_kernel -- the same walk (128 tokens per
-// workgroup, the chunk's 16 KB of A^T staged in LDS one chunk ahead, ~110 registers, four waves per SIMD), once per MODALITY of the
-// workgroup's token run (block uniform; one, except on span boundaries): a walk stages that modality's weights, the waves that hold none of
-// its tokens only help staging, and a lane -- one token, eight consecutive columns -- adds and stores only if its token has the walk's
-// modality, so every dx element is still read, added to and rounded exactly once.  The product passes the dropout mask of x.
+// workgroup, the chunk's 16 KB of A^T staged in LDS one chunk ahead, ~110 registers, four waves per SIMD).  ONE walk whatever the token run
+// holds: the weights of the run's lowest modality are staged a chunk ahead as in moka_yt_kernel, those of the other modalities of the run
+// (span boundaries only: 3 of 32 token blocks of the bench layout) go into further 16 KB slots behind the chunk's barrier, and a wave takes
+// the slot of its 16 tokens' modality (a tile that straddles a span boundary runs the MFMAs once per modality it holds and selects per
+// lane).  A lane -- one token, eight consecutive columns -- reads, adds to and rounds every dx element exactly once.  The product passes
+// the dropout mask of x.
+// (Until round 6 the kernel walked its columns once per modality of the run: the launches are one round of workgroups, so the few
+// two-walk workgroups set the launch time -- 13B widths, 2 x 4096 tokens: o 70.5 us with the bench layout against 47.4 us text only, down
+// 175.9 against 112.6.)
 // Replaces moka_expand_kernel<64, 4, false, 1, 2, true> (256 registers, one wave per SIMD: 13B widths, dx of o / down 2.7 TB/s).
 // ------------------------------------------------------------------------------------------
 template <int RP>
 __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;
-    constexpr int PER = NF * 64 / 512;
-    bf16x8* wl = (bf16x8*)smem;                                              // [NQ][2][KH][64]
+    constexpr int PER = NF * 64 / 512, SLOT = NF * 64;                       // 16-byte fragments per thread / per modality slot
+    bf16x8* wl = (bf16x8*)smem;                                              // [slot][NQ][2][KH][64]
     __shared__ unsigned s_wpm[8];
     const ExpandArgs& a = ab.z[0];
     const uint2 ep = drop_epoch(a.drop);
@@ -641,6 +646,7 @@ __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
     };
+    issue_o(oA, ch0);                                                        // the dx stream starts before anything else (every wave: no load is conditional)
     bf16x8 bh[KH], bl[KH];
     {
         const unsigned char* prp = (const unsigned char*)a.pack + (size_t)t * (2 * RP * 2);
@@ -660,90 +666,112 @@ __global__ void __launch_bounds__(512, 4) moka_dxt_kernel(const ExpandBatch ab, 
     if (pmB == 0) return;                                                    // a run of padding only (block uniform)
     const unsigned trow = (unsigned)t;
     const float dsc = a.drop.thr ? a.drop.inv_keep : 1.f;
+    const int m0 = __builtin_ctz(pmB);                                       // slot 0: the run's lowest modality; slot s: its s-th
+    const bool one = (pm & (pm - 1u)) == 0;                                  // wave uniform: my 16 tokens have one modality (or none)
+    const int sw = pm ? __builtin_popcount(pmB & ((1u << __builtin_ctz(pm)) - 1u)) : 0;     // ... whose slot this is
+    const bool store = valid && mrow < a.M;
 
-    unsigned rest = pmB;
-    while (rest) {                                                           // block uniform: one walk per modality of the run
-        const int m = __builtin_ctz(rest);
-        rest &= rest - 1;
-        const bool wmine = (pm >> m) & 1u;                                   // wave uniform: some of my 16 tokens have this modality
-        const bool mine = valid && mrow == m;
-        const unsigned char* wm = a.W[0] + (size_t)m * a.C * RP * 2;         // (the shadows of the modalities follow each other)
-        bf16x8 wp[PER];
-        auto wload = [&](int ch) {
-            const int cb = ch * CWK;
+    auto wfrag = [&](int m, int ch, int u) {
+        const int e = tid + 512 * u;                                         // (q, p, kh, lane)
+        const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
+        const int c = min(ch * CWK + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);   // columns >= C are never stored
+        const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
+        return *(const bf16x8*)(a.W[0] + (((size_t)m * a.C + c) * RP + k0) * 2);                    // (the shadows of the modalities follow each other)
+    };
+    bf16x8 wp[PER];
+    auto wload = [&](int ch) {
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int e = tid + 512 * u;                                 // (q, p, kh, lane)
-                const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
-                const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);   // columns >= C are never stored
-                const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
-                wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + k0) * 2);
+        for (int u = 0; u < PER; ++u) wp[u] = wfrag(m0, ch, u);
+    };
+    auto product = [&](int slot, int q, f32x4 (&d)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const bf16x8 wf = wl[(size_t)slot * SLOT + ((size_t)q * 2 + p) * KH * 64 + kh * 64 + lane];
+                d[p] = MFMA16(wf, bh[kh], d[p]);
+                if (RP != 16) d[p] = MFMA16(wf, bl[kh], d[p]);
             }
-        };
-        auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
-            const int cb = ch * CWK;
-            if (wmine) issue_o(onext, ch + 1);
-            __syncthreads();                                                 // the previous chunk's fragments are no longer read
-#pragma unroll
-            for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
-            __syncthreads();
-            if (ch + 1 < ch1) wload(ch + 1);
-            if (!wmine) return;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                f32x4 d[2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kh = 0; kh < KH; ++kh) {
-                        const bf16x8 wf = wl[((size_t)q * 2 + p) * KH * 64 + kh * 64 + lane];
-                        d[p] = MFMA16(wf, bh[kh], d[p]);
-                        if (RP != 16) d[p] = MFMA16(wf, bl[kh], d[p]);
-                    }
-                }
-                if (cb + 32 * q >= a.C) continue;                            // C % 32 == 0 (block uniform)
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
-                if (a.drop.thr) {
-                    const KeepMask keep = drop_keep8(a.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) {
-                        const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
-                        v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
-                        v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
-                    }
-                }
-                union { bf16x8 b; unsigned u[4]; } ou, res;
-                ou.b = o[q];
-#pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2)
-                    res.u[w2] = f2bf_pk(fmaf(v[2 * w2], dsc, __uint_as_float(ou.u[w2] << 16)), fmaf(v[2 * w2 + 1], dsc, __uint_as_float(ou.u[w2] & 0xffff0000u)));
-                if (mine) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
-            }
-        };
-        if (wmine) issue_o(oA, ch0);
-        wload(ch0);
-        for (int ch = ch0; ch < ch1; ch += 2) {
-            step(oA, oB, ch);
-            if (ch + 1 < ch1) step(oB, oA, ch + 1);
         }
-        __syncthreads();                                                     // the last chunk's fragments are no longer read (next walk restages)
+    };
+    auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+        const int cb = ch * CWK;
+        issue_o(onext, ch + 1);
+        __syncthreads();                                                     // the previous chunk's fragments are no longer read
+#pragma unroll
+        for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+        {                                                                    // block uniform: the other modalities of the run, not a chunk ahead
+            int slot = 1;
+            for (unsigned rest = pmB & (pmB - 1u); rest; rest &= rest - 1u, ++slot) {
+                const int m = __builtin_ctz(rest);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) wl[(size_t)slot * SLOT + tid + 512 * u] = wfrag(m, ch, u);
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < ch1) wload(ch + 1);
+        if (!pm) return;                                                     // a tile of padding
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 d[2];
+            if (one) product(sw, q, d);
+            else {                                                           // a tile across a span boundary: once per modality it holds
+                d[0] = d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                int slot = 0;
+                for (unsigned rest = pmB; rest; rest &= rest - 1u, ++slot) {
+                    const int m = __builtin_ctz(rest);
+                    if (!((pm >> m) & 1u)) continue;
+                    f32x4 dm[2];
+                    product(slot, q, dm);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[p][e] = (mrow == m) ? dm[p][e] : d[p][e];
+                }
+            }
+            if (cb + 32 * q >= a.C) continue;                                // C % 32 == 0 (block uniform)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
+            if (a.drop.thr) {
+                const KeepMask keep = drop_keep8(a.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
+                    v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
+                    v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
+                }
+            }
+            union { bf16x8 b; unsigned u[4]; } ou, res;
+            ou.b = o[q];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)
+                res.u[w2] = f2bf_pk(fmaf(v[2 * w2], dsc, __uint_as_float(ou.u[w2] << 16)), fmaf(v[2 * w2 + 1], dsc, __uint_as_float(ou.u[w2] & 0xffff0000u)));
+            if (store) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+        }
+    };
+    wload(ch0);
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        step(oA, oB, ch);
+        if (ch + 1 < ch1) step(oB, oA, ch + 1);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// E (rank pads 32 / 64, G > 1): moka_dxg_kernel in the lean form of moka_dxt_kernel -- one walk over the workgroup's columns per MODALITY of its
-// token run (a lane stores only if its token has the walk's modality, so the fp32 sum over the G projections of a 32-column block lives in 8
-// registers instead of a [4][8] array that has to survive the modality loop), the G products of a block formed back to back.
+// E (rank pads 32 / 64, G > 1): moka_dxg_kernel in the lean form of moka_dxt_kernel -- ONE walk over the workgroup's columns, the G products of a
+// 32-column block formed back to back into one fp32 sum of 8 registers.  The weights of the token run's lowest modality are staged a chunk ahead;
+// those of its other modalities (span boundaries only) go into further slots of G x 8 / 16 KB behind the chunk's barrier, and a wave takes the slot of
+// its 16 tokens' modality (a tile across a span boundary: once per modality it holds, selected per lane).
+// (Until round 6: one walk per modality of the run -- 7B widths, r = 32, 4096 tokens per launch: q+k+v 36.5 us with the bench layout against 28.4 us
+// with every span boundary on a multiple of 128 tokens, gate+up 32.3 against 20.9.)
 // ------------------------------------------------------------------------------------------
 template <int RP, int G>
 __global__ void __launch_bounds__(512, RP == 16 ? 4 : 3) moka_dxgt_kernel(const ExpandBatch ab, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KH = (RP + 31) / 32, NQ = 4, CWK = NQ * 32, NF = NQ * 2 * KH;
-    constexpr int PG = NF * 64 / 512, PER = G * PG;
-    bf16x8* wl = (bf16x8*)smem;                                              // [G][NQ][2][KH][64]
+    constexpr int PG = NF * 64 / 512, PER = G * PG, SLOT = G * NF * 64;      // 16-byte fragments per thread and projection / per thread / per modality slot
+    bf16x8* wl = (bf16x8*)smem;                                              // [slot][G][NQ][2][KH][64]
     __shared__ unsigned s_wpm[8];
     const ExpandArgs& a = ab.z[0];
     const uint2 ep = drop_epoch(a.drop);
@@ -770,6 +798,7 @@ __global__ void __launch_bounds__(512, RP == 16 ? 4 : 3) moka_dxgt_kernel(const 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) o[q] = *(const bf16x8*)(orow0 + (size_t)min(cb + 32 * q, a.C - 32) * 2);
     };
+    issue_o(oA, ch0);                                                        // the dx stream starts before anything else (every wave: no load is conditional)
     bf16x8 bh[G][KH], bl[G][KH];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
@@ -789,89 +818,109 @@ __global__ void __launch_bounds__(512, RP == 16 ? 4 : 3) moka_dxgt_kernel(const 
     for (int w = 0; w < 8; ++w) pmB |= s_wpm[w];
     if (pmB == 0) return;
     unsigned trow = (unsigned)t;
+    const int m0 = __builtin_ctz(pmB);                                       // slot 0: the run's lowest modality; slot s: its s-th
+    const bool one = (pm & (pm - 1u)) == 0;                                  // wave uniform: my 16 tokens have one modality (or none)
+    const int sw = pm ? __builtin_popcount(pmB & ((1u << __builtin_ctz(pm)) - 1u)) : 0;     // ... whose slot this is
+    const bool store = valid && mrow < a.M;
 
-    unsigned rest = pmB;
-    while (rest) {                                                           // block uniform: one walk per modality of the run
-        const int m = __builtin_ctz(rest);
-        rest &= rest - 1;
-        const bool wmine = (pm >> m) & 1u;
-        const bool mine = valid && mrow == m;
-        bf16x8 wp[PER];
-        auto wload = [&](int ch) {
-            const int cb = ch * CWK;
+    auto wfrag = [&](int m, int ch, int u) {
+        const unsigned char* wm = ab.z[u / PG].W[0] + (size_t)m * a.C * RP * 2;
+        const int e = tid + 512 * (u % PG);
+        const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
+        const int c = min(ch * CWK + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);
+        const int k0 = (RP == 16) ? 8 * ((ln >> 4) & 1) : 32 * kh + 8 * (ln >> 4);
+        return *(const bf16x8*)(wm + ((size_t)c * RP + k0) * 2);
+    };
+    bf16x8 wp[PER];
+    auto wload = [&](int ch) {
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const unsigned char* wm = ab.z[u / PG].W[0] + (size_t)m * a.C * RP * 2;
-                const int e = tid + 512 * (u % PG);
-                const int ln = e & 63, kh = (e >> 6) % KH, p = ((e >> 6) / KH) & 1, q = (e >> 6) / (2 * KH);
-                const int c = min(cb + 32 * q + 8 * ((ln & 15) >> 2) + 4 * p + (ln & 3), a.C - 1);
-                if constexpr (RP == 16) wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + 8 * ((ln >> 4) & 1)) * 2);
-                else wp[u] = *(const bf16x8*)(wm + ((size_t)c * RP + 32 * kh + 8 * (ln >> 4)) * 2);
+        for (int u = 0; u < PER; ++u) wp[u] = wfrag(m0, ch, u);
+    };
+    auto product = [&](int slot, int gi, int q, f32x4 (&d)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const bf16x8 wf = wl[(size_t)slot * SLOT + (((size_t)gi * NQ + q) * 2 + p) * KH * 64 + kh * 64 + lane];
+                d[p] = MFMA16(wf, bh[gi][kh], d[p]);
+                if constexpr (RP != 16) d[p] = MFMA16(wf, bl[gi][kh], d[p]);
             }
-        };
-        auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
-            const int cb = ch * CWK;
-            if (wmine) issue_o(onext, ch + 1);
-            __syncthreads();
+        }
+    };
+    auto step = [&](bf16x8 (&o)[NQ], bf16x8 (&onext)[NQ], int ch) {
+        const int cb = ch * CWK;
+        issue_o(onext, ch + 1);
+        __syncthreads();
 #pragma unroll
-            for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
-            __syncthreads();
-            if (ch + 1 < ch1) wload(ch + 1);
-            if (!wmine) return;
-            asm volatile("" : "+v"(trow));                                   // (the masks are made where they are used: see moka_dxg_kernel)
+        for (int u = 0; u < PER; ++u) wl[tid + 512 * u] = wp[u];
+        {                                                                    // block uniform: the other modalities of the run, not a chunk ahead
+            int slot = 1;
+            for (unsigned rest = pmB & (pmB - 1u); rest; rest &= rest - 1u, ++slot) {
+                const int m = __builtin_ctz(rest);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float sum[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum[e] = 0.f;
-#pragma unroll
-                for (int gi = 0; gi < G; ++gi) {
-                    const ExpandArgs& ag = ab.z[gi];
-                    f32x4 d[2];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        d[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kh = 0; kh < KH; ++kh) {
-                            const bf16x8 wf = wl[(((size_t)gi * NQ + q) * 2 + p) * KH * 64 + kh * 64 + lane];
-                            d[p] = MFMA16(wf, bh[gi][kh], d[p]);
-                            if constexpr (RP != 16) d[p] = MFMA16(wf, bl[gi][kh], d[p]);
-                        }
-                    }
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
-                    float dsc = 1.f;
-                    if (ag.drop.thr) {
-                        const KeepMask keep = drop_keep8(ag.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
-                        dsc = ag.drop.inv_keep;
-#pragma unroll
-                        for (int w2 = 0; w2 < 4; ++w2) {
-                            const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
-                            v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
-                            v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sum[e] = fmaf(v[e], dsc, sum[e]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (cb + 32 * q >= a.C) continue;
-                union { bf16x8 b; unsigned u[4]; } ou, res;
-                ou.b = o[q];
-#pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2)
-                    res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[2 * w2 + 1]);
-                if (mine) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+                for (int u = 0; u < PER; ++u) wl[(size_t)slot * SLOT + tid + 512 * u] = wfrag(m, ch, u);
             }
-        };
-        if (wmine) issue_o(oA, ch0);
-        wload(ch0);
-        for (int ch = ch0; ch < ch1; ch += 2) {
-            step(oA, oB, ch);
-            if (ch + 1 < ch1) step(oB, oA, ch + 1);
         }
         __syncthreads();
+        if (ch + 1 < ch1) wload(ch + 1);
+        if (!pm) return;                                                     // a tile of padding
+        asm volatile("" : "+v"(trow));                                       // (the masks are made where they are used: see moka_dxg_kernel)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float sum[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
+                const ExpandArgs& ag = ab.z[gi];
+                f32x4 d[2];
+                if (one) product(sw, gi, q, d);
+                else {                                                       // a tile across a span boundary: once per modality it holds
+                    d[0] = d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    int slot = 0;
+                    for (unsigned rest = pmB; rest; rest &= rest - 1u, ++slot) {
+                        const int m = __builtin_ctz(rest);
+                        if (!((pm >> m) & 1u)) continue;
+                        f32x4 dm[2];
+                        product(slot, gi, q, dm);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[p][e] = (mrow == m) ? dm[p][e] : d[p][e];
+                    }
+                }
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = d[e >> 2][e & 3];
+                float dsc = 1.f;
+                if (ag.drop.thr) {
+                    const KeepMask keep = drop_keep8(ag.drop, ep, trow * (unsigned)(a.C >> 3) + (unsigned)((cb + 32 * q) >> 3) + (unsigned)g);
+                    dsc = ag.drop.inv_keep;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const int mlo = __builtin_amdgcn_sbfe((int)keep.w[w2], 0, 16), mhi = (int)keep.w[w2] >> 16;
+                        v[2 * w2] = __int_as_float(__float_as_int(v[2 * w2]) & mlo);
+                        v[2 * w2 + 1] = __int_as_float(__float_as_int(v[2 * w2 + 1]) & mhi);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[e] = fmaf(v[e], dsc, sum[e]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cb + 32 * q >= a.C) continue;
+            union { bf16x8 b; unsigned u[4]; } ou, res;
+            ou.b = o[q];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)
+                res.u[w2] = f2bf_pk(__uint_as_float(ou.u[w2] << 16) + sum[2 * w2], __uint_as_float(ou.u[w2] & 0xffff0000u) + sum[2 * w2 + 1]);
+            if (store) *(bf16x8*)(orow0 + (size_t)(cb + 32 * q) * 2) = res.b;
+        }
+    };
+    wload(ch0);
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        step(oA, oB, ch);
+        if (ch + 1 < ch1) step(oB, oA, ch + 1);
     }
 }
 
@@ -1306,7 +1355,7 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
             int want = ((g_tune_expand_bpc > 0 ? g_tune_expand_bpc : 2) * num_cu() + ntb - 1) / ntb;
             want = want < 1 ? 1 : (want > nch ? nch : want);
             const int cpb = (nch + want - 1) / want;
-            constexpr size_t lds = (size_t)4 * 2 * 2 * 1024;
+            constexpr size_t lds = (size_t)MOKA_MAX_MOD * 4 * 2 * 2 * 1024;        // a 16 KB slot per modality of the token run
             ensure_lds((const void*)moka_dxt_kernel<64>, lds);
             hipLaunchKernelGGL((moka_dxt_kernel<64>), dim3((nch + cpb - 1) / cpb, ntb), dim3(512), lds, st, ab, cpb);
             return check_launch("moka_dxt_kernel");
@@ -1328,8 +1377,8 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
             else          { if (nz == 2) go(moka_dxg_kernel<32, 2>, (size_t)2 * 8 * 1024); else go(moka_dxg_kernel<32, 3>, (size_t)3 * 8 * 1024); }
             return check_launch("moka_dxg_kernel");
         }
-        if (RP == 64) { if (nz == 2) go(moka_dxgt_kernel<64, 2>, (size_t)2 * 16 * 1024); else go(moka_dxgt_kernel<64, 3>, (size_t)3 * 16 * 1024); }
-        else          { if (nz == 2) go(moka_dxgt_kernel<32, 2>, (size_t)2 * 8 * 1024); else go(moka_dxgt_kernel<32, 3>, (size_t)3 * 8 * 1024); }
+        if (RP == 64) { if (nz == 2) go(moka_dxgt_kernel<64, 2>, (size_t)MOKA_MAX_MOD * 2 * 16 * 1024); else go(moka_dxgt_kernel<64, 3>, (size_t)MOKA_MAX_MOD * 3 * 16 * 1024); }
+        else          { if (nz == 2) go(moka_dxgt_kernel<32, 2>, (size_t)MOKA_MAX_MOD * 2 * 8 * 1024); else go(moka_dxgt_kernel<32, 3>, (size_t)MOKA_MAX_MOD * 3 * 8 * 1024); }
         return check_launch("moka_dxgt_kernel");
     } else {                                             // can_group(): RP == 16 -- projections sharing dx: ONE read-modify-write pass
         // (the same kernel at rank pad 64: the G = 3 instance needs 250 VGPRs, one wave per SIMD, and lost: 45.8 -> 47.2 ms per backward pass;
@@ -1343,8 +1392,8 @@ static int launch_expand(const ExpandBatch& ab, int nz, int RP, hipStream_t st) 
             want = want < 1 ? 1 : (want > nch ? nch : want);
             const int cpb = (nch + want - 1) / want;
             const dim3 grid((nch + cpb - 1) / cpb, ntb);
-            if (nz == 2) { ensure_lds((const void*)moka_dxgt_kernel<16, 2>, (size_t)2 * 8 * 1024); hipLaunchKernelGGL((moka_dxgt_kernel<16, 2>), grid, dim3(512), (size_t)2 * 8 * 1024, st, ab, cpb); }
-            else { ensure_lds((const void*)moka_dxgt_kernel<16, 3>, (size_t)3 * 8 * 1024); hipLaunchKernelGGL((moka_dxgt_kernel<16, 3>), grid, dim3(512), (size_t)3 * 8 * 1024, st, ab, cpb); }
+            if (nz == 2) { ensure_lds((const void*)moka_dxgt_kernel<16, 2>, (size_t)MOKA_MAX_MOD * 2 * 8 * 1024); hipLaunchKernelGGL((moka_dxgt_kernel<16, 2>), grid, dim3(512), (size_t)MOKA_MAX_MOD * 2 * 8 * 1024, st, ab, cpb); }
+            else { ensure_lds((const void*)moka_dxgt_kernel<16, 3>, (size_t)MOKA_MAX_MOD * 3 * 8 * 1024); hipLaunchKernelGGL((moka_dxgt_kernel<16, 3>), grid, dim3(512), (size_t)MOKA_MAX_MOD * 3 * 8 * 1024, st, ab, cpb); }
             return check_launch("moka_dxgt_kernel");
         }
         if (nz == 2) launch_expand_t<16, 2, false, 2, 2>(ab, 1, st);

@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaBa
         // the fragments of the next chunk are requested (L2) before the current one is computed and go to LDS behind the barrier
         bf16x8 wp[NSLOT][G][NT * FR / 512];
         auto wload = [&](int ch) {
-            const int cbn = ch * KW, nkn = min(NKS, (a.C - cbn) >> 5);
+            const int cbn = ch * KW;
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl) {
                 const int m = sl ? m1 : m0;
@@ -915,8 +915,10 @@ __global__ void __launch_bounds__(512, G > 1 ? 2 : 4) moka_xwm_kernel(const XaBa
                     for (int u = 0; u < NT * FR / 512; ++u) {
                         const int e = tid + 512 * u;
                         const int ln = e & 63, ks = (e >> 6) % NKS, nt = e / FR;
-                        // rank rows >= r do not exist: clamp the row, the result rows are zeroed when the slice is written
-                        wp[sl][gi][u] = (ks < nkn) ? *(const bf16x8*)(a.A[gi][m] + ((size_t)min(nt * 16 + (ln & 15), a.r - 1) * a.C + cbn + 32 * ks + 8 * (ln >> 4)) * 2) : z8;
+                        // rank rows >= r do not exist: clamp the row, the result rows are zeroed when the slice is written; K steps past the width: clamp
+                        // the column -- their x fragments are zero -- so that NO load of the walk is conditional (a load behind a per-lane branch
+                        // makes every later wait of the kernel a vmcnt(0): the x stream then waits for the loads it has just issued)
+                        wp[sl][gi][u] = *(const bf16x8*)(a.A[gi][m] + ((size_t)min(nt * 16 + (ln & 15), a.r - 1) * a.C + min(cbn + 32 * ks + 8 * (ln >> 4), a.C - 8)) * 2);
                     }
             }
         };

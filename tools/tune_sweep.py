@@ -2,7 +2,8 @@ import os as _os
 _os.environ.setdefault("MOKA_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "moka_amd", "libmoka_hip_diag.so"))   # moka_tune: diagnostics build only
 #!/usr/bin/env python3
 """Time every C entry point at the bench shape (T = 8192, Llama-2-7B widths, r = 16, M = 3) under
-different diagnostic tuning settings (moka_tune).  Run on the GPU box; prints a table."""
+different diagnostic tuning settings (moka_tune).  Run on the GPU box; prints a table.
+env: B, S, R, DROP, WIDTHS="5120x5120,5120x13824,13824x5120", ONLY=<entry point substring>, SWEEP=0 (defaults only), MOKA_HIP_LIB=<library to time>."""
 import math
 import os
 import sys
@@ -23,7 +24,7 @@ DROP = 0.0
 def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    B, S, r, M = int(os.environ.get("B", 4)), 2048, int(os.environ.get("R", 16)), 3
+    B, S, r, M = int(os.environ.get("B", 4)), int(os.environ.get("S", 2048)), int(os.environ.get("R", 16)), 3
     global DROP
     DROP = float(os.environ.get("DROP", 0.0))
     T = B * S
@@ -99,7 +100,8 @@ def main():
 
     E = 2
     only = os.environ.get("ONLY")
-    for (d_in, d_out) in [(4096, 4096), (4096, 11008), (11008, 4096)]:
+    widths = [tuple(int(v) for v in w.split("x")) for w in os.environ.get("WIDTHS", "4096x4096,4096x11008,11008x4096").split(",")]
+    for (d_in, d_out) in widths:
         w = shapes(d_in, d_out)
         cs = calls(w)
         # make the rank-space inputs valid once
@@ -123,7 +125,7 @@ def main():
             base = timeit(fn)
             gb = algo[name] / (base * 1e-6) / 1e9 if algo[name] else 0
             print(f"{name:20s} default            {base:8.1f} us  {gb:7.0f} GB/s algorithmic")
-            for key, val in sweeps.get(name, []):
+            for key, val in ([] if os.environ.get("SWEEP") == "0" else sweeps.get(name, [])):
                 lib.moka_tune(key.encode(), val)
                 t = timeit(fn)
                 lib.moka_tune(key.encode(), 0)
