@@ -1304,10 +1304,13 @@ static int launch_yx(const YxBatch& fb, int nz, hipStream_t st) {
     // four (7B widths, 8192 tokens, cpb = 2 / 4 / 8 / 16 at 4096 columns: o 43.0 / 39.2 / 35.8 / 57.4 us, q+k+v 101.9 / 92.7 / 85.0 / 105.5;
     // gate+up 22 / 16 / 8 chunks per range: 149.6 / 169.2 / 161.1), more only where fewer tokens would leave CUs without a workgroup
     // ("yx_bpc": workgroups per CU instead; "yx_cpb": chunks per range)
-    int want = g_tune_yx_bpc > 0 ? (g_tune_yx_bpc * num_cu() + ntb * nz - 1) / (ntb * nz) : 4;
+    // rank pad 32: three workgroups per CU instead (r = 32, two chains of 4096 tokens, yx_bpc 0 / 2 / 3 / 4 / 6: 37.5 / 37.1 / 37.0 / 38.2 / 38.8 ms per step;
+    // r = 16 the same settings: 30.3 / 31.0 / 31.3 / 31.5 / 31.9 -- four ranges stay there)
+    const int bpc = g_tune_yx_bpc > 0 ? g_tune_yx_bpc : (RP == 32 ? 3 : 0);
+    int want = bpc > 0 ? (bpc * num_cu() + ntb * nz - 1) / (ntb * nz) : 4;
     // ("yx_fill" 1: never more than four ranges; 2: two ranges for single projections)
     if (g_tune_yx_fill == 2 && nz == 1) want = 2;
-    if (g_tune_yx_bpc <= 0 && g_tune_yx_fill == 0 && (long)want * ntb * nz < (long)num_cu()) want = (num_cu() + ntb * nz - 1) / (ntb * nz);
+    if (bpc <= 0 && g_tune_yx_fill == 0 && (long)want * ntb * nz < (long)num_cu()) want = (num_cu() + ntb * nz - 1) / (ntb * nz);
     want = want < 1 ? 1 : (want > nch ? nch : want);
     const int cpb = g_tune_yx_cpb > 0 ? g_tune_yx_cpb : (nch + want - 1) / want;
     constexpr size_t lds_w = (size_t)4 * 2 * ((RP + 31) / 32) * 1024, lds_p = (size_t)(8 * 2 * 16 + 64) * (RP + 1) * 4;
