@@ -53,6 +53,9 @@ def test_ksplit_covers_width(lib):
     assert lib.moka_ksplit_bwd(8192, 5120, 16) == 10 and lib.moka_ksplit_bwd(8192, 5120, 64) == 4 and lib.moka_ksplit_bwd(8192, 13824, 64) == 4
     assert lib.moka_ksplit_bwd(128, 5120, 64) == 20
     assert lib.moka_ksplit(8192, 4096, 32) == 8 and lib.moka_ksplit(8192, 11008, 32) == 11 and lib.moka_ksplit_bwd(8192, 11008, 32) == 22
+    # ... and at least two chunks per slice while that still gives every CU a workgroup (round 6: 4096-token launches wrote 16 slices per 4096 columns)
+    assert lib.moka_ksplit(4096, 4096, 32) == 8 and lib.moka_ksplit_group(4096, 4096, 32, 3) == 8 and lib.moka_ksplit(4096, 11008, 32) == 15
+    assert lib.moka_ksplit(2048, 4096, 32) == 16 and lib.moka_ksplit(4096, 5120, 64) == 10 and lib.moka_ksplit(4096, 13824, 64) == 18
     # passes over gy of moka_up_bwd: one up to rank 32 in bf16 storage, dB on its own beyond and in fp32 storage
     assert [lib.moka_up_bwd_passes(r, 0) for r in (4, 16, 32, 33, 64)] == [1, 1, 1, 2, 2] and lib.moka_up_bwd_passes(16, 1) == 2
     assert lib.moka_up_bwd_passes(65, 0) < 0 and lib.moka_up_bwd_passes(16, 7) < 0
